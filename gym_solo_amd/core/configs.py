@@ -1,0 +1,108 @@
+"""Environment configuration — batched counterpart of gym_solo/core/configs.py:8-38.
+
+Every field of the reference's ``Solo8BaseConfig`` is kept with the same name, default and
+"dataclass field vs plain class attribute" status (tests mutate ``max_motor_rotation`` on the
+instance, gym_solo/envs/test_solo8v2vanilla.py:110).  Fields below the marker are build
+extensions consumed by the HIP engine.
+"""
+from dataclasses import dataclass
+from typing import Tuple
+
+import numpy as np
+
+from gym_solo_amd import abi
+
+
+@dataclass
+class Solo8BaseConfig:
+  dt: float = 1e-3
+  # Max torque supplied by the motors
+  motor_torque_limit: float = 2
+
+  robot_start_pos: Tuple[float] = (0., 0., 0.5)
+  robot_start_orientation_euler: Tuple[float] = (0., 0., 0.)
+  gravity: Tuple[float] = (0., 0., -9.81)
+
+  max_motor_rotation = 2 * np.pi
+
+  linear_damping: float = .04
+  angular_damping: float = .04
+  restitution: float = 0.
+  lateral_friction: float = 0.5
+
+  # render_* fields of the reference (configs.py:26-34) configure the pybullet camera; rendering
+  # is out of scope for the batched engine — kept so configs stay swappable.
+  render_width: int = 369
+  render_height: int = 369
+  render_fov: int = 80
+  render_aspect: float = render_width / render_height
+  render_pos = [0, 0, .2]
+  render_cam_distance = 1
+  render_yaw = 0.
+  render_pitch = -20.
+  render_roll = 0.
+
+  # ---- build extensions (not in the reference) -------------------------------------
+  num_envs: int = 1
+  device: int = 0
+  dtype: str = 'float32'          # arithmetic type of the engine: 'float32' | 'float64'
+  solver_iterations: int = 50     # Bullet default [recalled]
+  motor_kp: float = 0.1           # pybullet POSITION_CONTROL default positionGain [recalled]
+  motor_kd: float = 1.0           # pybullet POSITION_CONTROL default velocityGain [recalled]
+  contact_erp: float = 0.2
+  contact_margin: float = 0.005
+  settle_steps: int = 500         # gym_solo/envs/solo8v2vanilla.py:130
+  auto_reset: bool = False
+
+  @property
+  def urdf(self):
+    # The reference resolves a packaged URDF (configs.py:36-38); the batched engine takes
+    # compiled model constants instead (gym_solo_amd/model.py).
+    raise NotImplementedError('the batched engine uses gym_solo_amd.model.Solo8Model')
+
+
+def euler_to_quat(euler) -> Tuple[float, float, float, float]:
+  """pybullet.getQuaternionFromEuler: xyzw from roll, pitch, yaw (solo8v2vanilla.py:153)."""
+  r, p, y = (float(e) for e in euler)
+  cr, sr = np.cos(r / 2), np.sin(r / 2)
+  cp, sp = np.cos(p / 2), np.sin(p / 2)
+  cy, sy = np.cos(y / 2), np.sin(y / 2)
+  return (sr * cp * cy - cr * sp * sy,
+          cr * sp * cy + sr * cp * sy,
+          cr * cp * sy - sr * sp * cy,
+          cr * cp * cy + sr * sp * sy)
+
+
+def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
+                  normalize_actions=False) -> abi.SoloConfig:
+  c = abi.SoloConfig()
+  c.abi_version = abi.ABI_VERSION
+  if config.dtype not in ('float32', 'float64'):
+    raise ValueError('dtype must be float32 or float64: {}'.format(config.dtype))
+  c.dtype = abi.F32 if config.dtype == 'float32' else abi.F64
+  if not config.dt:
+    raise ValueError('the batched engine needs a fixed timestep (dt)')
+  c.dt = float(config.dt)
+  for a in range(3):
+    c.gravity[a] = float(config.gravity[a])
+    c.start_pos[a] = float(config.robot_start_pos[a])
+  c.motor_torque_limit = float(config.motor_torque_limit)
+  c.motor_kp = float(config.motor_kp)
+  c.motor_kd = float(config.motor_kd)
+  c.linear_damping = float(config.linear_damping)
+  c.angular_damping = float(config.angular_damping)
+  c.lateral_friction = float(config.lateral_friction)
+  c.restitution = float(config.restitution)
+  c.contact_erp = float(config.contact_erp)
+  c.contact_margin = float(config.contact_margin)
+  c.solver_iterations = int(config.solver_iterations)
+  c.settle_steps = int(config.settle_steps)
+  q = euler_to_quat(config.robot_start_orientation_euler)
+  for a in range(4):
+    c.start_quat[a] = q[a]
+  if starting_joint_pos is not None:
+    for j, name in enumerate(joint_ordering):
+      c.settle_targets[j] = float(starting_joint_pos[name])
+  c.action_scale = float(config.max_motor_rotation) if normalize_actions else 1.0
+  c.auto_reset = 1 if config.auto_reset else 0
+  return c

@@ -1,0 +1,255 @@
+/* solo_engine.h — C-ABI of the MI355X batched Solo8 physics engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of WPI-MMR/gym_solo:
+ * the per-step pybullet call sequence issued by Solo8VanillaEnv.step()
+ *   client.setJointMotorControlArray(...)   gym_solo/envs/solo8v2vanilla.py:87-90
+ *   client.stepSimulation()                 gym_solo/envs/solo8v2vanilla.py:91
+ *   client.getBasePositionAndOrientation    gym_solo/core/obs.py:268, rewards.py:232,264,370
+ *   client.getBaseVelocity                  gym_solo/core/obs.py:273, rewards.py:334
+ *   client.getJointState                    gym_solo/core/obs.py:354, rewards.py:298
+ * plus the obs/reward/termination reductions (obs.py:130-159, rewards.py:104-118,
+ * termination.py:38-50) and the reset/settle loop (solo8v2vanilla.py:104-143),
+ * for N independent robots at once.
+ *
+ * The reference binds pybullet through `pybullet_utils.bullet_client.BulletClient`
+ * (solo8_base_env.py:34-35).  A maintainer replaces that object by a ctypes stub
+ * over this header; no torch / C++ type crosses the boundary:
+ * plain pointers (device pointers are `void*`), sizes and PODs only.
+ *
+ * Conventions
+ *  - return value: 0 = SOLO_OK, negative = SoloStatus error; text via
+ *    solo_engine_last_error().
+ *  - one engine handle per GPU / process; NOT thread-safe per handle; all work
+ *    is enqueued on the caller-provided HIP stream (NULL = default stream), no
+ *    hidden device synchronisation except where stated.
+ *  - device buffers are owned by the engine and exposed zero-copy through
+ *    SoloStateView; pointers passed IN (actions, masks, params) are borrowed.
+ *  - `real` below means float (dtype SOLO_F32) or double (SOLO_F64) as chosen at
+ *    create time; every device buffer of the engine uses that type.
+ */
+#ifndef SOLO_ENGINE_H_
+#define SOLO_ENGINE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOLO_ABI_VERSION 1
+
+/* ---- fixed Solo8 dimensions -------------------------------------------- */
+#define SOLO_NUM_LEGS 4
+#define SOLO_NUM_DOF 8        /* actuated revolute joints (HFE, KFE per leg)          */
+#define SOLO_NUM_JOINTS 12    /* pybullet joint count incl. 4 fixed ANKLE joints:      */
+                              /* gym_solo/envs/test_solo8v2vanilla.py:57               */
+#define SOLO_NUM_BODIES 9     /* base + 8 moving links (feet are welded to lower legs) */
+#define SOLO_NV 14            /* velocity dofs: 6 (floating base) + 8                  */
+#define SOLO_MAX_SPHERES 16   /* collision primitives (sphere vs ground)               */
+#define SOLO_STATE_STRIDE 32  /* reals per env record (one 128-B line in f32)          */
+#define SOLO_MAX_OBS 64       /* observation elements per env                          */
+#define SOLO_MAX_REWARD_OPS 32
+#define SOLO_MAX_TERMS 4
+
+/* env record layout (reals), AoS so that one wavefront reads its robot's whole
+ * state as ONE coalesced 128-B (f32) / 256-B (f64) line: */
+#define SOLO_S_POS 0      /* base CoM position, world            [3] */
+#define SOLO_S_QUAT 3     /* base orientation xyzw (pybullet)    [4] */
+#define SOLO_S_Q 7        /* joint angles, dof order             [8] */
+#define SOLO_S_ANGVEL 15  /* base angular velocity, world frame  [3] */
+#define SOLO_S_LINVEL 18  /* base linear velocity, world frame   [3] */
+#define SOLO_S_QD 21      /* joint velocities                    [8] */
+#define SOLO_S_RETURN 29  /* episodic return accumulator             */
+#define SOLO_S_EPLEN 30   /* episode length accumulator              */
+#define SOLO_S_SPARE 31
+
+typedef enum SoloStatus {
+  SOLO_OK = 0,
+  SOLO_ERR_INVALID_ARG = -1, /* -> ValueError in the Python facade */
+  SOLO_ERR_HIP = -2,         /* -> RuntimeError                    */
+  SOLO_ERR_UNSUPPORTED_MODEL = -3,
+  SOLO_ERR_NO_PROGRAM = -4,  /* step() without a reward / obs / termination registered:
+                                mirrors the ValueErrors of rewards.py:115-116, obs.py:138-139,
+                                termination.py:43-44 */
+  SOLO_ERR_NO_DEVICE = -5
+} SoloStatus;
+
+typedef enum SoloDType { SOLO_F32 = 0, SOLO_F64 = 1 } SoloDType;
+
+/* ---- robot model (DATA, not code: both the engine and the CPU oracle take it) */
+typedef struct SoloModel {
+  /* body 0 = base; body 1+j = link moved by dof j.  dof order:
+   * FL_HFE, FL_KFE, FR_HFE, FR_KFE, HL_HFE, HL_KFE, HR_HFE, HR_KFE. */
+  int32_t parent[SOLO_NUM_DOF];            /* parent BODY index of dof j's link         */
+  double joint_origin[SOLO_NUM_DOF][3];    /* joint frame origin, in parent body frame  */
+  double joint_axis[SOLO_NUM_DOF][3];      /* unit axis (Solo8: all +y)                 */
+  double mass[SOLO_NUM_BODIES];
+  double com[SOLO_NUM_BODIES][3];          /* in body frame; base com must be 0         */
+  double inertia[SOLO_NUM_BODIES][6];      /* about com, body axes: xx yy zz xy xz yz   */
+  int32_t num_spheres;
+  int32_t sphere_body[SOLO_MAX_SPHERES];
+  double sphere_center[SOLO_MAX_SPHERES][3]; /* in body frame */
+  double sphere_radius[SOLO_MAX_SPHERES];
+  /* dof j <-> pybullet joint index (for getJointState facade), and the 12 names */
+  int32_t dof_to_joint[SOLO_NUM_DOF];
+} SoloModel;
+
+/* ---- physics / env configuration (gym_solo/core/configs.py:8-38) -------- */
+typedef struct SoloConfig {
+  int32_t abi_version;       /* = SOLO_ABI_VERSION */
+  int32_t dtype;             /* SoloDType */
+  double dt;                 /* configs.py:10  (1e-3), one substep: solo8_base_env.py:39-41 */
+  double gravity[3];         /* configs.py:17 */
+  double motor_torque_limit; /* configs.py:12  -> impulse clamp +-limit*dt per step */
+  double motor_kp;           /* pybullet POSITION_CONTROL default positionGain 0.1 [recalled] */
+  double motor_kd;           /* pybullet POSITION_CONTROL default velocityGain 1.0 [recalled] */
+  double linear_damping;     /* configs.py:21 */
+  double angular_damping;    /* configs.py:22 */
+  double lateral_friction;   /* configs.py:24 (x plane friction 1.0) */
+  double restitution;        /* configs.py:23 (0; only 0 is supported) */
+  double contact_erp;        /* penetration recovery rate (Bullet erp2 0.2 [recalled]) */
+  double contact_margin;     /* spheres closer than this to the ground create rows */
+  int32_t solver_iterations; /* Bullet default 50 [recalled] */
+  int32_t settle_steps;      /* solo8v2vanilla.py:130 (500) */
+  double start_pos[3];       /* configs.py:15 */
+  double start_quat[4];      /* from configs.py:16 euler */
+  double settle_targets[SOLO_NUM_JOINTS]; /* solo8v2vanilla.py:21-34, pybullet joint order */
+  double action_scale;       /* normalize_actions ? max_motor_rotation : 1 (solo8v2vanilla.py:84-85) */
+  int32_t auto_reset;        /* 1: envs whose `done` fires are restored from the snapshot in-kernel */
+  int32_t reserved;
+} SoloConfig;
+
+/* ---- fused observation / reward / termination programs ------------------ */
+/* Source vector the obs program indexes (per env, computed in-kernel):
+ *   [0..2] euler xyz  [3..5] base lin vel  [6..8] base ang vel
+ *   [9..20] joint angle by pybullet joint index (fixed joints = 0)
+ *   [21..32] joint velocity by pybullet joint index
+ *   [33..35] base position  [36..39] quaternion xyzw  [40] constant 1.0 */
+#define SOLO_SRC_EULER 0
+#define SOLO_SRC_LINVEL 3
+#define SOLO_SRC_ANGVEL 6
+#define SOLO_SRC_JPOS 9
+#define SOLO_SRC_JVEL 21
+#define SOLO_SRC_POS 33
+#define SOLO_SRC_QUAT 36
+#define SOLO_SRC_ONE 40
+#define SOLO_SRC_COUNT 41
+
+typedef struct SoloObsElem {
+  int32_t src;      /* index into the source vector */
+  int32_t flags;    /* bit0: clip to [lo,hi]; bit1: normalise 2(a-nlo)/(nhi-nlo)-1 (obs.py:149-152) */
+  double scale;     /* e.g. 180/pi for degrees (obs.py:277-279, 358) */
+  double lo, hi;    /* clip bounds (obs.py:282, 361) */
+  double nlo, nhi;  /* normalisation bounds: the float32 Box bounds widened to double */
+} SoloObsElem;
+
+/* reward program: postfix (RPN) over a small value stack */
+typedef enum SoloRewardOp {
+  SOLO_R_CONST = 0,        /* push a                                              */
+  SOLO_R_UPRIGHT = 1,      /* push (-pi/2)*pitch/(-pi/2)^2      rewards.py:221-234 */
+  SOLO_R_FLAT_TORSO = 2,   /* push tol(sqrt(tx^2+ty^2),(-a,a),b) rewards.py:256-269 */
+  SOLO_R_TORSO_HEIGHT = 3, /* push tol(z,(a-b,a+b),c)            rewards.py:362-373 */
+  SOLO_R_HORIZ_SPEED = 4,  /* push tol(|vxy|,(a-b,a+b),c)        rewards.py:326-338 */
+  SOLO_R_SMALL_CONTROL = 5,/* push tol(mean12|qd|,(0,0),a)       rewards.py:290-301 */
+  SOLO_R_SCALE = 6,        /* top *= a                                            */
+  SOLO_R_ADD = 7,          /* pop b, pop a, push a+b                              */
+  SOLO_R_MUL = 8           /* pop b, pop a, push a*b                              */
+} SoloRewardOp;
+
+typedef struct SoloRewardInstr {
+  int32_t op;
+  int32_t pad;
+  double a, b, c;
+} SoloRewardInstr;
+
+typedef enum SoloTermKind {
+  SOLO_T_PERPETUAL = 0,  /* termination.py:86-97  */
+  SOLO_T_TIME = 1,       /* termination.py:59-83  */
+  SOLO_T_CONST = 2       /* testing.py DummyTermination: fixed flag */
+} SoloTermKind;
+
+typedef struct SoloProgram {
+  int32_t num_obs;
+  int32_t num_reward_ops;
+  int32_t num_terms;
+  int32_t pad;
+  SoloObsElem obs[SOLO_MAX_OBS];
+  SoloRewardInstr reward[SOLO_MAX_REWARD_OPS];
+  int32_t term_kind[SOLO_MAX_TERMS];
+  int32_t term_param[SOLO_MAX_TERMS]; /* max_step_delta / flag */
+} SoloProgram;
+
+/* ---- zero-copy view of engine-owned device buffers ----------------------- */
+typedef struct SoloStateView {
+  int32_t num_envs;
+  int32_t dtype;        /* SoloDType of every `real` buffer               */
+  int32_t state_stride; /* = SOLO_STATE_STRIDE                            */
+  int32_t obs_dim;      /* D of the current program (0 if none)           */
+  void* state;          /* real  [N][SOLO_STATE_STRIDE]                   */
+  void* snapshot;       /* real  [N][SOLO_STATE_STRIDE] post-settle state */
+  void* targets;        /* real  [N][12] last motor targets (radians)     */
+  void* obs;            /* real  [N][D]                                   */
+  void* reward;         /* real  [N]                                      */
+  void* done;           /* uint8 [N]                                      */
+  void* term_count;     /* int32 [N][SOLO_MAX_TERMS]                      */
+  void* params;         /* real  [N][4]: lateral friction, base-mass scale, 2 spare */
+  void* stats;          /* double[8]: sum return, sum return^2, episodes, sum length, steps, diverged, 2 spare */
+} SoloStateView;
+
+typedef struct SoloEngine SoloEngine;
+
+/* flags of solo_engine_step */
+#define SOLO_STEP_PHYSICS 1u  /* A3+A4: motors + stepSimulation */
+#define SOLO_STEP_OBS 2u      /* A5-A7  */
+#define SOLO_STEP_REWARD 4u   /* A8-A11 */
+#define SOLO_STEP_DONE 8u     /* A12 (+ auto-reset when configured) */
+#define SOLO_STEP_ALL 15u
+
+/* BulletClient(connection_mode) + setGravity + setPhysicsEngineParameter + loadURDF x2
+ * (solo8_base_env.py:34-48).  Allocates device buffers, uploads the model, places every
+ * robot at start_pos and runs the settle loop (solo8v2vanilla.py:124-136) to build the
+ * reset snapshot.  Synchronises the device once. */
+int solo_engine_create(const SoloConfig* cfg, const SoloModel* model, int32_t num_envs,
+                       int32_t device_id, SoloEngine** out);
+/* client.disconnect()  (solo8_base_env.py:150-152) */
+int solo_engine_destroy(SoloEngine* eng);
+/* register_observation / register_reward / register_termination, compiled
+ * (obs.py:109-128, rewards.py:91-102, termination.py:28-36) */
+int solo_engine_set_program(SoloEngine* eng, const SoloProgram* prog);
+/* resetSimulation + reload + settle (solo8v2vanilla.py:104-143): restores the snapshot for
+ * envs with mask[i] != 0 (mask NULL = all) and clears their termination counters. */
+int solo_engine_reset(SoloEngine* eng, const uint8_t* mask_dev, void* stream);
+/* re-run the settle loop from the start pose for every env and refresh the snapshot
+ * (needed after solo_engine_set_params). Synchronises the stream. */
+int solo_engine_settle(SoloEngine* eng, void* stream);
+/* setJointMotorControlArray(..., POSITION_CONTROL, targetPositions=a, forces=limit)
+ * (solo8v2vanilla.py:87-90).  actions_dev: real [N][12] in pybullet joint order
+ * (entries 2,5,8,11 = fixed ANKLE joints are ignored); multiplied by action_scale. */
+int solo_engine_set_targets(SoloEngine* eng, const void* actions_dev, void* stream);
+/* One env step for all N robots (solo8v2vanilla.py:72-102).  actions_dev may be NULL
+ * (keep the last targets).  flags: SOLO_STEP_*.  One kernel launch. */
+int solo_engine_step(SoloEngine* eng, const void* actions_dev, uint32_t flags, void* stream);
+/* K consecutive env steps with per-step actions real [K][N][12]; one launch per step,
+ * enqueued back-to-back (rollout helper used by bench.py). */
+int solo_engine_rollout(SoloEngine* eng, const void* actions_dev, int32_t num_steps,
+                        uint32_t flags, void* stream);
+int solo_engine_get_view(SoloEngine* eng, SoloStateView* out);
+/* changeDynamics(lateralFriction=...) per env + base-mass randomisation
+ * (solo8v2vanilla.py:158-163; BASELINE config 4).  which: 0 = friction, 1 = base mass scale.
+ * per_env_dev: real [N]. */
+int solo_engine_set_params(SoloEngine* eng, int32_t which, const void* per_env_dev, void* stream);
+/* name of the dominant kernel (for rocprof cross-checks) and its last launch geometry */
+const char* solo_engine_kernel_name(SoloEngine* eng);
+/* Times `reps` back-to-back launches of the step kernel with hipEvents on `stream`
+ * (the stream the kernel runs on) and returns the mean milliseconds per launch. */
+int solo_engine_time_step(SoloEngine* eng, const void* actions_dev, uint32_t flags,
+                          int32_t reps, void* stream, double* ms_per_launch);
+const char* solo_engine_last_error(SoloEngine* eng);
+/* library-level: last error of a failed create (eng == NULL) */
+const char* solo_last_create_error(void);
+int solo_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOLO_ENGINE_H_ */

@@ -1,0 +1,629 @@
+/* solo_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * PARITY UNPINNED for trajectories: the arithmetic of the reference's hot path
+ * (`client.stepSimulation()`, gym_solo/envs/solo8v2vanilla.py:91) lives in the third-party,
+ * un-vendored, un-pinned `pybullet` wheel (setup.py:7), which is absent from /root/reference
+ * and from this image, and the robot URDF lives in an empty git submodule (.gitmodules:1-3).
+ * This file therefore restates the *published algorithmic structure* of that path
+ * ([recalled] Bullet btMultiBody pipeline: unconstrained articulated forward dynamics ->
+ * sphere/plane contact generation -> sequential-impulse (PGS) solve of joint-motor and
+ * contact/friction rows -> semi-implicit Euler), in double precision, scalar, generic over
+ * the kinematic tree, using textbook 6-D spatial algebra (Featherstone, RBDA ch. 5, 6, 9).
+ * It is pinned only by (a) physics known-answer tests in tests/test_oracle_physics.py,
+ * (b) the getJointInfo model fixture gym_solo/core/test_obs_observations.py:123-162 and
+ * (c) the determinism/rest properties of gym_solo/envs/test_solo8v2vanilla.py:77-194.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Step semantics restated (reference call sites):
+ *   setJointMotorControlArray(POSITION_CONTROL, targetPositions, forces)
+ *       solo8v2vanilla.py:87-90 -> 8 velocity-level motor rows, impulse clamp force*dt
+ *   stepSimulation()  solo8v2vanilla.py:91, fixedTimeStep=dt, numSubSteps=1
+ *       solo8_base_env.py:39-41
+ *   gravity configs.py:17, link damping configs.py:21-22 via changeDynamics
+ *       solo8v2vanilla.py:158-163, friction configs.py:24, restitution 0 configs.py:23
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/solo_engine.h"
+
+#define NB SOLO_NUM_BODIES
+#define ND SOLO_NUM_DOF
+#define NV SOLO_NV
+#define MAXROWS (ND + 3 * SOLO_MAX_SPHERES)
+
+/* ------------------------------------------------------------------ 3-vectors */
+static void v3cross(const double a[3], const double b[3], double o[3]) {
+  double x = a[1] * b[2] - a[2] * b[1];
+  double y = a[2] * b[0] - a[0] * b[2];
+  double z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static double v3dot(const double a[3], const double b[3]) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+static void m3v(const double M[9], const double v[3], double o[3]) {
+  double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  double y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  double z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3tv(const double M[9], const double v[3], double o[3]) {
+  double x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+  double y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+  double z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3m(const double A[9], const double B[9], double O[9]) {
+  double T[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(O, T, sizeof T);
+}
+static void m3t(const double A[9], double O[9]) {
+  double T[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * j + i];
+  memcpy(O, T, sizeof T);
+}
+/* body->world rotation of a unit quaternion (x,y,z,w) */
+static void quat_to_R(const double q[4], double R[9]) {
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+/* Rodrigues: rotation matrix of angle th about unit axis a (maps child coords -> parent) */
+static void axis_angle_R(const double a[3], double th, double R[9]) {
+  double c = cos(th), s = sin(th), t = 1 - c;
+  R[0] = t * a[0] * a[0] + c;        R[1] = t * a[0] * a[1] - s * a[2]; R[2] = t * a[0] * a[2] + s * a[1];
+  R[3] = t * a[0] * a[1] + s * a[2]; R[4] = t * a[1] * a[1] + c;        R[5] = t * a[1] * a[2] - s * a[0];
+  R[6] = t * a[0] * a[2] - s * a[1]; R[7] = t * a[1] * a[2] + s * a[0]; R[8] = t * a[2] * a[2] + c;
+}
+
+/* ------------------------------------------------------------- spatial algebra */
+/* Pluecker transform parent->child given E (child coords = E * parent coords) and r
+ * (child origin in parent coords):  X = [[E,0],[-E rx, E]]  (RBDA eq. 2.24) */
+static void xform_build(const double E[9], const double r[3], double X[36]) {
+  memset(X, 0, 36 * sizeof(double));
+  double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+  double Erx[9];
+  m3m(E, rx, Erx);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      X[6 * i + j] = E[3 * i + j];
+      X[6 * (i + 3) + (j + 3)] = E[3 * i + j];
+      X[6 * (i + 3) + j] = -Erx[3 * i + j];
+    }
+}
+static void m6v(const double M[36], const double v[6], double o[6]) {
+  double t[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = 0;
+    for (int j = 0; j < 6; ++j) s += M[6 * i + j] * v[j];
+    t[i] = s;
+  }
+  memcpy(o, t, sizeof t);
+}
+static void m6tv(const double M[36], const double v[6], double o[6]) {
+  double t[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = 0;
+    for (int j = 0; j < 6; ++j) s += M[6 * j + i] * v[j];
+    t[i] = s;
+  }
+  memcpy(o, t, sizeof t);
+}
+/* O += X^T I X */
+static void m6_congruence_add(const double X[36], const double I[36], double O[36]) {
+  double T[36];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += I[6 * i + k] * X[6 * k + j];
+      T[6 * i + j] = s;
+    }
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += X[6 * k + i] * T[6 * k + j];
+      O[6 * i + j] += s;
+    }
+}
+/* motion cross product  v x m  (RBDA eq. 2.31) */
+static void crm(const double v[6], const double m[6], double o[6]) {
+  double a[3], b[3], c[3];
+  v3cross(v, m, a);
+  v3cross(v, m + 3, b);
+  v3cross(v + 3, m, c);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+  o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+/* force cross product  v x* f  (RBDA eq. 2.32) */
+static void crf(const double v[6], const double f[6], double o[6]) {
+  double a[3], b[3], c[3];
+  v3cross(v, f, a);
+  v3cross(v + 3, f + 3, b);
+  v3cross(v, f + 3, c);
+  o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2];
+  o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+/* spatial inertia at the body origin from (m, c, Ic) (RBDA eq. 2.63) */
+static void spatial_inertia(double m, const double c[3], const double I6[6], double I[36]) {
+  double Ic[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+  double cx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+  double cxT[9], cc[9];
+  m3t(cx, cxT);
+  m3m(cx, cxT, cc);
+  memset(I, 0, 36 * sizeof(double));
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      I[6 * i + j] = Ic[3 * i + j] + m * cc[3 * i + j];
+      I[6 * i + (j + 3)] = m * cx[3 * i + j];
+      I[6 * (i + 3) + j] = m * cxT[3 * i + j];
+    }
+  I[6 * 3 + 3] = I[6 * 4 + 4] = I[6 * 5 + 5] = m;
+}
+
+/* ------------------------------------------------------------------ kinematics */
+typedef struct {
+  double Rwb[NB][9];   /* body -> world rotation               */
+  double pw[NB][3];    /* body origin in world                  */
+  double E[NB][9];     /* parent -> child coordinate rotation   */
+  double X[NB][36];    /* Pluecker transform parent -> child    */
+  double I[NB][36];    /* spatial inertia in body coords        */
+  double S[NB][6];     /* motion subspace of the joint moving body i (i >= 1) */
+  double mass[NB];
+  double Ic6[NB][6];
+} Kin;
+
+static void kinematics(const SoloModel* mdl, const double* st, double mass_scale, Kin* k) {
+  quat_to_R(st + SOLO_S_QUAT, k->Rwb[0]);
+  for (int a = 0; a < 3; ++a) k->pw[0][a] = st[SOLO_S_POS + a];
+  for (int b = 0; b < NB; ++b) {
+    double sc = (b == 0) ? mass_scale : 1.0;
+    k->mass[b] = mdl->mass[b] * sc;
+    for (int a = 0; a < 6; ++a) k->Ic6[b][a] = mdl->inertia[b][a] * sc;
+    spatial_inertia(k->mass[b], mdl->com[b], k->Ic6[b], k->I[b]);
+  }
+  for (int j = 0; j < ND; ++j) {
+    int b = j + 1, p = mdl->parent[j];
+    double Rj[9];
+    axis_angle_R(mdl->joint_axis[j], st[SOLO_S_Q + j], Rj); /* child -> parent */
+    m3t(Rj, k->E[b]);
+    xform_build(k->E[b], mdl->joint_origin[j], k->X[b]);
+    m3m(k->Rwb[p], Rj, k->Rwb[b]);
+    double o[3];
+    m3v(k->Rwb[p], mdl->joint_origin[j], o);
+    for (int a = 0; a < 3; ++a) k->pw[b][a] = k->pw[p][a] + o[a];
+    for (int a = 0; a < 3; ++a) { k->S[b][a] = mdl->joint_axis[j][a]; k->S[b][a + 3] = 0; }
+  }
+}
+
+/* generalized velocity in base-body coordinates u = [w_b, v_b, qd] */
+static void gen_velocity(const Kin* k, const double* st, double u[NV]) {
+  m3tv(k->Rwb[0], st + SOLO_S_ANGVEL, u);
+  m3tv(k->Rwb[0], st + SOLO_S_LINVEL, u + 3);
+  for (int j = 0; j < ND; ++j) u[6 + j] = st[SOLO_S_QD + j];
+}
+
+/* --------------------------------------------------- CRBA (RBDA table 9.5-ish) */
+static void crba(const SoloModel* mdl, const Kin* k, double M[NV * NV]) {
+  double Ic[NB][36];
+  memcpy(Ic, k->I, sizeof Ic);
+  for (int b = NB - 1; b >= 1; --b) m6_congruence_add(k->X[b], Ic[b], Ic[mdl->parent[b - 1]]);
+  memset(M, 0, NV * NV * sizeof(double));
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) M[NV * i + j] = Ic[0][6 * i + j];
+  for (int b = 1; b < NB; ++b) {
+    double F[6];
+    m6v(Ic[b], k->S[b], F);
+    M[NV * (5 + b) + (5 + b)] = F[0] * k->S[b][0] + F[1] * k->S[b][1] + F[2] * k->S[b][2];
+    int j = b;
+    while (mdl->parent[j - 1] != 0) {
+      m6tv(k->X[j], F, F);
+      j = mdl->parent[j - 1];
+      double h = 0;
+      for (int a = 0; a < 6; ++a) h += k->S[j][a] * F[a];
+      M[NV * (5 + b) + (5 + j)] = h;
+      M[NV * (5 + j) + (5 + b)] = h;
+    }
+    m6tv(k->X[j], F, F);
+    for (int a = 0; a < 6; ++a) { M[NV * a + (5 + b)] = F[a]; M[NV * (5 + b) + a] = F[a]; }
+  }
+}
+
+/* external wrench on body b in body coords at body origin: gravity + Bullet-style damping.
+ * [recalled] btMultiBody applies  -m v (k + k|v|)  and  -I w (k + k|w|)  per link with
+ * k = linearDamping / angularDamping (set for every link by solo8v2vanilla.py:158-163). */
+static void external_wrench(const SoloModel* mdl, const SoloConfig* cfg, const Kin* k, int b,
+                            const double v[6], double f[6]) {
+  double g_b[3], fg[3], ng[3];
+  m3tv(k->Rwb[b], cfg->gravity, g_b);
+  for (int a = 0; a < 3; ++a) fg[a] = k->mass[b] * g_b[a];
+  v3cross(mdl->com[b], fg, ng);
+  /* damping at the centre of mass */
+  double wxc[3], vc[3];
+  v3cross(v, mdl->com[b], wxc);
+  for (int a = 0; a < 3; ++a) vc[a] = v[3 + a] + wxc[a];
+  double nv = sqrt(v3dot(vc, vc)), nw = sqrt(v3dot(v, v));
+  double kl = cfg->linear_damping * (1.0 + nv), ka = cfg->angular_damping * (1.0 + nw);
+  const double* I6 = k->Ic6[b];
+  double Iw[3] = {I6[0] * v[0] + I6[3] * v[1] + I6[4] * v[2],
+                  I6[3] * v[0] + I6[1] * v[1] + I6[5] * v[2],
+                  I6[4] * v[0] + I6[5] * v[1] + I6[2] * v[2]};
+  double fd[3], nd[3], cxf[3];
+  for (int a = 0; a < 3; ++a) { fd[a] = -k->mass[b] * vc[a] * kl; nd[a] = -Iw[a] * ka; }
+  v3cross(mdl->com[b], fd, cxf);
+  for (int a = 0; a < 3; ++a) { f[a] = ng[a] + nd[a] + cxf[a]; f[3 + a] = fg[a] + fd[a]; }
+}
+
+/* bias h(q,u) with zero spatial acceleration (RNEA, RBDA table 9.6 with a_0 = 0, qdd = 0) */
+static void rnea_bias(const SoloModel* mdl, const SoloConfig* cfg, const Kin* k,
+                      const double u[NV], double h[NV]) {
+  double v[NB][6], a[NB][6], f[NB][6];
+  memcpy(v[0], u, 6 * sizeof(double));
+  memset(a[0], 0, sizeof a[0]);
+  for (int b = 1; b < NB; ++b) {
+    int p = mdl->parent[b - 1];
+    double vj[6], t[6];
+    for (int c = 0; c < 6; ++c) vj[c] = k->S[b][c] * u[5 + b];
+    m6v(k->X[b], v[p], v[b]);
+    for (int c = 0; c < 6; ++c) v[b][c] += vj[c];
+    m6v(k->X[b], a[p], a[b]);
+    crm(v[b], vj, t);
+    for (int c = 0; c < 6; ++c) a[b][c] += t[c];
+  }
+  for (int b = 0; b < NB; ++b) {
+    double Iv[6], Ia[6], t[6], fe[6];
+    m6v(k->I[b], v[b], Iv);
+    m6v(k->I[b], a[b], Ia);
+    crf(v[b], Iv, t);
+    external_wrench(mdl, cfg, k, b, v[b], fe);
+    for (int c = 0; c < 6; ++c) f[b][c] = Ia[c] + t[c] - fe[c];
+  }
+  for (int b = NB - 1; b >= 1; --b) {
+    double s = 0, t[6];
+    for (int c = 0; c < 6; ++c) s += k->S[b][c] * f[b][c];
+    h[5 + b] = s;
+    m6tv(k->X[b], f[b], t);
+    int p = mdl->parent[b - 1];
+    for (int c = 0; c < 6; ++c) f[p][c] += t[c];
+  }
+  memcpy(h, f[0], 6 * sizeof(double));
+}
+
+/* dense Cholesky  A = L L^T  (lower, in place); returns 0 on success */
+static int chol(double* A, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[n * j + j];
+    for (int k = 0; k < j; ++k) d -= A[n * j + k] * A[n * j + k];
+    if (!(d > 0)) return -1;
+    d = sqrt(d);
+    A[n * j + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[n * i + j];
+      for (int k = 0; k < j; ++k) s -= A[n * i + k] * A[n * j + k];
+      A[n * i + j] = s / d;
+    }
+  }
+  return 0;
+}
+static void chol_solve(const double* L, int n, double* b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[n * i + k] * b[k];
+    b[i] = s / L[n * i + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= L[n * k + i] * b[k];
+    b[i] = s / L[n * i + i];
+  }
+}
+
+/* ---------------- independent O(n) articulated-body algorithm (RBDA table 9.4) -------
+ * used ONLY to cross-check CRBA + RNEA + Cholesky (known-answer test 4).  Returns the
+ * spatial acceleration of the base (body coords) and qdd for generalized forces tau. */
+static void aba(const SoloModel* mdl, const SoloConfig* cfg, const Kin* k, const double u[NV],
+                const double tau[ND], double udot[NV]) {
+  double v[NB][6], c[NB][6], IA[NB][36], pA[NB][6], U[NB][6], D[NB], uu[NB], a[NB][6];
+  memcpy(v[0], u, 6 * sizeof(double));
+  for (int b = 1; b < NB; ++b) {
+    int p = mdl->parent[b - 1];
+    double vj[6];
+    for (int i = 0; i < 6; ++i) vj[i] = k->S[b][i] * u[5 + b];
+    m6v(k->X[b], v[p], v[b]);
+    for (int i = 0; i < 6; ++i) v[b][i] += vj[i];
+    crm(v[b], vj, c[b]);
+  }
+  for (int b = 0; b < NB; ++b) {
+    double Iv[6], fe[6];
+    memcpy(IA[b], k->I[b], sizeof IA[b]);
+    m6v(k->I[b], v[b], Iv);
+    crf(v[b], Iv, pA[b]);
+    external_wrench(mdl, cfg, k, b, v[b], fe);
+    for (int i = 0; i < 6; ++i) pA[b][i] -= fe[i];
+  }
+  for (int b = NB - 1; b >= 1; --b) {
+    int p = mdl->parent[b - 1];
+    m6v(IA[b], k->S[b], U[b]);
+    D[b] = 0; uu[b] = tau[b - 1];
+    for (int i = 0; i < 6; ++i) { D[b] += k->S[b][i] * U[b][i]; uu[b] -= k->S[b][i] * pA[b][i]; }
+    double Ia[36], pa[6], t[6];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) Ia[6 * i + j] = IA[b][6 * i + j] - U[b][i] * U[b][j] / D[b];
+    m6v(Ia, c[b], t);
+    for (int i = 0; i < 6; ++i) pa[i] = pA[b][i] + t[i] + U[b][i] * uu[b] / D[b];
+    m6_congruence_add(k->X[b], Ia, IA[p]);
+    m6tv(k->X[b], pa, t);
+    for (int i = 0; i < 6; ++i) pA[p][i] += t[i];
+  }
+  double L[36], rhs[6];
+  memcpy(L, IA[0], sizeof L);
+  chol(L, 6);
+  for (int i = 0; i < 6; ++i) rhs[i] = -pA[0][i];
+  chol_solve(L, 6, rhs);
+  memcpy(a[0], rhs, sizeof rhs);
+  memcpy(udot, rhs, sizeof rhs);
+  for (int b = 1; b < NB; ++b) {
+    int p = mdl->parent[b - 1];
+    double ap[6], s = 0;
+    m6v(k->X[b], a[p], ap);
+    for (int i = 0; i < 6; ++i) ap[i] += c[b][i];
+    for (int i = 0; i < 6; ++i) s += U[b][i] * ap[i];
+    double qdd = (uu[b] - s) / D[b];
+    udot[5 + b] = qdd;
+    for (int i = 0; i < 6; ++i) a[b][i] = ap[i] + k->S[b][i] * qdd;
+  }
+}
+
+/* ------------------------------------------------------------------ constraints */
+typedef struct {
+  int n;
+  double J[MAXROWS][NV];
+  double rhs[MAXROWS];   /* target constraint-space velocity */
+  double lo[MAXROWS], hi[MAXROWS];
+  int normal_row[MAXROWS]; /* >=0: friction row limited by mu * lambda[normal_row] */
+  int sphere[MAXROWS];
+  double mu;
+} Rows;
+
+/* Jacobian row of direction d (world) at world point x attached to body b, in the
+ * generalized-velocity coordinates u = [w_b, v_b, qd] (base-body coordinates). */
+static void point_jacobian(const SoloModel* mdl, const Kin* k, int b, const double x[3],
+                           const double d[3], double J[NV]) {
+  memset(J, 0, NV * sizeof(double));
+  double r[3] = {x[0] - k->pw[0][0], x[1] - k->pw[0][1], x[2] - k->pw[0][2]}, rxd[3];
+  v3cross(r, d, rxd);
+  m3tv(k->Rwb[0], rxd, J);
+  m3tv(k->Rwb[0], d, J + 3);
+  while (b != 0) {
+    double aw[3], rr[3], t[3];
+    m3v(k->Rwb[b], mdl->joint_axis[b - 1], aw);
+    for (int a = 0; a < 3; ++a) rr[a] = x[a] - k->pw[b][a];
+    v3cross(aw, rr, t);
+    J[5 + b] = v3dot(d, t);
+    b = mdl->parent[b - 1];
+  }
+}
+
+static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const Kin* k,
+                       const double* st, const double ustar[NV], const double targets[ND],
+                       double mu, Rows* R) {
+  R->n = 0; R->mu = mu;
+  /* joint motors: velocity-level rows, [recalled] btMultiBodyJointMotor:
+   *   v_target = kp*(q* - q)/dt + (1-kd)*qd,  |impulse| <= maxForce*dt */
+  for (int j = 0; j < ND; ++j) {
+    int r = R->n++;
+    memset(R->J[r], 0, sizeof R->J[r]);
+    R->J[r][6 + j] = 1.0;
+    R->rhs[r] = cfg->motor_kp * (targets[j] - st[SOLO_S_Q + j]) / cfg->dt +
+                (1.0 - cfg->motor_kd) * ustar[6 + j];
+    R->lo[r] = -cfg->motor_torque_limit * cfg->dt;
+    R->hi[r] = cfg->motor_torque_limit * cfg->dt;
+    R->normal_row[r] = -1; R->sphere[r] = -1;
+  }
+  /* sphere vs ground plane z = 0 (plane.urdf, solo8_base_env.py:47) */
+  const double n[3] = {0, 0, 1}, t1[3] = {1, 0, 0}, t2[3] = {0, 1, 0};
+  for (int s = 0; s < mdl->num_spheres; ++s) {
+    int b = mdl->sphere_body[s];
+    double cw[3];
+    m3v(k->Rwb[b], mdl->sphere_center[s], cw);
+    for (int a = 0; a < 3; ++a) cw[a] += k->pw[b][a];
+    double dist = cw[2] - mdl->sphere_radius[s];
+    if (!(dist < cfg->contact_margin)) continue;
+    double x[3] = {cw[0], cw[1], cw[2] - mdl->sphere_radius[s]};
+    int rn = R->n++;
+    point_jacobian(mdl, k, b, x, n, R->J[rn]);
+    /* non-penetration: v_n >= -dist/dt if separated (speculative), else push out with erp */
+    R->rhs[rn] = (dist > 0) ? -dist / cfg->dt : -cfg->contact_erp * dist / cfg->dt;
+    R->lo[rn] = 0; R->hi[rn] = INFINITY; R->normal_row[rn] = -1; R->sphere[rn] = s;
+    const double* td[2] = {t1, t2};
+    for (int q = 0; q < 2; ++q) {
+      int rt = R->n++;
+      point_jacobian(mdl, k, b, x, td[q], R->J[rt]);
+      R->rhs[rt] = 0; R->lo[rt] = 0; R->hi[rt] = 0; R->normal_row[rt] = rn; R->sphere[rt] = s;
+    }
+  }
+}
+
+/* scratch outputs for tests */
+typedef struct SoloOracleDebug {
+  double M[NV * NV];
+  double h[NV];
+  double udot[NV];     /* spatial-acceleration convention */
+  double ustar[NV];
+  double uplus[NV];
+  int32_t num_rows;
+  int32_t row_sphere[MAXROWS];
+  double lambda[MAXROWS];
+  double J[MAXROWS][NV];
+} SoloOracleDebug;
+
+static void quat_integrate(double q[4], const double w[3], double dt) {
+  /* q+ = exp(dt*w/2) (x) q  with world-frame w, then renormalise */
+  double th = sqrt(v3dot(w, w)) * dt, s, c = cos(0.5 * th);
+  if (th > 1e-12) s = sin(0.5 * th) / th * dt; else s = 0.5 * dt;
+  double dx = w[0] * s, dy = w[1] * s, dz = w[2] * s, dw = c;
+  double x = q[0], y = q[1], z = q[2], ww = q[3];
+  double nx = dw * x + dx * ww + dy * z - dz * y;
+  double ny = dw * y - dx * z + dy * ww + dz * x;
+  double nz = dw * z + dx * y - dy * x + dz * ww;
+  double nw = dw * ww - dx * x - dy * y - dz * z;
+  double nn = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+  q[0] = nx * nn; q[1] = ny * nn; q[2] = nz * nn; q[3] = nw * nn;
+}
+
+/* One physics step of ONE robot.  st: SOLO_STATE_STRIDE doubles (in/out); targets: 8 dof
+ * targets (radians); params: {friction, base-mass scale}.  dbg may be NULL. */
+int solo_oracle_step_env(const SoloConfig* cfg, const SoloModel* mdl, double* st,
+                         const double* targets, const double* params, SoloOracleDebug* dbg) {
+  static _Thread_local Kin k;
+  static _Thread_local Rows R;
+  double M[NV * NV], L[NV * NV], h[NV], u[NV], udot[NV], ustar[NV];
+  kinematics(mdl, st, params[1], &k);
+  gen_velocity(&k, st, u);
+  crba(mdl, &k, M);
+  rnea_bias(mdl, cfg, &k, u, h);
+  memcpy(L, M, sizeof L);
+  if (chol(L, NV)) return -1;
+  for (int i = 0; i < NV; ++i) udot[i] = -h[i];
+  chol_solve(L, NV, udot);
+  /* spatial -> classical acceleration of the base origin: + w x v */
+  double wxv[3];
+  v3cross(u, u + 3, wxv);
+  for (int i = 0; i < NV; ++i) ustar[i] = u[i] + cfg->dt * udot[i];
+  for (int a = 0; a < 3; ++a) ustar[3 + a] += cfg->dt * wxv[a];
+
+  build_rows(mdl, cfg, &k, st, ustar, targets, params[0], &R);
+  /* sequential impulse / projected Gauss-Seidel in velocity space */
+  static _Thread_local double B[MAXROWS][NV];
+  double diag[MAXROWS], lam[MAXROWS], up[NV];
+  for (int r = 0; r < R.n; ++r) {
+    memcpy(B[r], R.J[r], sizeof B[r]);
+    chol_solve(L, NV, B[r]);
+    double d = 0;
+    for (int i = 0; i < NV; ++i) d += R.J[r][i] * B[r][i];
+    diag[r] = d; lam[r] = 0;
+  }
+  memcpy(up, ustar, sizeof up);
+  for (int it = 0; it < cfg->solver_iterations; ++it)
+    for (int r = 0; r < R.n; ++r) {
+      double rel = 0;
+      for (int i = 0; i < NV; ++i) rel += R.J[r][i] * up[i];
+      double lo = R.lo[r], hi = R.hi[r];
+      if (R.normal_row[r] >= 0) { hi = R.mu * lam[R.normal_row[r]]; lo = -hi; }
+      double nl = lam[r] + (R.rhs[r] - rel) / diag[r];
+      if (nl < lo) nl = lo;
+      if (nl > hi) nl = hi;
+      double dl = nl - lam[r];
+      lam[r] = nl;
+      for (int i = 0; i < NV; ++i) up[i] += B[r][i] * dl;
+    }
+  /* back to world-frame velocities, integrate positions (semi-implicit Euler) */
+  double ww[3], vw[3];
+  m3v(k.Rwb[0], up, ww);
+  m3v(k.Rwb[0], up + 3, vw);
+  for (int a = 0; a < 3; ++a) {
+    st[SOLO_S_ANGVEL + a] = ww[a];
+    st[SOLO_S_LINVEL + a] = vw[a];
+    st[SOLO_S_POS + a] += cfg->dt * vw[a];
+  }
+  quat_integrate(st + SOLO_S_QUAT, ww, cfg->dt);
+  for (int j = 0; j < ND; ++j) {
+    st[SOLO_S_QD + j] = up[6 + j];
+    st[SOLO_S_Q + j] += cfg->dt * up[6 + j];
+  }
+  if (dbg) {
+    memcpy(dbg->M, M, sizeof M); memcpy(dbg->h, h, sizeof h);
+    memcpy(dbg->udot, udot, sizeof udot); memcpy(dbg->ustar, ustar, sizeof ustar);
+    memcpy(dbg->uplus, up, sizeof up);
+    dbg->num_rows = R.n;
+    for (int r = 0; r < R.n; ++r) {
+      dbg->row_sphere[r] = R.sphere[r]; dbg->lambda[r] = lam[r];
+      memcpy(dbg->J[r], R.J[r], sizeof R.J[r]);
+    }
+  }
+  return 0;
+}
+
+/* Forward dynamics two ways for known-answer test (4): returns udot from CRBA+RNEA+Cholesky
+ * in out_crba and from the O(n) ABA in out_aba (both: spatial base acceleration + qdd). */
+int solo_oracle_forward_dynamics(const SoloConfig* cfg, const SoloModel* mdl, const double* st,
+                                 const double* tau, double mass_scale, double* out_crba,
+                                 double* out_aba) {
+  static _Thread_local Kin k;
+  double M[NV * NV], h[NV], u[NV];
+  kinematics(mdl, st, mass_scale, &k);
+  gen_velocity(&k, st, u);
+  crba(mdl, &k, M);
+  rnea_bias(mdl, cfg, &k, u, h);
+  if (chol(M, NV)) return -1;
+  for (int i = 0; i < 6; ++i) out_crba[i] = -h[i];
+  for (int j = 0; j < ND; ++j) out_crba[6 + j] = tau[j] - h[6 + j];
+  chol_solve(M, NV, out_crba);
+  aba(mdl, cfg, &k, u, tau, out_aba);
+  return 0;
+}
+
+/* world position of every collision sphere centre (tests: standing height, fixture) */
+void solo_oracle_sphere_centers(const SoloModel* mdl, const double* st, double* out /*[S][3]*/) {
+  static _Thread_local Kin k;
+  kinematics(mdl, st, 1.0, &k);
+  for (int s = 0; s < mdl->num_spheres; ++s) {
+    int b = mdl->sphere_body[s];
+    double cw[3];
+    m3v(k.Rwb[b], mdl->sphere_center[s], cw);
+    for (int a = 0; a < 3; ++a) out[3 * s + a] = cw[a] + k.pw[b][a];
+  }
+}
+
+/* momentum (world frame, about the world origin) and kinetic energy, for invariants */
+void solo_oracle_momentum(const SoloModel* mdl, const double* st, double mass_scale,
+                          double* lin /*3*/, double* ang /*3*/, double* kinetic) {
+  static _Thread_local Kin k;
+  double u[NV], v[NB][6];
+  kinematics(mdl, st, mass_scale, &k);
+  gen_velocity(&k, st, u);
+  memcpy(v[0], u, 6 * sizeof(double));
+  for (int a = 0; a < 3; ++a) { lin[a] = 0; ang[a] = 0; }
+  *kinetic = 0;
+  for (int b = 0; b < NB; ++b) {
+    if (b > 0) {
+      m6v(k.X[b], v[mdl->parent[b - 1]], v[b]);
+      for (int c = 0; c < 6; ++c) v[b][c] += k.S[b][c] * u[5 + b];
+    }
+    double Iv[6], fw[3], nw[3], cx[3];
+    m6v(k.I[b], v[b], Iv);
+    for (int c = 0; c < 6; ++c) *kinetic += 0.5 * v[b][c] * Iv[c];
+    m3v(k.Rwb[b], Iv, nw);       /* angular momentum about body origin, world coords */
+    m3v(k.Rwb[b], Iv + 3, fw);   /* linear momentum */
+    v3cross(k.pw[b], fw, cx);
+    for (int a = 0; a < 3; ++a) { lin[a] += fw[a]; ang[a] += nw[a] + cx[a]; }
+  }
+}
+
+/* Batched stepping for the cpu_baseline leg and batch parity: st [N][32], actions [N][12]
+ * in pybullet joint order (scaled by cfg->action_scale), params [N][4].  OpenMP over envs. */
+int solo_oracle_step_batch(const SoloConfig* cfg, const SoloModel* mdl, int32_t n, double* st,
+                           const double* actions, const double* params, int32_t nthreads) {
+  int fail = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(| : fail)
+  for (int e = 0; e < n; ++e) {
+    double tg[ND];
+    for (int j = 0; j < ND; ++j)
+      tg[j] = actions[(size_t)e * SOLO_NUM_JOINTS + mdl->dof_to_joint[j]] * cfg->action_scale;
+    if (solo_oracle_step_env(cfg, mdl, st + (size_t)e * SOLO_STATE_STRIDE, tg,
+                             params + (size_t)e * 4, NULL))
+      fail = 1;
+  }
+  return fail ? -1 : 0;
+}
+
+size_t solo_oracle_debug_size(void) { return sizeof(SoloOracleDebug); }
+int solo_oracle_max_rows(void) { return MAXROWS; }

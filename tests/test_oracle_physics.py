@@ -1,0 +1,187 @@
+"""Known-answer tests pinning the CPU oracle's physics (SURVEY.md §8c list (2)-(6)).
+
+The reference holds no trajectory golden (parity unpinned), so the oracle is pinned by physics
+invariants and by the reference's own behavioural properties
+(gym_solo/envs/test_solo8v2vanilla.py:77-104, 141-163, 177-194).
+"""
+import numpy as np
+import pytest
+
+from gym_solo_amd import abi
+from gym_solo_amd.core.configs import Solo8BaseConfig, config_to_abi
+from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+from gym_solo_amd.model import JOINT_NAMES, Solo8Model
+from oracle import solo_oracle as so
+
+
+def make(cfg=None, **kw):
+  cfg = cfg or Solo8VanillaConfig()
+  for k, v in kw.items():
+    setattr(cfg, k, v)
+  ca = config_to_abi(cfg, getattr(cfg, 'starting_joint_pos', None), JOINT_NAMES)
+  return so.OraclePhysics(ca, Solo8Model().to_abi())
+
+
+def random_state(ph, seed, z=2.0):
+  rng = np.random.default_rng(seed)
+  st = ph.initial_state(1)
+  st[0, abi.S_POS + 2] = z
+  st[0, abi.S_Q:abi.S_Q + 8] = rng.uniform(-1.5, 1.5, 8)
+  st[0, abi.S_QD:abi.S_QD + 8] = rng.uniform(-3, 3, 8)
+  st[0, abi.S_ANGVEL:abi.S_ANGVEL + 3] = rng.uniform(-2, 2, 3)
+  st[0, abi.S_LINVEL:abi.S_LINVEL + 3] = rng.uniform(-1, 1, 3)
+  q = rng.normal(size=4)
+  st[0, abi.S_QUAT:abi.S_QUAT + 4] = q / np.linalg.norm(q)
+  return st
+
+
+@pytest.mark.parametrize('seed', range(5))
+def test_crba_rnea_matches_aba(seed):
+  """(4) two independent forward-dynamics algorithms agree (gravity, damping, random tau)."""
+  ph = make()
+  st = random_state(ph, seed)
+  tau = np.random.default_rng(100 + seed).uniform(-2, 2, 8)
+  a, b = ph.forward_dynamics(st[0].copy(), tau)
+  np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-9)
+
+
+def test_mass_matrix_properties():
+  ph = make()
+  st = random_state(ph, 7)
+  dbg = ph.step_debug(st[0].copy(), np.zeros(8))
+  M = np.array(dbg.M).reshape(abi.NV, abi.NV)
+  np.testing.assert_allclose(M, M.T, atol=1e-15)
+  assert np.linalg.eigvalsh(M).min() > 0
+  # linear-linear block = total mass * identity
+  np.testing.assert_allclose(M[3:6, 3:6], np.eye(3) * Solo8Model().total_mass, atol=1e-12)
+
+
+def test_free_fall_closed_form():
+  """(3) semi-implicit Euler free fall: v_k = g k dt, z_k = z0 + g dt^2 k(k+1)/2."""
+  ph = make(linear_damping=0.0, angular_damping=0.0, motor_torque_limit=0.0)
+  st = ph.initial_state(1)
+  st[0, abi.S_POS + 2] = 5.0
+  dt, g = ph.cfg.dt, ph.cfg.gravity[2]
+  for k in range(1, 201):
+    ph.step(st, np.zeros((1, 12)))
+    assert abs(st[0, abi.S_LINVEL + 2] - g * k * dt) < 1e-11
+    assert abs(st[0, abi.S_POS + 2] - (5.0 + g * dt * dt * k * (k + 1) / 2)) < 1e-11
+  # nothing else moved
+  np.testing.assert_allclose(st[0, abi.S_Q:abi.S_Q + 8], 0, atol=1e-10)
+  np.testing.assert_allclose(st[0, abi.S_QUAT:abi.S_QUAT + 4], [0, 0, 0, 1], atol=1e-12)
+
+
+def _with_velocity(ph, st, u):
+  """state with the generalized velocity u = [w_b, v_b, qd] (base-body coordinates)."""
+  x, y, z, w = st[abi.S_QUAT:abi.S_QUAT + 4]
+  R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+  out = st.copy()
+  out[abi.S_ANGVEL:abi.S_ANGVEL + 3] = R @ u[0:3]
+  out[abi.S_LINVEL:abi.S_LINVEL + 3] = R @ u[3:6]
+  out[abi.S_QD:abi.S_QD + 8] = u[6:]
+  return out
+
+
+def test_momentum_conservation_zero_gravity():
+  """(2) no gravity / damping / contact.  (a) motor impulses are internal: at fixed configuration
+  they change neither the linear nor the angular momentum; (b) with the motors off the
+  semi-implicit Euler scheme conserves momentum up to its first-order integration error, so the
+  drift halves with dt."""
+  ph = make(gravity=(0., 0., 0.), linear_damping=0.0, angular_damping=0.0)
+  st = random_state(ph, 3, z=10.0)
+  dbg = ph.step_debug(st[0].copy(), np.random.default_rng(1).uniform(-3, 3, 8))
+  lam = np.array(dbg.lam)[:dbg.num_rows]
+  assert dbg.num_rows == 8 and np.abs(lam).max() > 1e-4
+  la, aa, _ = ph.momentum(_with_velocity(ph, st[0], np.array(dbg.ustar)))
+  lb, ab, _ = ph.momentum(_with_velocity(ph, st[0], np.array(dbg.uplus)))
+  np.testing.assert_allclose(la, lb, atol=1e-13)
+  np.testing.assert_allclose(aa, ab, atol=1e-13)
+  drifts = []
+  for dt in (1e-3, 5e-4, 2.5e-4):
+    ph = make(gravity=(0., 0., 0.), linear_damping=0.0, angular_damping=0.0, dt=dt,
+              motor_torque_limit=0.0)
+    st = random_state(ph, 3, z=10.0)
+    lin0, ang0, _ = ph.momentum(st[0])
+    for k in range(int(round(0.2 / dt))):
+      ph.step(st, np.zeros((1, 12)))
+    lin1, ang1, _ = ph.momentum(st[0])
+    drifts.append((np.abs(lin1 - lin0).max(), np.abs(ang1 - ang0).max()))
+  drifts = np.array(drifts)
+  assert drifts[0].max() < 2e-3
+  assert np.all(drifts[1] < 0.55 * drifts[0])
+  assert np.all(drifts[2] < 0.55 * drifts[1])
+
+
+def test_energy_decreases_with_damping_only():
+  ph = make(gravity=(0., 0., 0.), motor_torque_limit=0.0)
+  st = random_state(ph, 11, z=10.0)
+  ke = [ph.momentum(st[0])[2]]
+  for _ in range(300):
+    ph.step(st, np.zeros((1, 12)))
+    ke.append(ph.momentum(st[0])[2])
+  assert ke[-1] < ke[0]
+
+
+def test_standing_height_and_static_force_balance():
+  """(5) standing at q = 0 on the four feet: base height 0.32 + foot radius (= 0.33698, the
+  target height of examples/solo8_vanilla/interactive_pos_control.py:23) and the normal
+  impulses balance m_total * g * dt."""
+  model = Solo8Model()
+  ph = make()
+  st = ph.initial_state(1)
+  st[0, abi.S_POS + 2] = 0.32 + model.foot_radius
+  centers = ph.sphere_centers(st[0])
+  np.testing.assert_allclose(centers[12:, 2], model.foot_radius, atol=1e-12)
+  for _ in range(1500):
+    ph.step(st, np.zeros((1, 12)))
+  dbg = ph.step_debug(st[0].copy(), np.zeros(8))
+  lam = np.array(dbg.lam)[:dbg.num_rows]
+  sph = np.array(dbg.row_sphere)[:dbg.num_rows]
+  J = np.array(dbg.J)[:dbg.num_rows]
+  normal = np.array([r for r in range(dbg.num_rows) if sph[r] >= 0 and abs(J[r, 5]) > 0.5
+                     and abs(J[r, 3]) < 0.5 and abs(J[r, 4]) < 0.5])
+  total = lam[normal].sum() / ph.cfg.dt
+  assert abs(total - model.total_mass * 9.81) < 1e-3 * model.total_mass * 9.81
+  assert abs(st[0, abi.S_POS + 2] - 0.33698) < 2e-3
+  assert np.abs(st[0, abi.S_LINVEL:abi.S_LINVEL + 3]).max() < 1e-5
+
+
+def test_reference_rest_and_determinism_properties():
+  """(6) gym_solo/envs/test_solo8v2vanilla.py:77-104 (rest stability to 6 decimals, an action
+  moves the robot), :141-163 / :177-194 (reset is deterministic across instances)."""
+  ph = make()
+  home = ph.settle(1)
+  home2 = make().settle(1)
+  np.testing.assert_array_equal(home, home2)
+  st = home.copy()
+  zero = np.zeros((1, 12))
+  for _ in range(1000):
+    ph.step(st, zero)
+  pos, orn = st[0, :3].copy(), st[0, 3:7].copy()
+  for _ in range(10):
+    ph.step(st, zero)
+  np.testing.assert_array_almost_equal(pos, st[0, :3])
+  np.testing.assert_array_almost_equal(orn, st[0, 3:7])
+  act = np.full((1, 12), 5.0)
+  for _ in range(10):
+    ph.step(st, act)
+  with pytest.raises(AssertionError):
+    np.testing.assert_array_almost_equal(pos, st[0, :3])
+  with pytest.raises(AssertionError):
+    np.testing.assert_array_almost_equal(orn, st[0, 3:7])
+
+
+def test_rest_pose_magnitudes_against_reference_vector():
+  """gym_solo/core/test_obs_observations.py:256-275 holds one 'real case extracted from
+  pybullet' at rest: |HFE| ~ 1.5301, |KFE| ~ 3.0853, ankles 0, qd ~ 1e-11.  Its sign pattern
+  predates today's starting_joint_pos so only magnitudes are comparable: the
+  settled pose must sit just short of the folded targets (pi/2, pi)."""
+  ph = make()
+  home = ph.settle(1)
+  q = home[0, abi.S_Q:abi.S_Q + 8]
+  assert np.all(np.abs(np.abs(q[0::2]) - np.pi / 2) < 0.15)
+  assert np.all(np.abs(np.abs(q[1::2]) - np.pi) < 0.15)
+  assert np.abs(home[0, abi.S_QD:abi.S_QD + 8]).max() < 1e-2
+  assert np.all(np.sign(q) == np.sign([1, 1, 1, 1, -1, -1, -1, -1]))
