@@ -230,7 +230,7 @@ def pybullet_joint_info(model: Solo8Model = None) -> List[tuple]:
       revolute = jtype == 0
       axis = tuple(Rc.T @ np.array([0.0, 1.0, 0.0])) if revolute else (0.0, 0.0, 0.0)
       pos = tuple(Rp.T @ (origin - pcom))
-      orn = tuple(_quat_from_R((Rc.T @ Rp).T))
+      orn = tuple(_quat_from_R(Rc.T @ Rp))
       dof = JOINT_TO_DOF.get(idx)
       q_index = 7 + dof if revolute else -1
       u_index = 6 + dof if revolute else -1
