@@ -1,0 +1,319 @@
+// solo_engine.hip — implementation of the C-ABI in include/solo_engine.h for gfx950.
+// Host logic only: buffer ownership, parameter upload, launches.  The arithmetic is in
+// solo_step_kernel.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "solo_wave_ops.h"
+#include "solo_step_kernel.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EngineBase {
+  virtual ~EngineBase() {}
+  virtual int set_program(const SoloProgram* p) = 0;
+  virtual int reset(const uint8_t* mask, hipStream_t s) = 0;
+  virtual int settle(hipStream_t s) = 0;
+  virtual int set_targets(const void* a, hipStream_t s) = 0;
+  virtual int step(const void* a, uint32_t flags, hipStream_t s) = 0;
+  virtual int rollout(const void* a, int k, uint32_t flags, hipStream_t s) = 0;
+  virtual int view(SoloStateView* v) = 0;
+  virtual int set_params(int which, const void* p, hipStream_t s) = 0;
+  virtual int time_step(const void* a, uint32_t flags, int reps, hipStream_t s, double* ms) = 0;
+  virtual const char* kernel_name() = 0;
+  std::string err;
+};
+
+#define HIP_TRY(expr)                                                                 \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+      return SOLO_ERR_HIP;                                                            \
+    }                                                                                 \
+  } while (0)
+
+template <typename T>
+struct Engine final : EngineBase {
+  SoloConfig cfg;
+  SoloModel model;
+  int n = 0, device = 0, obs_dim = 0;
+  bool have_program = false;
+  solo::KParams<T> hparams;
+  solo::KParams<T>* dparams = nullptr;
+  T *state = nullptr, *snapshot = nullptr, *targets = nullptr, *params = nullptr, *obs = nullptr,
+    *reward = nullptr, *settle_actions = nullptr;
+  uint8_t* done = nullptr;
+  int32_t* term_count = nullptr;
+  double* stats = nullptr;
+
+  ~Engine() override {
+    (void)hipSetDevice(device);
+    for (void* p : {(void*)dparams, (void*)state, (void*)snapshot, (void*)targets, (void*)params,
+                    (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
+                    (void*)term_count, (void*)stats})
+      if (p) (void)hipFree(p);
+  }
+
+  int init(const SoloConfig& c, const SoloModel& m, int num_envs, int dev) {
+    cfg = c; model = m; n = num_envs; device = dev;
+    HIP_TRY(hipSetDevice(device));
+    solo::pack_params<T>(cfg, model, &hparams);
+    const size_t ns = (size_t)n * SOLO_STATE_STRIDE;
+    HIP_TRY(hipMalloc((void**)&dparams, sizeof(hparams)));
+    HIP_TRY(hipMalloc((void**)&state, ns * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&snapshot, ns * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&targets, (size_t)n * SOLO_NUM_JOINTS * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&settle_actions, (size_t)n * SOLO_NUM_JOINTS * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&params, (size_t)n * 4 * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&obs, (size_t)n * SOLO_MAX_OBS * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&reward, (size_t)n * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&done, (size_t)n));
+    HIP_TRY(hipMalloc((void**)&term_count, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&stats, 8 * sizeof(double)));
+    HIP_TRY(hipMemset(obs, 0, (size_t)n * SOLO_MAX_OBS * sizeof(T)));
+    HIP_TRY(hipMemset(reward, 0, (size_t)n * sizeof(T)));
+    HIP_TRY(hipMemset(done, 0, (size_t)n));
+    HIP_TRY(hipMemset(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t)));
+    HIP_TRY(hipMemset(stats, 0, 8 * sizeof(double)));
+    std::vector<T> hp((size_t)n * 4, T(0));
+    std::vector<T> ha((size_t)n * SOLO_NUM_JOINTS);
+    for (int e = 0; e < n; ++e) {
+      hp[(size_t)e * 4 + 0] = (T)cfg.lateral_friction;
+      hp[(size_t)e * 4 + 1] = T(1);
+      // settle targets are absolute radians; the kernel multiplies actions by action_scale
+      for (int j = 0; j < SOLO_NUM_JOINTS; ++j)
+        ha[(size_t)e * SOLO_NUM_JOINTS + j] = (T)(cfg.settle_targets[j] / cfg.action_scale);
+    }
+    HIP_TRY(hipMemcpy(params, hp.data(), hp.size() * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(settle_actions, ha.data(), ha.size() * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dparams, &hparams, sizeof(hparams), hipMemcpyHostToDevice));
+    return settle(nullptr);
+  }
+
+  solo::KBuffers<T> buffers(const T* actions, uint32_t flags) const {
+    solo::KBuffers<T> b;
+    b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
+    b.params = params; b.obs = obs; b.reward = reward; b.done = done; b.term_count = term_count;
+    b.stats = stats; b.num_envs = n; b.flags = flags;
+    return b;
+  }
+
+  int launch(const T* actions, uint32_t flags, hipStream_t s) {
+    // one 64-lane workgroup (= one wavefront) per robot
+    hipLaunchKernelGGL(solo::solo_step_kernel<T>, dim3(n), dim3(64), 0, s, dparams, buffers(actions, flags));
+    HIP_TRY(hipGetLastError());
+    return SOLO_OK;
+  }
+
+  int settle(hipStream_t s) override {
+    HIP_TRY(hipSetDevice(device));
+    const int total = n * SOLO_STATE_STRIDE;
+    hipLaunchKernelGGL(solo::solo_init_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, state, targets,
+                       (T)cfg.start_pos[0], (T)cfg.start_pos[1], (T)cfg.start_pos[2], (T)cfg.start_quat[0],
+                       (T)cfg.start_quat[1], (T)cfg.start_quat[2], (T)cfg.start_quat[3], n);
+    HIP_TRY(hipGetLastError());
+    // the snapshot doubles as the divergence fallback during the settle loop itself
+    HIP_TRY(hipMemcpyAsync(snapshot, state, (size_t)total * sizeof(T), hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < cfg.settle_steps; ++i)
+      if (int rc = launch(settle_actions, SOLO_STEP_PHYSICS, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(snapshot, state, (size_t)total * sizeof(T), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(stats, 0, 8 * sizeof(double), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SOLO_OK;
+  }
+
+  int set_program(const SoloProgram* p) override {
+    HIP_TRY(hipSetDevice(device));
+    solo::KParams<T> tmp = hparams;
+    if (int rc = solo::pack_program<T>(*p, &tmp, &err)) return rc;
+    hparams = tmp;
+    obs_dim = p->num_obs;
+    have_program = true;
+    // uploads are rare (registration time): a blocking copy keeps later launches ordered
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dparams, &hparams, sizeof(hparams), hipMemcpyHostToDevice));
+    return SOLO_OK;
+  }
+
+  int reset(const uint8_t* mask, hipStream_t s) override {
+    HIP_TRY(hipSetDevice(device));
+    const int total = n * SOLO_STATE_STRIDE;
+    hipLaunchKernelGGL(solo::solo_reset_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, state, snapshot,
+                       term_count, mask, n);
+    HIP_TRY(hipGetLastError());
+    return SOLO_OK;
+  }
+
+  int set_targets(const void* a, hipStream_t s) override {
+    if (!a) { err = "actions must not be NULL"; return SOLO_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    const int total = n * SOLO_NUM_JOINTS;
+    hipLaunchKernelGGL(solo::solo_set_targets_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, (const T*)a,
+                       targets, (T)cfg.action_scale, total);
+    HIP_TRY(hipGetLastError());
+    return SOLO_OK;
+  }
+
+  int check_flags(uint32_t flags) {
+    if (flags == 0 || (flags & ~SOLO_STEP_ALL)) { err = "bad step flags"; return SOLO_ERR_INVALID_ARG; }
+    if ((flags & (SOLO_STEP_OBS | SOLO_STEP_REWARD | SOLO_STEP_DONE)) && !have_program) {
+      err = "no observation/reward/termination program registered";
+      return SOLO_ERR_NO_PROGRAM;
+    }
+    // mirrors the ValueErrors of obs.py:138-139, rewards.py:115-116, termination.py:43-44
+    if ((flags & SOLO_STEP_OBS) && hparams.num_obs == 0) { err = "Need to register at least one observation instance"; return SOLO_ERR_NO_PROGRAM; }
+    if ((flags & SOLO_STEP_REWARD) && hparams.num_reward_ops == 0) { err = "Need to register at least one reward instance"; return SOLO_ERR_NO_PROGRAM; }
+    if ((flags & SOLO_STEP_DONE) && hparams.num_terms == 0) { err = "Need to register at least one termination instance"; return SOLO_ERR_NO_PROGRAM; }
+    return SOLO_OK;
+  }
+
+  int step(const void* a, uint32_t flags, hipStream_t s) override {
+    if (int rc = check_flags(flags)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return launch((const T*)a, flags, s);
+  }
+
+  int rollout(const void* a, int k, uint32_t flags, hipStream_t s) override {
+    if (int rc = check_flags(flags)) return rc;
+    if (!a || k < 0) { err = "rollout needs actions [K][N][12]"; return SOLO_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    const T* act = (const T*)a;
+    for (int i = 0; i < k; ++i)
+      if (int rc = launch(act + (size_t)i * n * SOLO_NUM_JOINTS, flags, s)) return rc;
+    return SOLO_OK;
+  }
+
+  int time_step(const void* a, uint32_t flags, int reps, hipStream_t s, double* ms) override {
+    if (int rc = check_flags(flags)) return rc;
+    if (reps <= 0 || !ms) { err = "reps must be positive"; return SOLO_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i)
+      if (int rc = launch((const T*)a, flags, s)) return rc;
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = (double)t / reps;
+    return SOLO_OK;
+  }
+
+  int view(SoloStateView* v) override {
+    v->num_envs = n;
+    v->dtype = sizeof(T) == 4 ? SOLO_F32 : SOLO_F64;
+    v->state_stride = SOLO_STATE_STRIDE;
+    v->obs_dim = obs_dim;
+    v->state = state; v->snapshot = snapshot; v->targets = targets; v->obs = obs; v->reward = reward;
+    v->done = done; v->term_count = term_count; v->params = params; v->stats = stats;
+    return SOLO_OK;
+  }
+
+  int set_params(int which, const void* p, hipStream_t s) override {
+    if (which < 0 || which > 1 || !p) { err = "which must be 0 (friction) or 1 (base mass scale)"; return SOLO_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy2DAsync(params + which, 4 * sizeof(T), p, sizeof(T), sizeof(T), n, hipMemcpyDeviceToDevice, s));
+    return SOLO_OK;
+  }
+
+  const char* kernel_name() override { return sizeof(T) == 4 ? "solo_step_kernel<float>" : "solo_step_kernel<double>"; }
+};
+
+int check_config(const SoloConfig* c, std::string* err) {
+  auto fail = [&](const char* s) { *err = s; return (int)SOLO_ERR_INVALID_ARG; };
+  if (c->abi_version != SOLO_ABI_VERSION) return fail("abi_version mismatch");
+  if (c->dtype != SOLO_F32 && c->dtype != SOLO_F64) return fail("dtype must be SOLO_F32 or SOLO_F64");
+  if (!(c->dt > 0)) return fail("dt must be positive");
+  if (c->solver_iterations < 1 || c->solver_iterations > 10000) return fail("solver_iterations out of range");
+  if (c->settle_steps < 0 || c->settle_steps > 100000) return fail("settle_steps out of range");
+  if (c->restitution != 0.0) return fail("only restitution 0 is supported (gym_solo configs.py:23)");
+  if (!(c->action_scale > 0)) return fail("action_scale must be positive");
+  if (c->lateral_friction < 0 || c->contact_margin < 0 || c->contact_erp < 0) return fail("negative contact parameter");
+  return SOLO_OK;
+}
+
+}  // namespace
+
+struct SoloEngine { EngineBase* impl; };
+
+extern "C" {
+
+int solo_abi_version(void) { return SOLO_ABI_VERSION; }
+const char* solo_last_create_error(void) { return g_create_error.c_str(); }
+
+int solo_engine_create(const SoloConfig* cfg, const SoloModel* model, int32_t num_envs, int32_t device_id,
+                       SoloEngine** out) {
+  if (!cfg || !model || !out) { g_create_error = "NULL argument"; return SOLO_ERR_INVALID_ARG; }
+  *out = nullptr;
+  if (num_envs < 1 || num_envs > (1 << 24)) { g_create_error = "num_envs out of range"; return SOLO_ERR_INVALID_ARG; }
+  if (int rc = check_config(cfg, &g_create_error)) return rc;
+  if (int rc = solo::validate_model(*model, &g_create_error)) return rc;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    g_create_error = "no HIP device visible: the Solo8 engine has no CPU fallback";
+    return SOLO_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= count) { g_create_error = "device_id out of range"; return SOLO_ERR_INVALID_ARG; }
+  EngineBase* impl = nullptr;
+  int rc;
+  if (cfg->dtype == SOLO_F32) {
+    auto* e = new (std::nothrow) Engine<float>();
+    impl = e;
+    rc = e ? e->init(*cfg, *model, num_envs, device_id) : SOLO_ERR_HIP;
+  } else {
+    auto* e = new (std::nothrow) Engine<double>();
+    impl = e;
+    rc = e ? e->init(*cfg, *model, num_envs, device_id) : SOLO_ERR_HIP;
+  }
+  if (rc != SOLO_OK) {
+    g_create_error = impl ? impl->err : "out of host memory";
+    delete impl;
+    return rc;
+  }
+  *out = new SoloEngine{impl};
+  return SOLO_OK;
+}
+
+int solo_engine_destroy(SoloEngine* eng) {
+  if (!eng) return SOLO_ERR_INVALID_ARG;
+  delete eng->impl;
+  delete eng;
+  return SOLO_OK;
+}
+
+#define ENG_CALL(expr) (eng && eng->impl ? (eng->impl->expr) : (int)SOLO_ERR_INVALID_ARG)
+
+int solo_engine_set_program(SoloEngine* eng, const SoloProgram* prog) {
+  if (!prog) return SOLO_ERR_INVALID_ARG;
+  return ENG_CALL(set_program(prog));
+}
+int solo_engine_reset(SoloEngine* eng, const uint8_t* mask_dev, void* stream) { return ENG_CALL(reset(mask_dev, (hipStream_t)stream)); }
+int solo_engine_settle(SoloEngine* eng, void* stream) { return ENG_CALL(settle((hipStream_t)stream)); }
+int solo_engine_set_targets(SoloEngine* eng, const void* a, void* stream) { return ENG_CALL(set_targets(a, (hipStream_t)stream)); }
+int solo_engine_step(SoloEngine* eng, const void* a, uint32_t flags, void* stream) { return ENG_CALL(step(a, flags, (hipStream_t)stream)); }
+int solo_engine_rollout(SoloEngine* eng, const void* a, int32_t k, uint32_t flags, void* stream) { return ENG_CALL(rollout(a, k, flags, (hipStream_t)stream)); }
+int solo_engine_get_view(SoloEngine* eng, SoloStateView* out) {
+  if (!out) return SOLO_ERR_INVALID_ARG;
+  return ENG_CALL(view(out));
+}
+int solo_engine_set_params(SoloEngine* eng, int32_t which, const void* p, void* stream) { return ENG_CALL(set_params(which, p, (hipStream_t)stream)); }
+const char* solo_engine_kernel_name(SoloEngine* eng) { return eng && eng->impl ? eng->impl->kernel_name() : ""; }
+int solo_engine_time_step(SoloEngine* eng, const void* a, uint32_t flags, int32_t reps, void* stream, double* ms) {
+  return ENG_CALL(time_step(a, flags, reps, (hipStream_t)stream, ms));
+}
+const char* solo_engine_last_error(SoloEngine* eng) { return eng && eng->impl ? eng->impl->err.c_str() : "invalid engine handle"; }
+
+}  // extern "C"

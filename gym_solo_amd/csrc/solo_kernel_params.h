@@ -1,0 +1,228 @@
+// solo_kernel_params.h — parameter block of the fused step kernel and its host-side packing.
+//
+// The block is wave-uniform: the kernel receives a pointer to it in global memory and the
+// compiler turns the uniform reads into scalar (SMEM) loads.  Only the per-leg and per-row
+// tables are indexed by lane.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../../include/solo_engine.h"
+
+namespace solo {
+
+// lane layout of one wavefront = one robot.  lane = 16*leg + k:
+//   k 0,1      motor rows of the leg's HFE / KFE
+//   k 2..4     knee sphere (model sphere 8+leg): normal, tangent x, tangent y
+//   k 5..7     foot sphere (model sphere 12+leg)
+//   k 8..10    base sphere 2*leg          k 11..13  base sphere 2*leg+1
+//   k 14,15    idle
+enum RowType : int32_t { ROW_IDLE = 0, ROW_MOTOR = 1, ROW_NORMAL = 2, ROW_TAN1 = 3, ROW_TAN2 = 4 };
+enum BodyKind : int32_t { BODY_BASE = 0, BODY_UPPER = 1, BODY_LOWER = 2 };
+
+constexpr int kRowsPerLeg = 14;
+constexpr int kNumRowSlots = 4 * kRowsPerLeg;  // 56 live row slots (A-matrix columns)
+__host__ __device__ constexpr int slot_of_lane(int lane) { return (lane >> 4) * kRowsPerLeg + (lane & 15); }
+__host__ __device__ constexpr int motor_lane(int dof) { return 16 * (dof >> 1) + (dof & 1); }
+__host__ __device__ constexpr int sphere_lane(int s) {
+  return s < 8 ? 16 * (s >> 1) + 8 + 3 * (s & 1) : (s < 12 ? 16 * (s - 8) + 2 : 16 * (s - 12) + 5);
+}
+
+template <typename T>
+struct LegConst {
+  T hip[3];     // HFE joint origin in base frame
+  T knee[3];    // KFE joint origin in upper-leg frame
+  T mU, cU[3], IU[6];  // upper leg: mass, com (link frame), inertia about com (xx yy zz xy xz yz)
+  T mL, cL[3], IL[6];  // lower leg + welded foot
+};
+
+template <typename T>
+struct RowConst {
+  int32_t type;   // RowType
+  int32_t body;   // BodyKind of the sphere's body
+  int32_t dof;    // motor rows: dof index (0..7) ; contact rows: model sphere index
+  int32_t pad;
+  T center[3];    // sphere centre in its body frame
+  T radius;
+};
+
+template <typename T>
+struct ObsElemK {
+  int32_t src, flags;
+  T scale, lo, hi, nlo, range;  // normalise: 2*(a - nlo)/range - 1, range = nhi - nlo (obs.py:152)
+};
+
+template <typename T>
+struct RewardInstrK {
+  int32_t op, pad;
+  T a, b, c;
+};
+
+template <typename T>
+struct KParams {
+  T dt, inv_dt;
+  T gravity[3];
+  T kp_over_dt, one_minus_kd, motor_impulse;
+  T lin_damp, ang_damp;
+  T erp_over_dt, margin;
+  T action_scale;
+  T gauss_scale;  // sqrt(-2 ln 0.1): rewards.py:427 with the default margin_value
+  int32_t iterations, auto_reset;
+  T base_mass, base_I[6];
+  LegConst<T> leg[4];
+  RowConst<T> row[64];
+  int32_t num_obs, num_reward_ops, num_terms, pad0;
+  ObsElemK<T> obs[SOLO_MAX_OBS];
+  RewardInstrK<T> reward[SOLO_MAX_REWARD_OPS];
+  int32_t term_kind[SOLO_MAX_TERMS];
+  int32_t term_param[SOLO_MAX_TERMS];
+};
+
+template <typename T>
+struct KBuffers {
+  T* state;           // [N][32]
+  const T* snapshot;  // [N][32]
+  T* targets;         // [N][12]
+  const T* actions;   // [N][12] or null
+  const T* params;    // [N][4]
+  T* obs;             // [N][D]
+  T* reward;          // [N]
+  uint8_t* done;      // [N]
+  int32_t* term_count;  // [N][4]
+  double* stats;      // [8]
+  int32_t num_envs;
+  uint32_t flags;
+};
+
+// ---- host side: SoloConfig + SoloModel -> KParams ---------------------------------------
+inline int validate_model(const SoloModel& m, std::string* err) {
+  auto fail = [&](const char* s) { if (err) *err = s; return (int)SOLO_ERR_UNSUPPORTED_MODEL; };
+  for (int leg = 0; leg < 4; ++leg) {
+    if (m.parent[2 * leg] != 0) return fail("HFE link must hang off the base");
+    if (m.parent[2 * leg + 1] != 1 + 2 * leg) return fail("KFE link must hang off its HFE link");
+  }
+  for (int j = 0; j < SOLO_NUM_DOF; ++j)
+    if (m.joint_axis[j][0] != 0.0 || m.joint_axis[j][1] != 1.0 || m.joint_axis[j][2] != 0.0)
+      return fail("the HIP kernel is specialised to +y joint axes (Solo8)");
+  for (int a = 0; a < 3; ++a)
+    if (m.com[0][a] != 0.0) return fail("base frame must be the base CoM frame");
+  if (m.num_spheres != SOLO_MAX_SPHERES) return fail("expected 16 collision spheres");
+  for (int s = 0; s < 8; ++s)
+    if (m.sphere_body[s] != 0) return fail("spheres 0..7 must be attached to the base");
+  for (int leg = 0; leg < 4; ++leg)
+    for (int s : {8 + leg, 12 + leg})
+      if (m.sphere_body[s] != 1 + 2 * leg && m.sphere_body[s] != 2 + 2 * leg)
+        return fail("spheres 8+l / 12+l must be attached to leg l");
+  return SOLO_OK;
+}
+
+template <typename T>
+inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) {
+  std::memset(k, 0, sizeof(*k));
+  k->dt = (T)c.dt;
+  k->inv_dt = (T)(1.0 / c.dt);
+  for (int a = 0; a < 3; ++a) k->gravity[a] = (T)c.gravity[a];
+  k->kp_over_dt = (T)(c.motor_kp / c.dt);
+  k->one_minus_kd = (T)(1.0 - c.motor_kd);
+  k->motor_impulse = (T)(c.motor_torque_limit * c.dt);
+  k->lin_damp = (T)c.linear_damping;
+  k->ang_damp = (T)c.angular_damping;
+  k->erp_over_dt = (T)(c.contact_erp / c.dt);
+  k->margin = (T)c.contact_margin;
+  k->action_scale = (T)c.action_scale;
+  k->gauss_scale = (T)std::sqrt(-2.0 * std::log(0.1));
+  k->iterations = c.solver_iterations;
+  k->auto_reset = c.auto_reset;
+  k->base_mass = (T)m.mass[0];
+  for (int a = 0; a < 6; ++a) k->base_I[a] = (T)m.inertia[0][a];
+  for (int leg = 0; leg < 4; ++leg) {
+    LegConst<T>& L = k->leg[leg];
+    const int ju = 2 * leg, jl = 2 * leg + 1, bu = 1 + ju, bl = 1 + jl;
+    for (int a = 0; a < 3; ++a) {
+      L.hip[a] = (T)m.joint_origin[ju][a];
+      L.knee[a] = (T)m.joint_origin[jl][a];
+      L.cU[a] = (T)m.com[bu][a];
+      L.cL[a] = (T)m.com[bl][a];
+    }
+    L.mU = (T)m.mass[bu];
+    L.mL = (T)m.mass[bl];
+    for (int a = 0; a < 6; ++a) { L.IU[a] = (T)m.inertia[bu][a]; L.IL[a] = (T)m.inertia[bl][a]; }
+  }
+  for (int lane = 0; lane < 64; ++lane) k->row[lane].type = ROW_IDLE;
+  for (int d = 0; d < SOLO_NUM_DOF; ++d) {
+    RowConst<T>& r = k->row[motor_lane(d)];
+    r.type = ROW_MOTOR;
+    r.dof = d;
+  }
+  for (int s = 0; s < SOLO_MAX_SPHERES; ++s)
+    for (int q = 0; q < 3; ++q) {
+      RowConst<T>& r = k->row[sphere_lane(s) + q];
+      r.type = ROW_NORMAL + q;
+      r.dof = s;
+      const int b = m.sphere_body[s];
+      r.body = b == 0 ? BODY_BASE : ((b & 1) ? BODY_UPPER : BODY_LOWER);
+      for (int a = 0; a < 3; ++a) r.center[a] = (T)m.sphere_center[s][a];
+      r.radius = (T)m.sphere_radius[s];
+    }
+}
+
+template <typename T>
+inline int pack_program(const SoloProgram& p, KParams<T>* k, std::string* err) {
+  auto fail = [&](const char* s) { if (err) *err = s; return (int)SOLO_ERR_INVALID_ARG; };
+  if (p.num_obs < 0 || p.num_obs > SOLO_MAX_OBS) return fail("num_obs out of range");
+  if (p.num_reward_ops < 0 || p.num_reward_ops > SOLO_MAX_REWARD_OPS) return fail("num_reward_ops out of range");
+  if (p.num_terms < 0 || p.num_terms > SOLO_MAX_TERMS) return fail("num_terms out of range");
+  // the reward program must be a well-formed postfix expression leaving one value
+  int depth = 0;
+  for (int i = 0; i < p.num_reward_ops; ++i) {
+    const int op = p.reward[i].op;
+    if (op < SOLO_R_CONST || op > SOLO_R_MUL) return fail("bad reward opcode");
+    if (op <= SOLO_R_SMALL_CONTROL) ++depth;
+    else if (op == SOLO_R_SCALE) { if (depth < 1) return fail("reward stack underflow"); }
+    else { if (depth < 2) return fail("reward stack underflow"); --depth; }
+    if (depth > 8) return fail("reward stack deeper than 8");
+    if (op >= SOLO_R_FLAT_TORSO && op <= SOLO_R_SMALL_CONTROL) {
+      // rewards.py:405-417: lower <= upper, margin >= 0
+      const double margin = op == SOLO_R_FLAT_TORSO ? p.reward[i].b
+                            : (op == SOLO_R_SMALL_CONTROL ? p.reward[i].a : p.reward[i].c);
+      if (margin < 0) return fail("Margin must be non-negative");
+      const double half = op == SOLO_R_FLAT_TORSO ? p.reward[i].a
+                          : (op == SOLO_R_SMALL_CONTROL ? 0.0 : p.reward[i].b);
+      if (half < 0) return fail("Lower bound is greater than upper bound");
+    }
+  }
+  if (p.num_reward_ops > 0 && depth != 1) return fail("reward program must leave exactly one value");
+  for (int i = 0; i < p.num_obs; ++i)
+    if (p.obs[i].src < 0 || p.obs[i].src >= SOLO_SRC_COUNT) return fail("obs source out of range");
+  for (int i = 0; i < p.num_terms; ++i)
+    if (p.term_kind[i] < SOLO_T_PERPETUAL || p.term_kind[i] > SOLO_T_CONST) return fail("bad termination kind");
+  k->num_obs = p.num_obs;
+  k->num_reward_ops = p.num_reward_ops;
+  k->num_terms = p.num_terms;
+  for (int i = 0; i < p.num_obs; ++i) {
+    ObsElemK<T>& o = k->obs[i];
+    o.src = p.obs[i].src;
+    o.flags = p.obs[i].flags;
+    o.scale = (T)p.obs[i].scale;
+    o.lo = (T)p.obs[i].lo;
+    o.hi = (T)p.obs[i].hi;
+    o.nlo = (T)p.obs[i].nlo;
+    o.range = (T)(p.obs[i].nhi - p.obs[i].nlo);
+  }
+  for (int i = 0; i < p.num_reward_ops; ++i) {
+    k->reward[i].op = p.reward[i].op;
+    k->reward[i].a = (T)p.reward[i].a;
+    k->reward[i].b = (T)p.reward[i].b;
+    k->reward[i].c = (T)p.reward[i].c;
+  }
+  for (int i = 0; i < SOLO_MAX_TERMS; ++i) {
+    k->term_kind[i] = p.term_kind[i];
+    k->term_param[i] = p.term_param[i];
+  }
+  return SOLO_OK;
+}
+
+}  // namespace solo

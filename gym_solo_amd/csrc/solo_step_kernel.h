@@ -1,0 +1,673 @@
+// solo_step_kernel.h — the fused Solo8 env step for gfx950: ONE WAVEFRONT PER ROBOT.
+//
+// Replaces, for N robots at once, the reference's per-step call sequence
+//   setJointMotorControlArray + stepSimulation      gym_solo/envs/solo8v2vanilla.py:87-91
+//   ObservationFactory.get_obs                      gym_solo/core/obs.py:130-159
+//   RewardFactory.get_reward                        gym_solo/core/rewards.py:104-118
+//   TerminationFactory.is_terminated                gym_solo/core/termination.py:38-50
+//
+// Design (written for CDNA4, not translated from anything):
+//  * grid = N workgroups of 64 threads; the robot's 128-B state record is ONE coalesced load.
+//  * lane = 16*leg + k.  The four 16-lane groups run the leg-local part of the articulated
+//    dynamics (kinematics, composite inertias, Newton-Euler bias) in parallel; the base-level
+//    sums over the legs are wavefront shuffles (xor 16 / xor 32).
+//  * The floating base couples the legs only through a 6x6 block, so the joint-space inverse
+//    inertia is applied in factored form: Cholesky of the four 2x2 leg blocks P_l and of the
+//    6x6 base Schur complement S = M_bb - sum_l M_bl P_l^-1 M_lb (the base's articulated-body
+//    inertia).  Every constraint row r (8 motor rows + 3 per touching sphere) is owned by ONE
+//    LANE, which whitens its Jacobian against those factors (ghat_r in R^6, hhat_r in R^2), so
+//    that the Delassus matrix is  A_sr = ghat_s.ghat_r + [same leg] hhat_s.hhat_r.
+//  * Lane s keeps row s of A in registers (56 VGPRs in f32).  Projected Gauss-Seidel then costs
+//    per row: one fma + clamp + v_readlane broadcast of the impulse change + one fma in every
+//    lane; rows of spheres that do not touch are skipped with wave-uniform branches (no
+//    divergence: the whole wave belongs to one robot).
+//  * obs / reward / done are evaluated from the new state by the same wave (lane k = obs
+//    element k -> one coalesced store), reward as a small postfix program.
+// No MFMA: there is no dense contraction here (14 dofs, <= 56 rows per robot).
+//
+// The including translation unit must provide solo::lane_id/block_id/wave_sync/wave_readlane/
+// wave_shfl_xor/wave_ballot/Real<T>/stats_add (solo_wave_ops.h on the GPU).
+#pragma once
+
+#include "solo_kernel_params.h"
+
+namespace solo {
+
+template <typename T> struct V3 { T x, y, z; };
+template <typename T> __device__ __forceinline__ V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator*(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> __device__ __forceinline__ V3<T> cross(V3<T> a, V3<T> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// rotation about +y by the angle whose cos/sin are (c, s): child -> parent coordinates
+template <typename T> __device__ __forceinline__ V3<T> roty(T c, T s, V3<T> v) {
+  return {c * v.x + s * v.z, v.y, c * v.z - s * v.x};
+}
+// y_hat x r
+template <typename T> __device__ __forceinline__ V3<T> ycross(V3<T> r) { return {r.z, T(0), -r.x}; }
+// symmetric 3x3 (xx yy zz xy xz yz) times vector
+template <typename T> __device__ __forceinline__ V3<T> symmul(const T* I, V3<T> v) {
+  return {I[0] * v.x + I[3] * v.y + I[4] * v.z, I[3] * v.x + I[1] * v.y + I[5] * v.z,
+          I[4] * v.x + I[5] * v.y + I[2] * v.z};
+}
+// R I R^T for R = Ry
+template <typename T> __device__ __forceinline__ void rot_inertia_y(T c, T s, const T* I, T* o) {
+  const T cc = c * c, ss = s * s, cs = c * s;
+  o[0] = cc * I[0] + T(2) * cs * I[4] + ss * I[2];
+  o[1] = I[1];
+  o[2] = ss * I[0] - T(2) * cs * I[4] + cc * I[2];
+  o[3] = c * I[3] + s * I[5];
+  o[4] = cs * (I[2] - I[0]) + (cc - ss) * I[4];
+  o[5] = c * I[5] - s * I[3];
+}
+template <typename T> __device__ __forceinline__ T sum_over_legs(T x) {
+  x += wave_shfl_xor(x, 16);
+  x += wave_shfl_xor(x, 32);
+  return x;
+}
+template <typename T> __device__ __forceinline__ T sum_over_group16(T x) {
+  x += wave_shfl_xor(x, 1);
+  x += wave_shfl_xor(x, 2);
+  x += wave_shfl_xor(x, 4);
+  x += wave_shfl_xor(x, 8);
+  return x;
+}
+
+// Euler angles of pybullet.getEulerFromQuaternion ([recalled] pybullet.c; call sites
+// gym_solo/core/obs.py:271, rewards.py:233,265; known answer test_obs_observations.py:67-88)
+template <typename T>
+__device__ __forceinline__ void euler_from_quat(T x, T y, T z, T w, T* roll, T* pitch, T* yaw) {
+  using R = Real<T>;
+  const T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  const T sarg = T(-2) * (x * z - w * y);
+  const T half_pi = T(1.5707963267948966);
+  if (sarg <= T(-0.99999)) {
+    *roll = T(0); *pitch = -half_pi; *yaw = T(2) * R::atan2(x, -y);
+  } else if (sarg >= T(0.99999)) {
+    *roll = T(0); *pitch = half_pi; *yaw = T(2) * R::atan2(-x, y);
+  } else {
+    *roll = R::atan2(T(2) * (y * z + w * x), squ - sqx - sqy + sqz);
+    *pitch = R::asin(sarg);
+    *yaw = R::atan2(T(2) * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+}
+
+// gaussian tolerance, gym_solo/core/rewards.py:384-431 with margin_value = 0.1
+template <typename T>
+__device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
+  const bool within = (lo <= x) && (x <= hi);
+  if (margin == T(0)) return within ? T(1) : T(0);
+  const T sig = ((x < lo) ? (lo - x) : (x - hi)) / margin;
+  const T t = sig * scale;
+  const T v = Real<T>::exp(T(-0.5) * (t * t));
+  return within ? T(1) : v;
+}
+
+// ---- PGS row steps: LANE is the (compile-time) lane that owns the row -------------------
+template <typename T, int LANE>
+__device__ __forceinline__ void pgs_row_box(T& lam, T& w, T inv_d, T lo, T hi, const T (&A)[kNumRowSlots], int lane) {
+  T cand = lam - w * inv_d;
+  cand = Real<T>::min(Real<T>::max(cand, lo), hi);
+  const T delta = wave_readlane(cand - lam, LANE);
+  lam = (lane == LANE) ? cand : lam;
+  w += A[slot_of_lane(LANE)] * delta;
+}
+// one touching sphere: normal row at lane BASE, tangents at BASE+1, BASE+2
+template <typename T, int BASE>
+__device__ __forceinline__ void pgs_contact(T& lam, T& w, T inv_d, T mu, const T (&A)[kNumRowSlots], int lane) {
+  T cand = Real<T>::max(lam - w * inv_d, T(0));
+  const T ln = wave_readlane(cand, BASE);
+  const T dn = wave_readlane(cand - lam, BASE);
+  lam = (lane == BASE) ? cand : lam;
+  w += A[slot_of_lane(BASE)] * dn;
+  const T lim = mu * ln;
+  pgs_row_box<T, BASE + 1>(lam, w, inv_d, -lim, lim, A, lane);
+  pgs_row_box<T, BASE + 2>(lam, w, inv_d, -lim, lim, A, lane);
+}
+
+// A[slot(R)] for the three rows of sphere S (skipped when the sphere does not touch)
+template <typename T, int R>
+__device__ __forceinline__ void build_a_entry(T (&A)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, int lane) {
+  const T* rv = rowvec[R];
+  T a = gh[0] * rv[0] + gh[1] * rv[1] + gh[2] * rv[2] + gh[3] * rv[3] + gh[4] * rv[4] + gh[5] * rv[5];
+  const T b = hh[0] * rv[6] + hh[1] * rv[7];
+  A[slot_of_lane(R)] = ((lane >> 4) == (R >> 4)) ? (a + b) : a;
+}
+
+template <typename T, int S>
+struct ForSpheres {
+  static __device__ __forceinline__ void build(unsigned long long mask, T (&A)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, int lane) {
+    constexpr int B = sphere_lane(S);
+    if ((mask >> B) & 1ull) {
+      build_a_entry<T, B>(A, rowvec, gh, hh, lane);
+      build_a_entry<T, B + 1>(A, rowvec, gh, hh, lane);
+      build_a_entry<T, B + 2>(A, rowvec, gh, hh, lane);
+    }
+    ForSpheres<T, S + 1>::build(mask, A, rowvec, gh, hh, lane);
+  }
+  static __device__ __forceinline__ void solve(unsigned long long mask, T& lam, T& w, T inv_d, T mu, const T (&A)[kNumRowSlots], int lane) {
+    constexpr int B = sphere_lane(S);
+    if ((mask >> B) & 1ull) pgs_contact<T, B>(lam, w, inv_d, mu, A, lane);
+    ForSpheres<T, S + 1>::solve(mask, lam, w, inv_d, mu, A, lane);
+  }
+};
+template <typename T>
+struct ForSpheres<T, SOLO_MAX_SPHERES> {
+  static __device__ __forceinline__ void build(unsigned long long, T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, int) {}
+  static __device__ __forceinline__ void solve(unsigned long long, T&, T&, T, T, const T (&)[kNumRowSlots], int) {}
+};
+template <typename T, int D>
+struct ForMotors {
+  static __device__ __forceinline__ void build(T (&A)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, int lane) {
+    build_a_entry<T, motor_lane(D)>(A, rowvec, gh, hh, lane);
+    ForMotors<T, D + 1>::build(A, rowvec, gh, hh, lane);
+  }
+  static __device__ __forceinline__ void solve(T& lam, T& w, T inv_d, T imp, const T (&A)[kNumRowSlots], int lane) {
+    pgs_row_box<T, motor_lane(D)>(lam, w, inv_d, -imp, imp, A, lane);
+    ForMotors<T, D + 1>::solve(lam, w, inv_d, imp, A, lane);
+  }
+};
+template <typename T>
+struct ForMotors<T, SOLO_NUM_DOF> {
+  static __device__ __forceinline__ void build(T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, int) {}
+  static __device__ __forceinline__ void solve(T&, T&, T, T, const T (&)[kNumRowSlots], int) {}
+};
+
+// ------------------------------------------------------------------------------------------
+// physics: A3 + A4 of SURVEY.md §8a.  Reads s_state (old), writes s_state (new).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void physics_step(const KParams<T>* __restrict__ P, T* s_state, const T* s_tgt,
+                                             T (*s_rowvec)[8], T mu, T mass_scale, int lane) {
+  using R = Real<T>;
+  const int leg = lane >> 4, k = lane & 15;
+  const T dt = P->dt;
+
+  // ---- base: rotation (body -> world), velocities and gravity in base coordinates ----------
+  const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
+  const T r00 = T(1) - T(2) * (qy * qy + qz * qz), r01 = T(2) * (qx * qy - qw * qz), r02 = T(2) * (qx * qz + qw * qy);
+  const T r10 = T(2) * (qx * qy + qw * qz), r11 = T(1) - T(2) * (qx * qx + qz * qz), r12 = T(2) * (qy * qz - qw * qx);
+  const T r20 = T(2) * (qx * qz - qw * qy), r21 = T(2) * (qy * qz + qw * qx), r22 = T(1) - T(2) * (qx * qx + qy * qy);
+  const V3<T> ww = {s_state[SOLO_S_ANGVEL], s_state[SOLO_S_ANGVEL + 1], s_state[SOLO_S_ANGVEL + 2]};
+  const V3<T> vw = {s_state[SOLO_S_LINVEL], s_state[SOLO_S_LINVEL + 1], s_state[SOLO_S_LINVEL + 2]};
+  const V3<T> gw = {P->gravity[0], P->gravity[1], P->gravity[2]};
+  // R^T v
+  const V3<T> om = {r00 * ww.x + r10 * ww.y + r20 * ww.z, r01 * ww.x + r11 * ww.y + r21 * ww.z, r02 * ww.x + r12 * ww.y + r22 * ww.z};
+  const V3<T> vb = {r00 * vw.x + r10 * vw.y + r20 * vw.z, r01 * vw.x + r11 * vw.y + r21 * vw.z, r02 * vw.x + r12 * vw.y + r22 * vw.z};
+  const V3<T> gb = {r00 * gw.x + r10 * gw.y + r20 * gw.z, r01 * gw.x + r11 * gw.y + r21 * gw.z, r02 * gw.x + r12 * gw.y + r22 * gw.z};
+  const V3<T> nb = {r20, r21, r22};  // world z (ground normal) in base coordinates
+
+  // ---- leg-local kinematics (each 16-lane group works on its own leg) -----------------------
+  const LegConst<T>& L = P->leg[leg];
+  const T q1 = s_state[SOLO_S_Q + 2 * leg], q2 = s_state[SOLO_S_Q + 2 * leg + 1];
+  const T qd1 = s_state[SOLO_S_QD + 2 * leg], qd2 = s_state[SOLO_S_QD + 2 * leg + 1];
+  T s1, c1, s12, c12;
+  R::sincos(q1, &s1, &c1);
+  R::sincos(q1 + q2, &s12, &c12);
+  const V3<T> o1 = {L.hip[0], L.hip[1], L.hip[2]};
+  const V3<T> o2 = o1 + roty(c1, s1, V3<T>{L.knee[0], L.knee[1], L.knee[2]});
+  const V3<T> cU = o1 + roty(c1, s1, V3<T>{L.cU[0], L.cU[1], L.cU[2]});
+  const V3<T> cL = o2 + roty(c12, s12, V3<T>{L.cL[0], L.cL[1], L.cL[2]});
+  T IU[6], IL[6];
+  rot_inertia_y(c1, s1, L.IU, IU);
+  rot_inertia_y(c12, s12, L.IL, IL);
+  const T mU = L.mU, mL = L.mL;
+
+  // ---- joint-space inertia blocks of the leg (composite-rigid-body, closed form) -----------
+  const V3<T> rU1 = cU - o1, rL1 = cL - o1, rL2 = cL - o2;
+  const V3<T> tU1 = ycross(rU1), tL1 = ycross(rL1), tL2 = ycross(rL2);
+  const V3<T> IUy = {IU[3], IU[1], IU[5]}, ILy = {IL[3], IL[1], IL[5]};  // I * y_hat
+  // column of M for dof 1 / dof 2: [n; f] = [angular momentum about the base origin; linear]
+  const V3<T> f1 = mU * tU1 + mL * tL1, f2 = mL * tL2;
+  const V3<T> n1 = IUy + ILy + mU * cross(cU, tU1) + mL * cross(cL, tL1);
+  const V3<T> n2 = ILy + mL * cross(cL, tL2);
+  const T P11 = mU * dot(tU1, tU1) + mL * dot(tL1, tL1) + IU[1] + IL[1];
+  const T P12 = mL * dot(tL1, tL2) + IL[1];
+  const T P22 = mL * dot(tL2, tL2) + IL[1];
+  // Cholesky of the 2x2 leg block, W = Lp^-1 [F1;F2], K = P^-1 M_lb = Lp^-T W
+  const T iL11 = R::rsqrt(P11);
+  const T L21 = P12 * iL11;
+  const T iL22 = R::rsqrt(P22 - L21 * L21);
+  T W1[6] = {n1.x * iL11, n1.y * iL11, n1.z * iL11, f1.x * iL11, f1.y * iL11, f1.z * iL11};
+  const T F2[6] = {n2.x, n2.y, n2.z, f2.x, f2.y, f2.z};
+  T W2[6], K1[6], K2[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    W2[i] = (F2[i] - L21 * W1[i]) * iL22;
+    K2[i] = W2[i] * iL22;
+    K1[i] = (W1[i] - L21 * K2[i]) * iL11;
+  }
+
+  // ---- bias forces of the leg: Newton-Euler with classical accelerations in the frame that
+  //      coincides with the base at this instant (gravity + Bullet-style damping included) ----
+  const V3<T> yh = {T(0), T(1), T(0)};
+  const V3<T> wU = {om.x, om.y + qd1, om.z}, wL = {om.x, om.y + qd1 + qd2, om.z};
+  const V3<T> aU = {-qd1 * om.z, T(0), qd1 * om.x};                       // om x (qd1 y)
+  const V3<T> aL = {aU.x - qd2 * wU.z, T(0), aU.z + qd2 * wU.x};          // + wU x (qd2 y)
+  const V3<T> a_o1 = cross(om, cross(om, o1));
+  const V3<T> d12 = o2 - o1;
+  const V3<T> a_cU = a_o1 + cross(aU, rU1) + cross(wU, cross(wU, rU1));
+  const V3<T> a_o2 = a_o1 + cross(aU, d12) + cross(wU, cross(wU, d12));
+  const V3<T> a_cL = a_o2 + cross(aL, rL2) + cross(wL, cross(wL, rL2));
+  const V3<T> v_cU = vb + cross(om, cU) + qd1 * tU1;
+  const V3<T> v_cL = vb + cross(om, cL) + qd1 * tL1 + qd2 * tL2;
+  const T kl = P->lin_damp, ka = P->ang_damp;
+  const T dU = kl * (T(1) + R::sqrt(dot(v_cU, v_cU))), dL = kl * (T(1) + R::sqrt(dot(v_cL, v_cL)));
+  const T eU = ka * (T(1) + R::sqrt(dot(wU, wU))), eL = ka * (T(1) + R::sqrt(dot(wL, wL)));
+  const V3<T> FU = mU * (a_cU - gb + dU * v_cU);
+  const V3<T> FL = mL * (a_cL - gb + dL * v_cL);
+  const V3<T> IwU = symmul(IU, wU), IwL = symmul(IL, wL);
+  const V3<T> NU = symmul(IU, aU) + cross(wU, IwU) + eU * IwU;
+  const V3<T> NL = symmul(IL, aL) + cross(wL, IwL) + eL * IwL;
+  const T h2 = dot(yh, NL + cross(rL2, FL));
+  const T h1 = dot(yh, NU + cross(rU1, FU) + NL + cross(rL1, FL));
+  const V3<T> Fleg = FU + FL;
+  const V3<T> Nleg = NU + cross(cU, FU) + NL + cross(cL, FL);
+  // e = Lp^-1 h ; y = Lp^-T e = P^-1 h
+  const T e1 = h1 * iL11, e2 = (h2 - L21 * e1) * iL22;
+  const T y2 = e2 * iL22, y1 = (e1 - L21 * y2) * iL11;
+
+  // ---- base level: Schur complement S and right-hand side, summed over the four legs -------
+  // leg composite about the base origin
+  const T mleg = mU + mL;
+  const V3<T> mc = mU * cU + mL * cL;
+  T IO[6];
+  IO[0] = IU[0] + IL[0] + mU * (cU.y * cU.y + cU.z * cU.z) + mL * (cL.y * cL.y + cL.z * cL.z);
+  IO[1] = IU[1] + IL[1] + mU * (cU.x * cU.x + cU.z * cU.z) + mL * (cL.x * cL.x + cL.z * cL.z);
+  IO[2] = IU[2] + IL[2] + mU * (cU.x * cU.x + cU.y * cU.y) + mL * (cL.x * cL.x + cL.y * cL.y);
+  IO[3] = IU[3] + IL[3] - mU * cU.x * cU.y - mL * cL.x * cL.y;
+  IO[4] = IU[4] + IL[4] - mU * cU.x * cU.z - mL * cL.x * cL.z;
+  IO[5] = IU[5] + IL[5] - mU * cU.y * cU.z - mL * cL.y * cL.z;
+  T S[6][6];  // lower triangle used
+  S[0][0] = IO[0]; S[1][0] = IO[3]; S[1][1] = IO[1]; S[2][0] = IO[4]; S[2][1] = IO[5]; S[2][2] = IO[2];
+  S[3][0] = T(0);  S[3][1] = mc.z;  S[3][2] = -mc.y;
+  S[4][0] = -mc.z; S[4][1] = T(0);  S[4][2] = mc.x;
+  S[5][0] = mc.y;  S[5][1] = -mc.x; S[5][2] = T(0);
+  S[3][3] = mleg; S[4][3] = T(0); S[4][4] = mleg; S[5][3] = T(0); S[5][4] = T(0); S[5][5] = mleg;
+  T rhs[6] = {-Nleg.x, -Nleg.y, -Nleg.z, -Fleg.x, -Fleg.y, -Fleg.z};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) S[i][j] = sum_over_legs(S[i][j] - W1[i] * W1[j] - W2[i] * W2[j]);
+    rhs[i] = sum_over_legs(rhs[i] + W1[i] * e1 + W2[i] * e2);
+  }
+  // the base body itself (mass / inertia scaled per env for domain randomisation)
+  {
+    const T m0 = P->base_mass * mass_scale;
+    T I0[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) I0[i] = P->base_I[i] * mass_scale;
+    S[0][0] += I0[0]; S[1][0] += I0[3]; S[1][1] += I0[1]; S[2][0] += I0[4]; S[2][1] += I0[5]; S[2][2] += I0[2];
+    S[3][3] += m0; S[4][4] += m0; S[5][5] += m0;
+    const V3<T> Iw = symmul(I0, om);
+    const V3<T> N0 = cross(om, Iw) + (ka * (T(1) + R::sqrt(dot(om, om)))) * Iw;
+    const V3<T> F0 = m0 * ((kl * (T(1) + R::sqrt(dot(vb, vb)))) * vb - gb);
+    rhs[0] -= N0.x; rhs[1] -= N0.y; rhs[2] -= N0.z;
+    rhs[3] -= F0.x; rhs[4] -= F0.y; rhs[5] -= F0.z;
+  }
+  // Cholesky S = C C^T (C lower, stored in S; iC = 1/diag)
+  T iC[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    T d = S[j][j];
+#pragma unroll
+    for (int m = 0; m < j; ++m) d -= S[j][m] * S[j][m];
+    iC[j] = R::rsqrt(d);
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      T s = S[i][j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) s -= S[i][m] * S[j][m];
+      S[i][j] = s * iC[j];
+    }
+  }
+  // unconstrained acceleration: x_b = S^-1 rhs ; qdd_l = -y_l - K_l x_b
+  T xb[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    T s = rhs[i];
+#pragma unroll
+    for (int m = 0; m < i; ++m) s -= S[i][m] * xb[m];
+    xb[i] = s * iC[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    T s = xb[i];
+#pragma unroll
+    for (int m = i + 1; m < 6; ++m) s -= S[m][i] * xb[m];
+    xb[i] = s * iC[i];
+  }
+  T kx1 = T(0), kx2 = T(0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { kx1 += K1[i] * xb[i]; kx2 += K2[i] * xb[i]; }
+  // velocities after the unconstrained update (semi-implicit Euler)
+  T ub[6] = {om.x + dt * xb[0], om.y + dt * xb[1], om.z + dt * xb[2],
+             vb.x + dt * xb[3], vb.y + dt * xb[4], vb.z + dt * xb[5]};
+  T us1 = qd1 + dt * (-y1 - kx1), us2 = qd2 + dt * (-y2 - kx2);
+
+  // ---- constraint rows: one per lane --------------------------------------------------------
+  const RowConst<T>& rc = P->row[lane];
+  const int type = rc.type;
+  const bool is_motor = type == ROW_MOTOR, is_contact = type >= ROW_NORMAL;
+  V3<T> cb = {rc.center[0], rc.center[1], rc.center[2]};
+  if (rc.body == BODY_UPPER) cb = o1 + roty(c1, s1, cb);
+  else if (rc.body == BODY_LOWER) cb = o2 + roty(c12, s12, cb);
+  const T dist = s_state[SOLO_S_POS + 2] + dot(nb, cb) - rc.radius;
+  const bool live = is_motor || (is_contact && dist < P->margin);
+  const V3<T> x = cb - rc.radius * nb;  // contact point in base coordinates
+  V3<T> d = nb;
+  if (type == ROW_TAN1) d = V3<T>{r00, r01, r02};
+  if (type == ROW_TAN2) d = V3<T>{r10, r11, r12};
+  T jb[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  T jl1 = T(0), jl2 = T(0), bias = T(0);
+  if (is_contact) {
+    const V3<T> xd = cross(x, d);
+    jb[0] = xd.x; jb[1] = xd.y; jb[2] = xd.z; jb[3] = d.x; jb[4] = d.y; jb[5] = d.z;
+    if (rc.body != BODY_BASE) jl1 = dot(d, ycross(x - o1));
+    if (rc.body == BODY_LOWER) jl2 = dot(d, ycross(x - o2));
+    if (type == ROW_NORMAL) bias = (dist > T(0)) ? -dist * P->inv_dt : -P->erp_over_dt * dist;
+  } else if (is_motor) {
+    // POSITION_CONTROL motor row ([recalled] btMultiBodyJointMotor): target velocity
+    // kp (q* - q)/dt + (1 - kd) qd, impulse clamp +-maxForce*dt
+    const int jt = 3 * leg + k;  // pybullet joint index of this dof
+    jl1 = (k == 0) ? T(1) : T(0);
+    jl2 = (k == 1) ? T(1) : T(0);
+    const T qj = (k == 0) ? q1 : q2, uj = (k == 0) ? us1 : us2;
+    bias = P->kp_over_dt * (s_tgt[jt] - qj) + P->one_minus_kd * uj;
+  }
+  T gh[6], hh[2];
+  {
+    T g[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = jb[i] - K1[i] * jl1 - K2[i] * jl2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      T s = g[i];
+#pragma unroll
+      for (int m = 0; m < i; ++m) s -= S[i][m] * gh[m];
+      gh[i] = s * iC[i];
+    }
+    hh[0] = jl1 * iL11;
+    hh[1] = (jl2 - L21 * hh[0]) * iL22;
+  }
+  T w = jl1 * us1 + jl2 * us2 - bias;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) w += jb[i] * ub[i];
+  T diag = hh[0] * hh[0] + hh[1] * hh[1];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) diag += gh[i] * gh[i];
+  T inv_d = T(1) / diag;
+  if (!live) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gh[i] = T(0);
+    hh[0] = hh[1] = T(0);
+    inv_d = T(0);
+    w = T(0);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s_rowvec[lane][i] = gh[i];
+  s_rowvec[lane][6] = hh[0];
+  s_rowvec[lane][7] = hh[1];
+  const unsigned long long touching = wave_ballot(live && type == ROW_NORMAL);
+  wave_sync();
+
+  // ---- Delassus row of this lane, then projected Gauss-Seidel -------------------------------
+  T A[kNumRowSlots];
+#pragma unroll
+  for (int i = 0; i < kNumRowSlots; ++i) A[i] = T(0);
+  ForMotors<T, 0>::build(A, s_rowvec, gh, hh, lane);
+  ForSpheres<T, 0>::build(touching, A, s_rowvec, gh, hh, lane);
+  T lam = T(0);
+  const T imp = P->motor_impulse;
+#pragma unroll 1
+  for (int it = 0; it < P->iterations; ++it) {
+    ForMotors<T, 0>::solve(lam, w, inv_d, imp, A, lane);
+    ForSpheres<T, 0>::solve(touching, lam, w, inv_d, mu, A, lane);
+  }
+
+  // ---- apply the impulses: du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam - K du_b ---
+  T z[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) z[i] = sum_over_legs(sum_over_group16(gh[i] * lam));
+  const T yl1 = sum_over_group16(hh[0] * lam), yl2 = sum_over_group16(hh[1] * lam);
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    T s = z[i];
+#pragma unroll
+    for (int m = i + 1; m < 6; ++m) s -= S[m][i] * z[m];
+    z[i] = s * iC[i];
+  }
+  const T t2 = yl2 * iL22, t1 = (yl1 - L21 * t2) * iL11;
+  T kz1 = T(0), kz2 = T(0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { kz1 += K1[i] * z[i]; kz2 += K2[i] * z[i]; ub[i] += z[i]; }
+  us1 += t1 - kz1;
+  us2 += t2 - kz2;
+
+  // ---- back to world-frame velocities, integrate positions ----------------------------------
+  const V3<T> wn = {r00 * ub[0] + r01 * ub[1] + r02 * ub[2], r10 * ub[0] + r11 * ub[1] + r12 * ub[2], r20 * ub[0] + r21 * ub[1] + r22 * ub[2]};
+  const V3<T> vn = {r00 * ub[3] + r01 * ub[4] + r02 * ub[5], r10 * ub[3] + r11 * ub[4] + r12 * ub[5], r20 * ub[3] + r21 * ub[4] + r22 * ub[5]};
+  // q+ = exp(dt w / 2) (x) q, renormalised
+  const T th = R::sqrt(dot(wn, wn)) * dt;
+  T sh, ch;
+  R::sincos(T(0.5) * th, &sh, &ch);
+  const T sc = (th > T(1e-12)) ? sh / th * dt : T(0.5) * dt;
+  const T dx = wn.x * sc, dy = wn.y * sc, dz = wn.z * sc, dw = ch;
+  T nx = dw * qx + dx * qw + dy * qz - dz * qy;
+  T ny = dw * qy - dx * qz + dy * qw + dz * qx;
+  T nz = dw * qz + dx * qy - dy * qx + dz * qw;
+  T nw = dw * qw - dx * qx - dy * qy - dz * qz;
+  const T nn = R::rsqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+  wave_sync();  // every lane has finished reading the old state
+  if (lane == 0) {
+    s_state[SOLO_S_POS] += dt * vn.x; s_state[SOLO_S_POS + 1] += dt * vn.y; s_state[SOLO_S_POS + 2] += dt * vn.z;
+    s_state[SOLO_S_QUAT] = nx * nn; s_state[SOLO_S_QUAT + 1] = ny * nn; s_state[SOLO_S_QUAT + 2] = nz * nn; s_state[SOLO_S_QUAT + 3] = nw * nn;
+    s_state[SOLO_S_ANGVEL] = wn.x; s_state[SOLO_S_ANGVEL + 1] = wn.y; s_state[SOLO_S_ANGVEL + 2] = wn.z;
+    s_state[SOLO_S_LINVEL] = vn.x; s_state[SOLO_S_LINVEL + 1] = vn.y; s_state[SOLO_S_LINVEL + 2] = vn.z;
+  }
+  if (k == 0) {
+    s_state[SOLO_S_Q + 2 * leg] = q1 + dt * us1;
+    s_state[SOLO_S_Q + 2 * leg + 1] = q2 + dt * us2;
+    s_state[SOLO_S_QD + 2 * leg] = us1;
+    s_state[SOLO_S_QD + 2 * leg + 1] = us2;
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------
+// the fused kernel
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void solo_step_kernel(const KParams<T>* __restrict__ P, KBuffers<T> B) {
+  using R = Real<T>;
+  __shared__ T s_state[SOLO_STATE_STRIDE];
+  __shared__ T s_tgt[16];
+  __shared__ T s_rowvec[64][8];
+  __shared__ T s_src[48];
+  __shared__ T s_stack[8];
+
+  const int lane = lane_id();
+  const int env = block_id();
+  if (env >= B.num_envs) return;
+  const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
+
+  if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.state[rec + lane];
+  if (lane < SOLO_NUM_JOINTS) {
+    T t;
+    if (B.actions != nullptr) {
+      // action de-normalisation (solo8v2vanilla.py:84-85) + setJointMotorControlArray (:87-90)
+      t = B.actions[(size_t)env * SOLO_NUM_JOINTS + lane] * P->action_scale;
+      B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = t;
+    } else {
+      t = B.targets[(size_t)env * SOLO_NUM_JOINTS + lane];
+    }
+    s_tgt[lane] = t;
+  }
+  const T mu = B.params[(size_t)env * 4 + 0];
+  const T mass_scale = B.params[(size_t)env * 4 + 1];
+  wave_sync();
+
+  bool diverged = false;
+  if (B.flags & SOLO_STEP_PHYSICS) {
+    physics_step<T>(P, s_state, s_tgt, s_rowvec, mu, mass_scale, lane);
+    // a robot whose state went non-finite is restored from its snapshot and counted
+    const bool bad = lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31]);
+    diverged = wave_ballot(bad) != 0ull;
+    if (diverged) {
+      if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
+      if (lane == 0) stats_add(&B.stats[5], 1.0);
+      wave_sync();
+    }
+  }
+
+  // ---- source vector for the observation program (see include/solo_engine.h) ---------------
+  const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
+  T roll, pitch, yaw;
+  euler_from_quat<T>(qx, qy, qz, qw, &roll, &pitch, &yaw);
+  if (B.flags & SOLO_STEP_OBS) {
+    if (lane < SOLO_SRC_COUNT) {
+      T v;
+      if (lane < 3) v = lane == 0 ? roll : (lane == 1 ? pitch : yaw);
+      else if (lane < 6) v = s_state[SOLO_S_LINVEL + lane - 3];
+      else if (lane < 9) v = s_state[SOLO_S_ANGVEL + lane - 6];
+      else if (lane < 33) {
+        const int j = (lane - 9) % 12, off = lane < 21 ? SOLO_S_Q : SOLO_S_QD;
+        v = (j % 3 == 2) ? T(0) : s_state[off + 2 * (j / 3) + (j % 3)];
+      } else if (lane < 36) v = s_state[SOLO_S_POS + lane - 33];
+      else if (lane < 40) v = s_state[SOLO_S_QUAT + lane - 36];
+      else v = T(1);
+      s_src[lane] = v;
+    }
+    wave_sync();
+    if (lane < P->num_obs) {
+      const ObsElemK<T>& e = P->obs[lane];
+      T v = s_src[e.src] * e.scale;
+      if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
+      if (e.flags & 2) v = (T(2) * (v - e.nlo)) / e.range - T(1);
+      B.obs[(size_t)env * P->num_obs + lane] = v;
+    }
+  }
+
+  // ---- reward: postfix program, evaluated redundantly by every lane (wave-uniform) -----------
+  T reward = T(0);
+  if (B.flags & SOLO_STEP_REWARD) {
+    int sp = 0;
+    for (int i = 0; i < P->num_reward_ops; ++i) {
+      const RewardInstrK<T>& in = P->reward[i];
+      const T gs = P->gauss_scale;
+      switch (in.op) {
+        case SOLO_R_CONST: s_stack[sp++] = in.a; break;
+        case SOLO_R_UPRIGHT: {
+          const T fu = T(-1.5707963267948966);
+          s_stack[sp++] = fu * pitch / (fu * fu);
+        } break;
+        case SOLO_R_FLAT_TORSO:
+          s_stack[sp++] = tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -in.a, in.a, in.b, gs);
+          break;
+        case SOLO_R_TORSO_HEIGHT:
+          s_stack[sp++] = tolerance<T>(s_state[SOLO_S_POS + 2], in.a - in.b, in.a + in.b, in.c, gs);
+          break;
+        case SOLO_R_HORIZ_SPEED: {
+          const T vx = s_state[SOLO_S_LINVEL], vy = s_state[SOLO_S_LINVEL + 1];
+          s_stack[sp++] = tolerance<T>(R::sqrt(vx * vx + vy * vy), in.a - in.b, in.a + in.b, in.c, gs);
+        } break;
+        case SOLO_R_SMALL_CONTROL: {
+          T s = T(0);
+#pragma unroll
+          for (int j = 0; j < SOLO_NUM_DOF; ++j) s += R::abs(s_state[SOLO_S_QD + j]);
+          // mean over all 12 pybullet joints incl. the 4 fixed ones (rewards.py:297-300)
+          s_stack[sp++] = tolerance<T>(s / T(SOLO_NUM_JOINTS), T(0), T(0), in.a, gs);
+        } break;
+        case SOLO_R_SCALE: s_stack[sp - 1] = in.a * s_stack[sp - 1]; break;
+        case SOLO_R_ADD: s_stack[sp - 2] = s_stack[sp - 2] + s_stack[sp - 1]; --sp; break;
+        case SOLO_R_MUL: s_stack[sp - 2] = s_stack[sp - 2] * s_stack[sp - 1]; --sp; break;
+        default: break;
+      }
+    }
+    reward = s_stack[0];
+    if (lane == 0) B.reward[env] = reward;
+  }
+
+  // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83)
+  bool done = false;
+  if (B.flags & SOLO_STEP_DONE) {
+    int cnt[SOLO_MAX_TERMS];
+#pragma unroll
+    for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = B.term_count[(size_t)env * SOLO_MAX_TERMS + t];
+#pragma unroll
+    for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
+      if (t < P->num_terms && !done) {
+        if (P->term_kind[t] == SOLO_T_TIME) {
+          cnt[t] += 1;
+          done = cnt[t] > P->term_param[t];
+        } else if (P->term_kind[t] == SOLO_T_CONST) {
+          done = P->term_param[t] != 0;
+        }
+      }
+    }
+    if (B.flags & SOLO_STEP_REWARD) {
+      // episodic-return bookkeeping kept in the env record (same 128-B line as the state)
+      if (lane == 0) { s_state[SOLO_S_RETURN] += reward; s_state[SOLO_S_EPLEN] += T(1); }
+      wave_sync();
+    }
+    const bool restart = (done || diverged) && P->auto_reset != 0;
+    if (restart) {
+      if (lane == 0 && done) {
+        const double ret = (double)s_state[SOLO_S_RETURN];
+        stats_add(&B.stats[0], ret);
+        stats_add(&B.stats[1], ret * ret);
+        stats_add(&B.stats[2], 1.0);
+        stats_add(&B.stats[3], (double)s_state[SOLO_S_EPLEN]);
+      }
+      wave_sync();
+      if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.snapshot[rec + lane];
+#pragma unroll
+      for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = 0;
+      wave_sync();
+    }
+    if (lane == 0) {
+      B.done[env] = done ? 1 : 0;
+#pragma unroll
+      for (int t = 0; t < SOLO_MAX_TERMS; ++t) B.term_count[(size_t)env * SOLO_MAX_TERMS + t] = cnt[t];
+    }
+  }
+  if (lane == 0 && (B.flags & SOLO_STEP_PHYSICS)) stats_add(&B.stats[4], 1.0);
+  if (lane < SOLO_STATE_STRIDE) B.state[rec + lane] = s_state[lane];
+}
+
+// setJointMotorControlArray without a step (solo8v2vanilla.py:87-90)
+template <typename T>
+__global__ void solo_set_targets_kernel(const T* __restrict__ actions, T* __restrict__ targets, T scale, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) targets[i] = actions[i] * scale;
+}
+
+// resetSimulation + settle, as a masked snapshot restore (solo8v2vanilla.py:104-143)
+template <typename T>
+__global__ void solo_reset_kernel(T* __restrict__ state, const T* __restrict__ snapshot,
+                                  int32_t* __restrict__ term_count, const uint8_t* __restrict__ mask, int num_envs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int env = i / SOLO_STATE_STRIDE, e = i % SOLO_STATE_STRIDE;
+  if (env >= num_envs) return;
+  if (mask != nullptr && mask[env] == 0) return;
+  state[i] = snapshot[i];
+  if (e < SOLO_MAX_TERMS) term_count[env * SOLO_MAX_TERMS + e] = 0;
+}
+
+// loadURDF at robot_start_pos / orientation (solo8v2vanilla.py:151-155), zero velocities
+template <typename T>
+__global__ void solo_init_kernel(T* __restrict__ state, T* __restrict__ targets, T px, T py, T pz, T qx, T qy, T qz, T qw, int num_envs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int env = i / SOLO_STATE_STRIDE, e = i % SOLO_STATE_STRIDE;
+  if (env >= num_envs) return;
+  T v = T(0);
+  if (e == SOLO_S_POS) v = px; else if (e == SOLO_S_POS + 1) v = py; else if (e == SOLO_S_POS + 2) v = pz;
+  else if (e == SOLO_S_QUAT) v = qx; else if (e == SOLO_S_QUAT + 1) v = qy; else if (e == SOLO_S_QUAT + 2) v = qz;
+  else if (e == SOLO_S_QUAT + 3) v = qw;
+  state[i] = v;
+  if (e < SOLO_NUM_JOINTS) targets[env * SOLO_NUM_JOINTS + e] = T(0);
+}
+
+}  // namespace solo

@@ -1,0 +1,180 @@
+"""ctypes binding of the HIP engine (``gym_solo_amd/csrc/libsolo_hip.so``, C-ABI in
+``include/solo_engine.h``).
+
+PyTorch is plumbing here: it provides the device tensors handed IN (actions, masks, per-env
+parameters) and zero-copy views of the engine-OWNED buffers (``__cuda_array_interface__``).
+There is NO CPU fallback: if the library is missing or no MI355X is visible, this raises.
+"""
+import ctypes as C
+import functools
+import os
+
+import numpy as np
+
+from gym_solo_amd import abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libsolo_hip.so')
+
+
+class EngineError(RuntimeError):
+  pass
+
+
+@functools.lru_cache(maxsize=None)
+def load_library(path=_LIB_PATH):
+  if not os.path.exists(path):
+    raise EngineError(
+      'HIP engine library not found at {} — build it with `make -C gym_solo_amd/csrc` or '
+      '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback.'.format(path))
+  lib = C.CDLL(path)
+  abi.bind(lib)
+  if lib.solo_abi_version() != abi.ABI_VERSION:
+    raise EngineError('ABI version mismatch between libsolo_hip.so and gym_solo_amd.abi')
+  return lib
+
+
+class _DeviceArray:
+  """Borrowed view of engine-owned device memory for ``torch.as_tensor`` (zero copy)."""
+
+  def __init__(self, ptr, shape, typestr, owner):
+    self._owner = owner  # keeps the engine alive while views exist
+    self.__cuda_array_interface__ = {
+      'shape': tuple(int(s) for s in shape), 'typestr': typestr, 'data': (int(ptr), False),
+      'version': 2, 'strides': None}
+
+
+def _raise(rc, msg):
+  if rc in (abi.ERR_INVALID_ARG, abi.ERR_NO_PROGRAM, abi.ERR_UNSUPPORTED_MODEL):
+    # misuse maps to ValueError exactly where the reference raises it
+    raise ValueError(msg)
+  raise EngineError('{} (status {})'.format(msg, rc))
+
+
+class Engine:
+  """One handle per GPU/process; not thread-safe; stream-ordered on torch's current stream."""
+
+  def __init__(self, cfg: abi.SoloConfig, model: abi.SoloModel, num_envs: int, device: int = 0):
+    import torch  # plumbing only
+    self._torch = torch
+    self.lib = load_library()
+    self.cfg, self.model = cfg, model
+    self.num_envs, self.device = int(num_envs), int(device)
+    self.tdtype = torch.float32 if cfg.dtype == abi.F32 else torch.float64
+    self._h = C.c_void_p()
+    rc = self.lib.solo_engine_create(C.byref(cfg), C.byref(model), self.num_envs, self.device,
+                                     C.byref(self._h))
+    if rc != abi.OK:
+      self._h = None
+      _raise(rc, 'solo_engine_create: ' + self.lib.solo_last_create_error().decode())
+    self.program = None
+    self._views = {}
+    self._make_views()
+
+  # ---- plumbing --------------------------------------------------------------------------
+  def _check(self, rc, what):
+    if rc != abi.OK:
+      _raise(rc, '{}: {}'.format(what, self.lib.solo_engine_last_error(self._h).decode()))
+
+  def _stream(self):
+    return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+  def _make_views(self):
+    torch = self._torch
+    v = abi.SoloStateView()
+    self._check(self.lib.solo_engine_get_view(self._h, C.byref(v)), 'get_view')
+    real = '<f4' if v.dtype == abi.F32 else '<f8'
+    n = v.num_envs
+    dev = 'cuda:%d' % self.device
+    def view(ptr, shape, typestr):
+      return torch.as_tensor(_DeviceArray(ptr, shape, typestr, self), device=dev)
+    self.state = view(v.state, (n, abi.STATE_STRIDE), real)
+    self.snapshot = view(v.snapshot, (n, abi.STATE_STRIDE), real)
+    self.targets = view(v.targets, (n, abi.NUM_JOINTS), real)
+    self.reward = view(v.reward, (n,), real)
+    self.done = view(v.done, (n,), '|u1')
+    self.term_count = view(v.term_count, (n, abi.MAX_TERMS), '<i4')
+    self.params = view(v.params, (n, 4), real)
+    self.stats = view(v.stats, (8,), '<f8')
+    self.obs_dim = v.obs_dim
+    self._obs_ptr, self._real = v.obs, real
+    self.obs = view(v.obs, (n, max(v.obs_dim, 1)), real) if v.obs_dim else None
+
+  def _dev_ptr(self, t, shape, dtype, name):
+    torch = self._torch
+    if not isinstance(t, torch.Tensor):
+      raise ValueError('{} must be a torch tensor on cuda:{}'.format(name, self.device))
+    if not t.is_cuda or t.device.index != self.device:
+      raise ValueError('{} must live on cuda:{}'.format(name, self.device))
+    if t.dtype != dtype:
+      raise ValueError('{} must have dtype {}'.format(name, dtype))
+    if tuple(t.shape) != tuple(shape):
+      raise ValueError('{} must have shape {}, got {}'.format(name, tuple(shape), tuple(t.shape)))
+    if not t.is_contiguous():
+      raise ValueError('{} must be contiguous'.format(name))
+    return C.c_void_p(t.data_ptr())
+
+  # ---- C-ABI calls -----------------------------------------------------------------------
+  def set_program(self, program: abi.SoloProgram):
+    self._check(self.lib.solo_engine_set_program(self._h, C.byref(program)), 'set_program')
+    self.program = program
+    self._make_views()
+
+  def reset(self, mask=None):
+    p = None
+    if mask is not None:
+      p = self._dev_ptr(mask, (self.num_envs,), self._torch.uint8, 'mask')
+    self._check(self.lib.solo_engine_reset(self._h, p, self._stream()), 'reset')
+
+  def settle(self):
+    self._check(self.lib.solo_engine_settle(self._h, self._stream()), 'settle')
+
+  def set_targets(self, actions):
+    p = self._dev_ptr(actions, (self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
+    self._check(self.lib.solo_engine_set_targets(self._h, p, self._stream()), 'set_targets')
+
+  def step(self, actions=None, flags=abi.STEP_ALL):
+    p = None
+    if actions is not None:
+      p = self._dev_ptr(actions, (self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
+    self._check(self.lib.solo_engine_step(self._h, p, flags, self._stream()), 'step')
+
+  def rollout(self, actions, flags=abi.STEP_ALL):
+    k = int(actions.shape[0])
+    p = self._dev_ptr(actions, (k, self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
+    self._check(self.lib.solo_engine_rollout(self._h, p, k, flags, self._stream()), 'rollout')
+
+  def time_step(self, actions=None, flags=abi.STEP_ALL, reps=100):
+    """Mean ms per launch of the step kernel, measured with HIP events on the launch stream."""
+    p = None
+    if actions is not None:
+      p = self._dev_ptr(actions, (self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
+    ms = C.c_double()
+    self._check(self.lib.solo_engine_time_step(self._h, p, flags, reps, self._stream(),
+                                               C.byref(ms)), 'time_step')
+    return ms.value
+
+  def set_params(self, which, per_env):
+    p = self._dev_ptr(per_env, (self.num_envs,), self.tdtype, 'per_env')
+    self._check(self.lib.solo_engine_set_params(self._h, which, p, self._stream()), 'set_params')
+
+  @property
+  def kernel_name(self):
+    return self.lib.solo_engine_kernel_name(self._h).decode()
+
+  def synchronize(self):
+    self._torch.cuda.synchronize(self.device)
+
+  def close(self):
+    if getattr(self, '_h', None):
+      self._torch.cuda.synchronize(self.device)
+      for name in ('state', 'snapshot', 'targets', 'reward', 'done', 'term_count', 'params',
+                   'stats', 'obs'):
+        setattr(self, name, None)
+      self.lib.solo_engine_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

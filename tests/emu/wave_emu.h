@@ -1,0 +1,176 @@
+// wave_emu.h — TEST-ONLY single-wavefront SIMT emulator for the CPU.
+//
+// Lets tests/ compile gym_solo_amd/csrc/solo_step_kernel.h UNCHANGED with g++ (optionally with
+// -fsanitize=address,undefined, which the GPU pool cannot run) and execute it lane by lane:
+// the 64 lanes of a workgroup are ucontext fibres that are switched at every cross-lane
+// operation (wave_sync / wave_readlane / wave_shfl_xor / wave_ballot).  The kernel keeps all
+// cross-lane operations in wave-uniform control flow, which is also what the hardware needs.
+// Nothing in the product path includes this file.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+// Minimal x86-64 fibre switch (callee-saved registers + stack pointer).  glibc's swapcontext
+// makes a sigprocmask syscall per switch, ~50x slower for the ~10^5 switches of one env step.
+extern "C" void solo_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl solo_emu_switch
+.type solo_emu_switch,@function
+solo_emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size solo_emu_switch, .-solo_emu_switch
+)");
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(x)
+
+struct EmuDim3 { int x = 0, y = 0, z = 0; };
+static EmuDim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace solo {
+
+class WaveEmu {
+ public:
+  static constexpr int W = 64;
+  static WaveEmu& get() { static WaveEmu e; return e; }
+
+  // runs `body` once per lane of workgroup `block`
+  void run_block(int block, int grid, const std::function<void()>& body) {
+    body_ = &body;
+    blockIdx.x = block; gridDim.x = grid; blockDim.x = W;
+    if (stacks_.empty()) stacks_.resize((size_t)W * kStack + 64);
+    int remaining = W;
+    for (int l = 0; l < W; ++l) {
+      uintptr_t top = (uintptr_t)(stacks_.data() + (size_t)(l + 1) * kStack);
+      top &= ~(uintptr_t)15;
+      void** sp = (void**)top;
+      *--sp = nullptr;                       // fake return address of the trampoline
+      *--sp = (void*)&WaveEmu::trampoline;   // popped by `ret` in solo_emu_switch
+      for (int r = 0; r < 6; ++r) *--sp = nullptr;
+      sp_[l] = (void*)sp;
+      finished_[l] = false;
+    }
+    while (remaining > 0) {
+      for (int l = 0; l < W; ++l) {
+        if (finished_[l]) continue;
+        cur_ = l;
+        threadIdx.x = l;
+        solo_emu_switch(&sched_sp_, sp_[l]);
+        if (finished_[l]) --remaining;
+      }
+    }
+  }
+  void yield() {
+    const int me = cur_;
+    solo_emu_switch(&sp_[me], sched_sp_);
+  }
+  uint64_t exchange(uint64_t mine, int src) {
+    xchg_[cur_] = mine;
+    yield();
+    const uint64_t v = xchg_[src & (W - 1)];
+    yield();
+    return v;
+  }
+  int lane() const { return cur_; }
+  uint64_t peek(int l) const { return xchg_[l]; }
+  void post(uint64_t v) { xchg_[cur_] = v; }
+
+ private:
+  static constexpr size_t kStack = 512 * 1024;
+  static void trampoline() {
+    WaveEmu& e = get();
+    (*e.body_)();
+    e.finished_[e.cur_] = true;
+    for (;;) e.yield();  // never returns: the scheduler does not resume finished lanes
+  }
+  void* sched_sp_ = nullptr;
+  void* sp_[W];
+  std::vector<char> stacks_;
+  bool finished_[W];
+  int cur_ = 0;
+  uint64_t xchg_[W];
+  const std::function<void()>* body_ = nullptr;
+};
+
+inline int lane_id() { return WaveEmu::get().lane(); }
+inline int block_id() { return blockIdx.x; }
+inline void wave_sync() { WaveEmu::get().yield(); }
+
+inline float wave_readlane(float x, int lane) {
+  uint32_t b; std::memcpy(&b, &x, 4);
+  b = (uint32_t)WaveEmu::get().exchange(b, lane);
+  std::memcpy(&x, &b, 4); return x;
+}
+inline double wave_readlane(double x, int lane) {
+  uint64_t b; std::memcpy(&b, &x, 8);
+  b = WaveEmu::get().exchange(b, lane);
+  std::memcpy(&x, &b, 8); return x;
+}
+inline float wave_shfl_xor(float x, int mask) { return wave_readlane(x, lane_id() ^ mask); }
+inline double wave_shfl_xor(double x, int mask) { return wave_readlane(x, lane_id() ^ mask); }
+inline unsigned long long wave_ballot(bool p) {
+  WaveEmu& e = WaveEmu::get();
+  e.post(p ? 1 : 0);
+  e.yield();
+  unsigned long long m = 0;
+  for (int l = 0; l < WaveEmu::W; ++l) m |= (unsigned long long)(e.peek(l) & 1) << l;
+  e.yield();
+  return m;
+}
+
+template <typename T> struct Real;
+template <> struct Real<float> {
+  static float sqrt(float x) { return std::sqrt(x); }
+  static float rsqrt(float x) { return 1.0f / std::sqrt(x); }
+  static void sincos(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
+  static float atan2(float y, float x) { return std::atan2(y, x); }
+  static float asin(float x) { return std::asin(x); }
+  static float exp(float x) { return std::exp(x); }
+  static float abs(float x) { return std::fabs(x); }
+  static float min(float a, float b) { return std::fmin(a, b); }
+  static float max(float a, float b) { return std::fmax(a, b); }
+  static bool finite(float x) { return std::isfinite(x); }
+  static float big() { return 3.0e38f; }
+};
+template <> struct Real<double> {
+  static double sqrt(double x) { return std::sqrt(x); }
+  static double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+  static void sincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
+  static double atan2(double y, double x) { return std::atan2(y, x); }
+  static double asin(double x) { return std::asin(x); }
+  static double exp(double x) { return std::exp(x); }
+  static double abs(double x) { return std::fabs(x); }
+  static double min(double a, double b) { return std::fmin(a, b); }
+  static double max(double a, double b) { return std::fmax(a, b); }
+  static bool finite(double x) { return std::isfinite(x); }
+  static double big() { return 1.0e300; }
+};
+
+inline void stats_add(double* p, double v) { *p += v; }
+
+}  // namespace solo
