@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched Solo8 hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is one pass of the whole hot path over one batch of 4096 robots
+per GPU (BASELINE.json configs[1]): fresh random actions -> action
+de-normalisation -> POSITION_CONTROL motors -> articulated forward dynamics -> ground contact PGS
+-> integration -> TorsoIMU+MotorEncoder observations (21 floats) -> the examples' stand reward
+-> TimeBasedTermination(1000) with auto-reset; ONE fused kernel launch per step through the
+C-ABI (solo_engine_rollout).  The action pool is generated on the device before the timed
+region.  The env batch is sharded over ranks with no data-path collective; the only
+communication is one RCCL all-reduce of the 8-double episodic-return statistics vector at the
+end of the interval (inside the timed region).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+BYTES_PER_ENV_STEP = {'float32': 385, 'float64': 765}  # SURVEY.md §8d algorithmic bytes
+HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md chip table
+FLOP_PER_ENV_STEP_EST = 3.0e5                           # SURVEY.md §8d estimate (secondary bound)
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+
+
+def build_env(num_envs, device, dtype, max_steps=1000):
+  import numpy as np
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
+  from gym_solo_amd.workloads import register_benchmark_workload
+  cfg = Solo8VanillaConfig()
+  cfg.num_envs, cfg.device, cfg.dtype, cfg.auto_reset = num_envs, device, dtype, True
+  env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
+  register_benchmark_workload(env, max_steps=max_steps)
+  env._ensure_program()
+  return env
+
+
+def cpu_baseline(num_envs, seconds_target=12.0):
+  """The CPU oracle (double-precision scalar C restatement + numpy reductions) on the host
+  cores, bounded sample of the same workload.  kind = "port": PyBullet itself is not
+  installable in this pipeline."""
+  import subprocess
+  import tempfile
+  import numpy as np
+  from helpers import make_abi
+  from oracle import solo_oracle as so
+  import env_cases
+  cores = os.cpu_count() or 1
+  tmp = tempfile.mkdtemp(prefix='solo_oracle_native_')
+  lib_path = os.path.join(tmp, 'libsolo_oracle_native.so')
+  try:
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle'), 'native', 'OUT=' + lib_path])
+  except Exception:  # noqa: BLE001 — fall back to the portable build
+    lib_path = None
+  ca, ma = make_abi('float64', auto_reset=True)
+  env = so.OracleEnv(ca, ma, num_envs, [('torso_imu', {}), ('motor_encoder', {})],
+                     [(1, env_cases.BENCH_REWARD)], [('time', 1000)], threads=cores)
+  if lib_path:
+    env.phys = so.OraclePhysics(ca, ma, lib_path)
+  rng = np.random.default_rng(1234)
+  env.step(rng.uniform(-2 * np.pi, 2 * np.pi, (num_envs, 12)))  # warm-up (thread pool, TLS)
+  steps, t0 = 0, time.perf_counter()
+  while True:
+    env.step(rng.uniform(-2 * np.pi, 2 * np.pi, (num_envs, 12)))
+    steps += 1
+    el = time.perf_counter() - t0
+    if el > seconds_target or steps >= 2000:
+      break
+  return {'value': num_envs * steps / el, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+          'sample': '%d envs x %d steps of the same workload on the f64 C oracle (OpenMP over envs, '
+                    '%d threads) + numpy obs/reward, %.1f s' % (num_envs, steps, cores, el)}
+
+
+def pmc_traffic(dtype):
+  """HBM bytes per launch from a committed rocprofv3 --pmc run (profiles/), or None."""
+  path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+  try:
+    with open(path) as f:
+      return json.load(f).get(dtype, {}).get('hbm_bytes_per_launch')
+  except Exception:  # noqa: BLE001
+    return None
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=1000)
+  ap.add_argument('--warmup', type=int, default=100)
+  ap.add_argument('--envs-per-gpu', type=int, default=4096)
+  ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  from gym_solo_amd import abi
+
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if world != args.gpus:
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+  torch.cuda.set_device(local_rank)
+  distributed = world > 1
+  if distributed:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local_rank))
+
+  n, k, w = args.envs_per_gpu, args.steps, args.warmup
+  tdtype = torch.float32 if args.dtype == 'float32' else torch.float64
+  env = build_env(n, local_rank, args.dtype)
+  eng = env.engine
+  gen = torch.Generator(device='cuda:%d' % local_rank).manual_seed(1234 + rank)
+  two_pi = 2 * 3.141592653589793
+
+  def action_pool(steps):
+    a = torch.rand(steps, n, abi.NUM_JOINTS, device='cuda:%d' % local_rank, dtype=tdtype, generator=gen)
+    return (a * 2 - 1) * two_pi
+
+  def barrier():
+    if distributed:
+      dist.barrier()
+    torch.cuda.synchronize(local_rank)
+
+  if w > 0:
+    eng.rollout(action_pool(w), abi.STEP_ALL)
+  acts = action_pool(k)
+  stats_before = eng.stats.clone()
+  barrier()
+  t0 = time.perf_counter()
+  eng.rollout(acts, abi.STEP_ALL)
+  stats = eng.stats - stats_before
+  if distributed:
+    dist.all_reduce(stats)  # episodic-return statistics over xGMI
+  barrier()
+  elapsed = time.perf_counter() - t0
+  t = torch.tensor([elapsed], dtype=torch.float64, device='cuda:%d' % local_rank)
+  if distributed:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  elapsed = float(t.item())
+
+  # dominant kernel: HIP-event timing on the launch stream, same workload
+  reps = min(k, 200)
+  kern_ms = eng.time_step(acts[0], abi.STEP_ALL, reps=reps)
+  # API-level rate through Solo8VanillaEnv.step (python loop, zero-copy outputs)
+  api_steps = min(k, 200)
+  torch.cuda.synchronize(local_rank)
+  ta = time.perf_counter()
+  for i in range(api_steps):
+    env.step(acts[i])
+  torch.cuda.synchronize(local_rank)
+  api_rate = n * api_steps / (time.perf_counter() - ta)
+
+  st = stats.cpu().numpy()
+  if rank == 0:
+    value = world * n * k / elapsed
+    bytes_per_launch = BYTES_PER_ENV_STEP[args.dtype] * n
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    line = {
+      'metric': 'env-steps/s (whole node), 4096 Solo8 envs/GPU', 'value': value, 'unit': 'env-steps/s',
+      'n_gpus': world, 'steps': k, 'warmup': w, 'ms_per_step': elapsed / k * 1e3,
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f32' if args.dtype == 'float32' else 'f64', 'data': 'synthetic',
+      'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
+                             'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
+                             'TimeBasedTermination(1000)+auto-reset, dt=1e-3, 50 PGS iterations' % n,
+                 'envs_per_gpu': n, 'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
+      'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                   'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_traffic(args.dtype),
+                   'kernel': eng.kernel_name, 'kernel_ms': kern_ms,
+                   'algorithmic_bytes_per_launch': bytes_per_launch,
+                   'note': 'latency/VALU-bound by construction (SURVEY.md §8d); secondary bound: est. '
+                           '%.0e flop/env-step -> %.3f of the %.1f TFLOP/s f32 vector peak'
+                           % (FLOP_PER_ENV_STEP_EST, FLOP_PER_ENV_STEP_EST * n / (kern_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                              FP32_VECTOR_PEAK_TFLOPS)},
+      'episodes': {'count': float(st[2]), 'mean_return': float(st[0] / st[2]) if st[2] else None,
+                   'mean_length': float(st[3] / st[2]) if st[2] else None, 'diverged': float(st[5])},
+      'env_api_env_steps_per_s_rank0': api_rate,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = cpu_baseline(n)
+    else:
+      line['cpu_baseline'] = None
+    print(json.dumps(line), flush=True)
+  if distributed:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

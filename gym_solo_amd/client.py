@@ -1,0 +1,169 @@
+"""``BatchedBulletClient`` — the batched stand-in for ``pybullet_utils.bullet_client.BulletClient``.
+
+The reference's env, observations and rewards talk to physics ONLY through this method surface
+(call sites solo8_base_env.py:34-48, solo8v2vanilla.py:87-91,110-163,
+obs.py:268-273,308-354, rewards.py:232-370).  Every getter returns torch tensors with a leading
+env axis ``[N, ...]`` that are zero-copy views of the engine's state record; every setter maps
+onto one C-ABI call of ``include/solo_engine.h``.  Rendering / GUI calls are out of scope.
+"""
+import numpy as np
+
+from gym_solo_amd import abi
+from gym_solo_amd.core.configs import euler_to_quat
+from gym_solo_amd.model import JOINT_TO_DOF, pybullet_joint_info
+
+# pybullet constants used by the reference
+DIRECT = 2
+GUI = 1
+POSITION_CONTROL = 2
+URDF_USE_INERTIA_FROM_FILE = 2
+
+PLANE_ID = 0
+ROBOT_ID = 1
+
+
+def _is_tensor(x):
+  return type(x).__module__.startswith('torch')
+
+
+def euler_from_quaternion_torch(quat):
+  """pybullet.getEulerFromQuaternion for a [..., 4] xyzw tensor ([recalled] pybullet.c; same
+  branches as the kernel's euler_from_quat and the oracle)."""
+  import torch
+  x, y, z, w = quat[..., 0], quat[..., 1], quat[..., 2], quat[..., 3]
+  sqx, sqy, sqz, squ = x * x, y * y, z * z, w * w
+  sarg = -2 * (x * z - w * y)
+  lo, hi = sarg <= -0.99999, sarg >= 0.99999
+  roll = torch.atan2(2 * (y * z + w * x), squ - sqx - sqy + sqz)
+  pitch = torch.asin(torch.clamp(sarg, -1, 1))
+  yaw = torch.atan2(2 * (x * y + w * z), squ + sqx - sqy - sqz)
+  zero = torch.zeros_like(roll)
+  half_pi = torch.full_like(roll, 0.5 * np.pi)
+  roll = torch.where(lo | hi, zero, roll)
+  pitch = torch.where(lo, -half_pi, torch.where(hi, half_pi, pitch))
+  yaw = torch.where(lo, 2 * torch.atan2(x, -y), torch.where(hi, 2 * torch.atan2(-x, y), yaw))
+  return torch.stack([roll, pitch, yaw], dim=-1)
+
+
+class BatchedBulletClient:
+  def __init__(self, engine, solo_model, connection_mode=DIRECT):
+    if connection_mode != DIRECT:
+      raise ValueError('the batched engine has no GUI (connection_mode must be DIRECT)')
+    self.engine = engine
+    self._model = solo_model
+    self._joint_info = pybullet_joint_info(solo_model)
+    self.state_version = 0
+    self._gravity = tuple(engine.cfg.gravity)
+
+  # ---- configuration setters: validated against the engine's compiled configuration --------
+  def setAdditionalSearchPath(self, path):
+    return None
+
+  def setGravity(self, gx, gy, gz):
+    if not np.allclose((gx, gy, gz), self._gravity):
+      raise ValueError('gravity is fixed at engine creation: {}'.format(self._gravity))
+
+  def setPhysicsEngineParameter(self, fixedTimeStep=None, numSubSteps=1, **kwargs):
+    if fixedTimeStep is not None and not np.isclose(fixedTimeStep, self.engine.cfg.dt):
+      raise ValueError('fixedTimeStep is fixed at engine creation: {}'.format(self.engine.cfg.dt))
+    if numSubSteps != 1:
+      raise ValueError('only numSubSteps=1 is supported (solo8_base_env.py:39-41)')
+
+  def setRealTimeSimulation(self, enable):
+    raise ValueError('real-time simulation is out of scope for the batched engine')
+
+  def loadURDF(self, path, *args, **kwargs):
+    return PLANE_ID if 'plane' in str(path) else ROBOT_ID
+
+  def changeDynamics(self, body, link, linearDamping=None, angularDamping=None,
+                     restitution=None, lateralFriction=None, **kwargs):
+    """solo8v2vanilla.py:158-163.  Damping / restitution are engine-wide constants; a lateral
+    friction that differs from the configured one is written to every env's parameter row."""
+    cfg = self.engine.cfg
+    for given, have, name in ((linearDamping, cfg.linear_damping, 'linearDamping'),
+                              (angularDamping, cfg.angular_damping, 'angularDamping'),
+                              (restitution, cfg.restitution, 'restitution')):
+      if given is not None and not np.isclose(given, have):
+        raise ValueError('{} is fixed at engine creation: {}'.format(name, have))
+    if lateralFriction is not None and not np.isclose(lateralFriction, cfg.lateral_friction):
+      import torch
+      self.engine.set_params(abi.PARAM_FRICTION, torch.full(
+        (self.engine.num_envs,), float(lateralFriction), device=self.engine.state.device,
+        dtype=self.engine.tdtype))
+
+  # ---- pure math ---------------------------------------------------------------------------
+  def getQuaternionFromEuler(self, euler):
+    return euler_to_quat(euler)
+
+  def getEulerFromQuaternion(self, quat):
+    if _is_tensor(quat):
+      return euler_from_quaternion_torch(quat)
+    import torch
+    e = euler_from_quaternion_torch(torch.as_tensor(np.asarray(quat, dtype=np.float64)))
+    return tuple(float(v) for v in e)
+
+  # ---- static model queries ------------------------------------------------------------------
+  def getNumJoints(self, body):
+    return abi.NUM_JOINTS
+
+  def getNumBodies(self):
+    return 2
+
+  def getJointInfo(self, body, joint):
+    return self._joint_info[joint]
+
+  # ---- the hot path ----------------------------------------------------------------------------
+  def resetSimulation(self):
+    self.engine.reset(None)
+    self.state_version += 1
+
+  def setJointMotorControlArray(self, body, jointIndices, controlMode, targetPositions=None,
+                                forces=None, **kwargs):
+    """solo8v2vanilla.py:87-90.  targetPositions: [N,12] tensor (or a 12-vector broadcast to
+    every env) in the units of the action space."""
+    if controlMode != POSITION_CONTROL:
+      raise ValueError('only POSITION_CONTROL is supported')
+    if forces is not None and not np.allclose(np.asarray(forces, dtype=np.float64),
+                                              self.engine.cfg.motor_torque_limit):
+      raise ValueError('forces are fixed at engine creation: {}'.format(
+        self.engine.cfg.motor_torque_limit))
+    self.engine.set_targets(self.as_actions(targetPositions))
+
+  def as_actions(self, a):
+    import torch
+    eng = self.engine
+    if not _is_tensor(a):
+      a = torch.as_tensor(np.asarray(a, dtype=np.float64))
+    a = a.to(device=eng.state.device, dtype=eng.tdtype)
+    if a.dim() == 1:
+      a = a.unsqueeze(0).expand(eng.num_envs, -1)
+    if tuple(a.shape) != (eng.num_envs, abi.NUM_JOINTS):
+      raise ValueError('actions must have shape ({}, {}) or ({},)'.format(
+        eng.num_envs, abi.NUM_JOINTS, abi.NUM_JOINTS))
+    return a.contiguous()
+
+  def stepSimulation(self):
+    self.engine.step(None, abi.STEP_PHYSICS)
+    self.state_version += 1
+
+  def getBasePositionAndOrientation(self, body):
+    s = self.engine.state
+    return s[:, abi.S_POS:abi.S_POS + 3], s[:, abi.S_QUAT:abi.S_QUAT + 4]
+
+  def getBaseVelocity(self, body):
+    s = self.engine.state
+    return s[:, abi.S_LINVEL:abi.S_LINVEL + 3], s[:, abi.S_ANGVEL:abi.S_ANGVEL + 3]
+
+  def getJointState(self, body, joint):
+    """(position [N], velocity [N], reaction forces, applied torque); fixed ANKLE joints read
+    0 (gym_solo/core/test_obs_observations.py:259)."""
+    import torch
+    s = self.engine.state
+    dof = JOINT_TO_DOF.get(int(joint))
+    if dof is None:
+      z = torch.zeros(self.engine.num_envs, device=s.device, dtype=s.dtype)
+      return z, z, (0.0,) * 6, 0.0
+    return s[:, abi.S_Q + dof], s[:, abi.S_QD + dof], (0.0,) * 6, 0.0
+
+  def disconnect(self):
+    self.engine.close()

@@ -1,0 +1,347 @@
+"""Batched rewards — counterpart of gym_solo/core/rewards.py.
+
+Same classes, constructor arguments, combinators and ``ValueError`` sites.  Each reward can
+describe itself as postfix instructions (``program()``) so that the whole ``RewardFactory``
+tree is evaluated inside the fused step kernel; ``compute()`` keeps the reference's pull-based
+semantics through the batched client (torch tensors ``[N]``) and doubles as an independent
+check of the fused path.
+"""
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import functools
+import math
+
+import numpy as np
+
+from gym_solo_amd import abi, solo_types
+
+
+def _is_tensor(x):
+  return type(x).__module__.startswith('torch')
+
+
+class Reward(ABC):
+  """A reward for a body in the simulation (rewards.py:15-55)."""
+  _client = None
+
+  @abstractmethod
+  def compute(self) -> solo_types.reward:
+    pass
+
+  @property
+  def client(self):
+    if self._client is None:
+      raise ValueError('PyBullet client needs to be set')
+    return self._client
+
+  @client.setter
+  def client(self, client):
+    self._client = client
+
+  def program(self):
+    """Postfix instruction list [(op, a, b, c), ...] leaving one value, or None when the
+    reward is Python-only."""
+    return None
+
+
+@dataclass
+class _WeightedReward:
+  reward: Reward
+  weight: float
+
+
+class RewardFactory:
+  """Linear combination of rewards (rewards.py:64-118).  ``register_reward`` is deprecated in
+  the reference in favour of ``AdditiveReward`` (rewards.py:86-89); it is kept, undecorated,
+  because the reference's envs and tests still use it."""
+
+  def __init__(self, client):
+    self._client = client
+    self._rewards: List[_WeightedReward] = []
+    self._engine_env = None
+
+  def register_reward(self, weight: float, reward: Reward):
+    reward.client = self._client
+    self._rewards.append(_WeightedReward(reward=reward, weight=weight))
+    if self._engine_env is not None:
+      self._engine_env._mark_dirty()
+
+  def fusable(self):
+    if not self._rewards:
+      return False
+    progs = [wr.reward.program() for wr in self._rewards]
+    if any(p is None for p in progs):
+      return False
+    return len(self.program()) <= abi.MAX_REWARD_OPS
+
+  def program(self):
+    """sum(w_i * r_i) left to right, like Python's sum() starting at 0 (rewards.py:118)."""
+    out = []
+    for i, wr in enumerate(self._rewards):
+      out.extend(wr.reward.program())
+      out.append((abi.R_SCALE, float(wr.weight), 0.0, 0.0))
+      if i > 0:
+        out.append((abi.R_ADD, 0.0, 0.0, 0.0))
+    return out
+
+  def get_reward_python(self):
+    return sum(wr.weight * wr.reward.compute() for wr in self._rewards)
+
+  def get_reward(self):
+    """rewards.py:104-118"""
+    if not self._rewards:
+      raise ValueError('Need to register at least one reward instance')
+    if self._engine_env is not None:
+      return self._engine_env._evaluate_reward()
+    return self.get_reward_python()
+
+
+class AdditiveReward(Reward):
+  """c1 r1 + c2 r2 + ... (rewards.py:121-160)."""
+
+  def __init__(self):
+    self._terms: List[_WeightedReward] = []
+
+  def add_term(self, coefficient: float, reward: Reward):
+    reward.client = self.client
+    self._terms.append(_WeightedReward(reward=reward, weight=coefficient))
+
+  def compute(self):
+    if not self._terms:
+      raise ValueError('Need to register at least one term')
+    return sum(wr.weight * wr.reward.compute() for wr in self._terms)
+
+  def program(self):
+    if not self._terms:
+      raise ValueError('Need to register at least one term')
+    out = []
+    for i, wr in enumerate(self._terms):
+      p = wr.reward.program()
+      if p is None:
+        return None
+      out.extend(p)
+      out.append((abi.R_SCALE, float(wr.weight), 0.0, 0.0))
+      if i > 0:
+        out.append((abi.R_ADD, 0.0, 0.0, 0.0))
+    return out
+
+
+class MultiplicitiveReward(Reward):
+  """c * r1 * r2 * ... (rewards.py:163-199)."""
+
+  def __init__(self, coefficient: float, *terms: Reward):
+    self._coeff = coefficient
+    self._terms = terms
+
+  def compute(self):
+    if not self._terms:
+      raise ValueError('Need to register at least one term')
+    return self._coeff * functools.reduce(lambda a, b: a * b, [t.compute() for t in self._terms])
+
+  def program(self):
+    if not self._terms:
+      raise ValueError('Need to register at least one term')
+    out = []
+    for i, t in enumerate(self._terms):
+      p = t.program()
+      if p is None:
+        return None
+      out.extend(p)
+      if i > 0:
+        out.append((abi.R_MUL, 0.0, 0.0, 0.0))
+    out.append((abi.R_SCALE, float(self._coeff), 0.0, 0.0))
+    return out
+
+  @property
+  def client(self):
+    return self._client
+
+  @client.setter
+  def client(self, client):
+    self._client = client
+    for t in self._terms:
+      t.client = self._client
+
+
+def _euler_xy(client, robot_id):
+  _, quat = client.getBasePositionAndOrientation(robot_id)
+  e = client.getEulerFromQuaternion(quat)
+  if _is_tensor(e):
+    return e[..., 0], e[..., 1]
+  return e[0], e[1]
+
+
+def _sqrt(x):
+  if _is_tensor(x):
+    import torch
+    return torch.sqrt(x)
+  return math.sqrt(x)
+
+
+class UprightReward(Reward):
+  """rewards.py:202-234: -2 pitch / pi (evaluated in the reference's operation order)."""
+  _fully_upright = -np.pi / 2
+
+  def __init__(self, robot_id: int):
+    self._robot_id = robot_id
+
+  def compute(self):
+    _, y = _euler_xy(self.client, self._robot_id)
+    return self._fully_upright * y / self._fully_upright ** 2
+
+  def program(self):
+    return [(abi.R_UPRIGHT, 0.0, 0.0, 0.0)]
+
+
+class FlatTorsoReward(Reward):
+  """rewards.py:237-269"""
+
+  def __init__(self, robot_id: int, hard_margin: float = .1, soft_margin: float = 0.1):
+    self._robot_id = robot_id
+    self._hard_margin = hard_margin
+    self._soft_margin = soft_margin
+
+  def compute(self):
+    theta_x, theta_y = _euler_xy(self.client, self._robot_id)
+    rmse = _sqrt(theta_x ** 2 + theta_y ** 2)
+    return tolerance(rmse, bounds=(-self._hard_margin, self._hard_margin),
+                     margin=self._soft_margin)
+
+  def program(self):
+    _validate(-self._hard_margin, self._hard_margin, self._soft_margin)
+    return [(abi.R_FLAT_TORSO, float(self._hard_margin), float(self._soft_margin), 0.0)]
+
+
+class SmallControlReward(Reward):
+  """rewards.py:272-301: tolerance of the mean |qd| over all 12 joints."""
+
+  def __init__(self, robot_id: int, margin: float = 1.):
+    self._robot_id = robot_id
+    self._margin = margin
+
+  def compute(self):
+    joint_cnt = self.client.getNumJoints(self._robot_id)
+    vels = [self.client.getJointState(self._robot_id, i)[1] for i in range(joint_cnt)]
+    if any(_is_tensor(v) for v in vels):
+      import torch
+      avg = torch.stack(vels, dim=-1).abs().mean(dim=-1)
+    else:
+      avg = np.average(np.abs(np.array(vels)))
+    return tolerance(avg, margin=self._margin)
+
+  def program(self):
+    _validate(0., 0., self._margin)
+    return [(abi.R_SMALL_CONTROL, float(self._margin), 0.0, 0.0)]
+
+
+class HorizontalMoveSpeedReward(Reward):
+  """rewards.py:304-338"""
+
+  def __init__(self, robot_id: int, target_speed: int, hard_margin: float = .1,
+               soft_margin: float = 0.1):
+    self._robot_id = robot_id
+    self._target_speed = target_speed
+    self._hard_margin = hard_margin
+    self._soft_margin = soft_margin
+
+  def compute(self):
+    v_lin, _ = self.client.getBaseVelocity(self._robot_id)
+    if _is_tensor(v_lin):
+      vx, vy = v_lin[..., 0], v_lin[..., 1]
+    else:
+      vx, vy = v_lin[0], v_lin[1]
+    speed = _sqrt(vx ** 2 + vy ** 2)
+    return tolerance(speed, bounds=(self._target_speed - self._hard_margin,
+                                    self._target_speed + self._hard_margin),
+                     margin=self._soft_margin)
+
+  def program(self):
+    _validate(self._target_speed - self._hard_margin, self._target_speed + self._hard_margin,
+              self._soft_margin)
+    return [(abi.R_HORIZ_SPEED, float(self._target_speed), float(self._hard_margin),
+             float(self._soft_margin))]
+
+
+class TorsoHeightReward(Reward):
+  """rewards.py:341-373"""
+
+  def __init__(self, robot_id: int, target_height: int, hard_margin: float = .1,
+               soft_margin: float = 0.1):
+    self._robot_id = robot_id
+    self._target_height = target_height
+    self._hard_margin = hard_margin
+    self._soft_margin = soft_margin
+
+  def compute(self):
+    pos, _ = self.client.getBasePositionAndOrientation(self._robot_id)
+    z = pos[..., 2] if _is_tensor(pos) else pos[2]
+    return tolerance(z, bounds=(self._target_height - self._hard_margin,
+                                self._target_height + self._hard_margin),
+                     margin=self._soft_margin)
+
+  def program(self):
+    _validate(self._target_height - self._hard_margin, self._target_height + self._hard_margin,
+              self._soft_margin)
+    return [(abi.R_TORSO_HEIGHT, float(self._target_height), float(self._hard_margin),
+             float(self._soft_margin))]
+
+
+def _validate(lower, upper, margin, margin_value=.1):
+  """The argument checks of gaussian() (rewards.py:405-417), also applied at compile time."""
+  if lower > upper:
+    raise ValueError('Lower bound ({}) is greater than upper bound ({})'.format(lower, upper))
+  if margin < 0:
+    raise ValueError('Margin must be non-negative: {}'.format(margin))
+  if not 0 < margin_value <= 1:
+    raise ValueError('Margin value must be valued in (0, 1]: {}'.format(margin_value))
+
+
+def tolerance(*args, **kwargs):
+  """rewards.py:376-381"""
+  return gaussian(*args, **kwargs)
+
+
+def gaussian(x, bounds: Tuple[float, float] = (0., 0.), margin: float = 0.,
+             margin_value: float = .1):
+  """rewards.py:384-431 — sloped reward about a bounds range; accepts scalars, numpy arrays
+  and torch tensors."""
+  lower, upper = bounds
+  _validate(lower, upper, margin, margin_value)
+  if _is_tensor(x):
+    import torch
+    within = (lower <= x) & (x <= upper)
+    one = torch.ones_like(x)
+    if margin == 0:
+      return torch.where(within, one, torch.zeros_like(x))
+    scale = math.sqrt(-2 * math.log(margin_value))
+    sigmas = torch.where(x < lower, lower - x, x - upper) / margin
+    values = torch.exp(-0.5 * (sigmas * scale) ** 2)
+    return torch.where(within, one, values)
+
+  within_bounds = np.logical_and(lower <= x, x <= upper)
+  if margin == 0:
+    value = np.where(within_bounds, 1., 0.)
+  else:
+    scale = np.sqrt(-2 * np.log(margin_value))
+    sigmas = np.where(x < lower, lower - x, x - upper) / margin
+    values = np.exp(-0.5 * (sigmas * scale) ** 2)
+    value = np.where(within_bounds, 1., values)
+  return float(value) if np.isscalar(x) else value
+
+
+def linear(x: float, target: float, span: float, symmetric=False) -> float:
+  """rewards.py:434-461"""
+  if span == 0:
+    return 1. if x == target else 0.
+
+  x_delta = x - target
+  if abs(x_delta) > abs(span):
+    return 0.
+
+  ratio = x_delta / span
+  if not symmetric and ratio < 0:
+    return 0
+
+  return 1 - abs(ratio)

@@ -58,6 +58,8 @@ class EmuEngine:
   def step(self, actions=None, flags=abi.STEP_ALL):
     if self.program is None:
       flags &= abi.STEP_PHYSICS
+    if flags == 0:
+      return
     a = None
     if actions is not None:
       a = np.ascontiguousarray(actions, dtype=np.float64)
@@ -78,3 +80,85 @@ class EmuEngine:
     for _ in range(self.cfg.settle_steps):
       self.step(tg, abi.STEP_PHYSICS)
     self.snapshot[:] = self.state
+
+
+class EmuTorchEngine:
+  """Drop-in for gym_solo_amd.engine.Engine backed by the CPU emulator: torch CPU tensors that
+  share memory with the emulator's numpy buffers.  Lets the host API (envs, factories, client
+  facade) be tested without a GPU while still running the product kernel source."""
+
+  _settled = {}  # (config bytes, n) -> snapshot: the settle loop is deterministic
+
+  def __init__(self, cfg, model, n, device=0):
+    import torch
+    import ctypes as C
+    self._torch = torch
+    self._e = EmuEngine(cfg, model, n)
+    key = (bytes(C.string_at(C.addressof(cfg), C.sizeof(cfg))), n)
+    if key not in EmuTorchEngine._settled:
+      self._e.settle()
+      EmuTorchEngine._settled[key] = self._e.snapshot.copy()
+    self._e.snapshot[:] = EmuTorchEngine._settled[key]
+    self._e.state[:] = self._e.snapshot
+    self.cfg, self.model = cfg, model
+    self.num_envs, self.device = n, device
+    self.tdtype = torch.float64  # emulator buffers are double; kernel arithmetic is cfg.dtype
+    self.program = None
+    self.obs_dim = 0
+    for name in ('state', 'snapshot', 'targets', 'params', 'reward', 'done', 'term_count', 'stats'):
+      setattr(self, name, torch.from_numpy(getattr(self._e, name)))
+    self.obs = None
+
+  def set_program(self, program):
+    if (program.num_obs > abi.MAX_OBS or program.num_reward_ops > abi.MAX_REWARD_OPS
+        or program.num_terms > abi.MAX_TERMS):
+      raise ValueError('program too large')
+    self.program = program
+    self._e.program = program
+    self._e.obs = np.zeros((self.num_envs, max(program.num_obs, 1)))
+    self.obs_dim = program.num_obs
+    self.obs = self._torch.from_numpy(self._e.obs) if program.num_obs else None
+
+  def step(self, actions=None, flags=abi.STEP_ALL):
+    prog = self.program
+    if flags & (abi.STEP_OBS | abi.STEP_REWARD | abi.STEP_DONE):
+      # same checks as Engine<T>::check_flags in solo_engine.hip
+      if prog is None:
+        raise ValueError('no observation/reward/termination program registered')
+      if (flags & abi.STEP_OBS) and prog.num_obs == 0:
+        raise ValueError('Need to register at least one observation instance')
+      if (flags & abi.STEP_REWARD) and prog.num_reward_ops == 0:
+        raise ValueError('Need to register at least one reward instance')
+      if (flags & abi.STEP_DONE) and prog.num_terms == 0:
+        raise ValueError('Need to register at least one termination instance')
+    a = None if actions is None else actions.detach().cpu().numpy()
+    self._e.step(a, flags)
+
+  def set_targets(self, actions):
+    self._e.targets[:] = actions.detach().cpu().numpy() * self.cfg.action_scale
+
+  def reset(self, mask=None):
+    e = self._e
+    if mask is None:
+      e.state[:] = e.snapshot
+      e.term_count[:] = 0
+    else:
+      m = mask.detach().cpu().numpy().astype(bool)
+      e.state[m] = e.snapshot[m]
+      e.term_count[m] = 0
+
+  def settle(self):
+    self._e.settle()
+
+  def set_params(self, which, per_env):
+    self._e.params[:, which] = per_env.detach().cpu().numpy()
+
+  def synchronize(self):
+    pass
+
+  def close(self):
+    pass
+
+  @property
+  def kernel_name(self):
+    return 'emulated'

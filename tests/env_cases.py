@@ -1,0 +1,180 @@
+"""Env-level test bodies shared by the CPU (emulator-backed) and GPU (HIP engine) suites.
+They mirror the reference's own env tests, gym_solo/envs/test_solo8v2vanilla.py:22-194, on the
+batched API; each takes ``make_env(**kwargs) -> Solo8VanillaEnv``."""
+import numpy as np
+import pytest
+import torch
+
+from gym_solo_amd import abi, spaces
+from gym_solo_amd.core import obs as solo_obs
+from gym_solo_amd.core import rewards, termination as terms
+from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+from gym_solo_amd.testing import CompliantObs, DummyTermination, SimpleReward
+from oracle import solo_oracle as so
+
+
+def np_(t):
+  return t.detach().cpu().numpy() if hasattr(t, 'detach') else np.asarray(t)
+
+
+def base_pose(env):
+  pos, orn = env.client.getBasePositionAndOrientation(env.robot)
+  return np_(pos).copy(), np_(orn).copy()
+
+
+def case_action_space(make_env):
+  # test_solo8v2vanilla.py:55-70
+  limit = 2 * np.pi
+  env = make_env(config=Solo8VanillaConfig(motor_torque_limit=limit))
+  assert env.action_space == spaces.Box(-limit, limit, shape=(12,))
+  env2 = make_env(normalize_actions=True)
+  assert env2.action_space == spaces.Box(-1, 1, shape=(12,))
+  env2._action_space = None
+  with pytest.raises(ValueError):
+    env2.action_space
+
+
+def case_step_no_rewards(make_env):
+  # test_solo8v2vanilla.py:165-168
+  env = make_env()
+  with pytest.raises(ValueError):
+    env.step(np.zeros(12))
+  env.obs_factory.register_observation(CompliantObs(None))
+  with pytest.raises(ValueError):
+    env.step(np.zeros(12))
+  env.reward_factory.register_reward(1, SimpleReward())
+  with pytest.raises(ValueError):
+    env.step(np.zeros(12))
+
+
+def case_step_simple_reward(make_env):
+  # test_solo8v2vanilla.py:170-175
+  env = make_env()
+  env.reward_factory.register_reward(1, SimpleReward())
+  env.obs_factory.register_observation(CompliantObs(None))
+  env.termination_factory.register_termination(DummyTermination(0, True))
+  o, r, d, info = env.step(env.action_space.sample())
+  n = env.num_envs
+  np.testing.assert_array_equal(np_(r), np.ones(n))
+  np.testing.assert_array_equal(np_(o), np.tile([1., 2.], (n, 1)))
+  assert np_(d).all()
+  assert info['labels'] == ['1', '2']
+
+
+def case_actions_rest_and_motion(make_env):
+  # test_solo8v2vanilla.py:77-104: at rest zero targets keep the pose to 6 decimals; an action
+  # moves it
+  env = make_env()
+  env.reward_factory.register_reward(1, SimpleReward())
+  env.obs_factory.register_observation(CompliantObs(None))
+  env.termination_factory.register_termination(DummyTermination(0, True))
+  no_op = np.zeros(12)
+  for _ in range(1000):
+    env.step(no_op)
+  position, orientation = base_pose(env)
+  for _ in range(10):
+    env.step(no_op)
+  new_pos, new_or = base_pose(env)
+  np.testing.assert_array_almost_equal(position, new_pos)
+  np.testing.assert_array_almost_equal(orientation, new_or)
+  action = np.array([5.] * 12)
+  for _ in range(10):
+    env.step(action)
+  new_pos, new_or = base_pose(env)
+  with pytest.raises(AssertionError):
+    np.testing.assert_array_almost_equal(position, new_pos)
+  with pytest.raises(AssertionError):
+    np.testing.assert_array_almost_equal(orientation, new_or)
+
+
+def case_action_normalization(make_env):
+  # test_solo8v2vanilla.py:106-139: de-normalised targets are exactly +-max_motor_rotation / 0
+  config = Solo8VanillaConfig()
+  config.max_motor_rotation = 10
+  env = make_env(config=config, normalize_actions=True)
+  env.obs_factory.register_observation(CompliantObs(None))
+  env.termination_factory.register_termination(DummyTermination(0, True))
+  env.reward_factory.register_reward(1, SimpleReward())
+  for a, expect in ((-1., -10.), (1., 10.), (0., 0.)):
+    env.step([a] * 12)
+    np.testing.assert_array_equal(np_(env.engine.targets), np.full((env.num_envs, 12), expect))
+
+
+def case_reset(make_env):
+  # test_solo8v2vanilla.py:141-163
+  env = make_env()
+  env.reward_factory.register_reward(1, SimpleReward())
+  env.obs_factory.register_observation(CompliantObs(None))
+  env.termination_factory.register_termination(DummyTermination(0, True))
+  base_pos, base_or = base_pose(env)
+  action = np.array([5.] * 12)
+  for _ in range(100):
+    env.step(action)
+  assert env.termination_factory._terminations[0].reset_counter == 1
+  new_pos, new_or = base_pose(env)
+  with pytest.raises(AssertionError):
+    np.testing.assert_array_almost_equal(base_pos, new_pos)
+  env.reset()
+  assert env.termination_factory._terminations[0].reset_counter == 2
+  new_pos, new_or = base_pose(env)
+  np.testing.assert_array_almost_equal(base_pos, new_pos)
+  np.testing.assert_array_almost_equal(base_or, new_or)
+
+
+def case_disjoint_environments(make_env):
+  # test_solo8v2vanilla.py:177-194: reset obs identical across instances
+  def build():
+    env = make_env()
+    env.obs_factory.register_observation(solo_obs.TorsoIMU(env.robot))
+    env.obs_factory.register_observation(solo_obs.MotorEncoder(env.robot))
+    env.reward_factory.register_reward(1, SimpleReward())
+    env.termination_factory.register_termination(DummyTermination(0, True))
+    return env
+  env1 = build()
+  home_position = np_(env1.reset()).copy()
+  assert home_position.shape == (env1.num_envs, 21)
+  for _ in range(60):
+    env1.step(np.random.uniform(-2 * np.pi, 2 * np.pi, (env1.num_envs, 12)))
+  env2 = build()
+  np.testing.assert_array_almost_equal(home_position, np_(env2.reset()))
+  np.testing.assert_array_almost_equal(home_position, np_(env1.reset()))
+
+
+BENCH_REWARD = ('multiplicative', 1, [
+  ('additive', [(0.5, ('flat_torso', .1, np.pi)), (0.5, ('torso_height', 0.33698, 0.025, 0.15))]),
+  ('small_control', 10), ('horizontal_speed', 0, .5, 3)])
+
+
+from gym_solo_amd.workloads import register_benchmark_workload  # noqa: E402,F401
+
+
+def case_fused_matches_python_and_oracle(make_env, steps, tol, normalize_observations=False,
+                                         dtype='float64'):
+  """The fused kernel's obs/reward/done vs (a) the pull-based Python path over the batched
+  client and (b) the CPU oracle env on the same action stream."""
+  cfg = Solo8VanillaConfig()
+  cfg.dtype = dtype
+  env = make_env(config=cfg, normalize_observations=normalize_observations)
+  register_benchmark_workload(env, max_steps=steps - 3)
+  n = env.num_envs
+  from helpers import make_abi
+  ca, ma = make_abi(dtype)
+  oracle = so.OracleEnv(ca, ma, n, [('torso_imu', {}), ('motor_encoder', {})],
+                        [(1, BENCH_REWARD)], [('time', steps - 3)],
+                        normalize_obs=normalize_observations)
+  np.testing.assert_allclose(np_(env.reset()), oracle.reset(), rtol=0, atol=tol)
+  rng = np.random.default_rng(3)
+  for k in range(steps):
+    a = rng.uniform(-2 * np.pi, 2 * np.pi, (n, 12))
+    o, r, d, _ = env.step(torch.as_tensor(a))
+    oo, orr, od = oracle.step(a)
+    # (a) python path on the very same state
+    py_o = env.obs_factory.get_obs_python()
+    py_r = env.reward_factory.get_reward_python()
+    np.testing.assert_allclose(np_(o), np_(py_o), rtol=0, atol=tol)
+    np.testing.assert_allclose(np_(r), np_(py_r), rtol=0, atol=tol)
+    # (b) oracle
+    np.testing.assert_allclose(np_(o), oo, rtol=0, atol=tol)
+    np.testing.assert_allclose(np_(r), orr, rtol=0, atol=tol)
+    np.testing.assert_array_equal(np_(d).astype(bool), od)
+  assert np_(d).all() and k == steps - 1

@@ -1,0 +1,77 @@
+"""The C-ABI library loads on a CPU-only machine and exports every symbol that
+include/solo_engine.h declares (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from gym_solo_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'solo_engine.h')
+LIB = os.path.join(ROOT, 'gym_solo_amd', 'csrc', 'libsolo_hip.so')
+
+
+def declared_functions():
+  text = open(HEADER).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(solo_[a-z_]+)\s*\(', text)))
+
+
+def test_header_and_ctypes_mirror_agree():
+  assert declared_functions() == sorted(abi.ENTRY_POINTS)
+
+
+def test_struct_sizes_match_header():
+  """Compile a tiny C program against the header and compare sizeof() with the ctypes mirror."""
+  import subprocess, tempfile
+  src = '#include <stdio.h>\n#include "solo_engine.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",' \
+        'sizeof(SoloModel),sizeof(SoloConfig),sizeof(SoloObsElem),sizeof(SoloRewardInstr),' \
+        'sizeof(SoloProgram),sizeof(SoloStateView));return 0;}\n'
+  with tempfile.TemporaryDirectory() as d:
+    open(os.path.join(d, 't.c'), 'w').write(src)
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', os.path.join(d, 't'),
+                           os.path.join(d, 't.c')])
+    got = [int(x) for x in subprocess.check_output([os.path.join(d, 't')]).split()]
+  want = [C.sizeof(t) for t in (abi.SoloModel, abi.SoloConfig, abi.SoloObsElem,
+                                abi.SoloRewardInstr, abi.SoloProgram, abi.SoloStateView)]
+  assert got == want
+
+
+def test_library_exports_every_declared_symbol():
+  if not os.path.exists(LIB):
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.dirname(LIB)])
+  lib = C.CDLL(LIB)
+  for name in declared_functions():
+    assert hasattr(lib, name), name
+  abi.bind(lib)
+  assert lib.solo_abi_version() == abi.ABI_VERSION
+
+
+def test_product_fails_loudly_without_gpu():
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('a GPU is visible')
+  from gym_solo_amd.engine import Engine, EngineError
+  from helpers import make_abi
+  ca, ma = make_abi('float32')
+  with pytest.raises(EngineError, match='no CPU fallback'):
+    Engine(ca, ma, 4)
+
+
+def test_create_rejects_bad_arguments():
+  from gym_solo_amd.engine import load_library
+  from helpers import make_abi
+  lib = load_library()
+  ca, ma = make_abi('float32')
+  h = C.c_void_p()
+  assert lib.solo_engine_create(C.byref(ca), C.byref(ma), 0, 0, C.byref(h)) == abi.ERR_INVALID_ARG
+  ca.restitution = 0.5
+  assert lib.solo_engine_create(C.byref(ca), C.byref(ma), 4, 0, C.byref(h)) == abi.ERR_INVALID_ARG
+  assert b'restitution' in lib.solo_last_create_error()
+  ca, ma = make_abi('float32')
+  ma.joint_axis[3][1] = 0.0
+  ma.joint_axis[3][2] = 1.0
+  assert lib.solo_engine_create(C.byref(ca), C.byref(ma), 4, 0, C.byref(h)) == abi.ERR_UNSUPPORTED_MODEL

@@ -1,0 +1,105 @@
+"""GPU suite of the env-level cases (HIP engine through the C-ABI); mirrors
+gym_solo/envs/test_solo8v2vanilla.py on the batched API."""
+import numpy as np
+import pytest
+
+import env_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(config=None, **kw):
+  import torch
+  if not torch.cuda.is_available():
+    pytest.fail('GPU tests need a visible MI355X')
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
+  config = config or Solo8VanillaConfig()
+  if not getattr(config, '_dtype_pinned', False):
+    config.dtype = getattr(make_env, 'dtype', 'float64')
+  config.num_envs = getattr(make_env, 'num_envs', 64)
+  return Solo8VanillaEnv(config=config, **kw)
+
+
+def test_action_space():
+  cases.case_action_space(make_env)
+
+
+def test_step_no_rewards():
+  cases.case_step_no_rewards(make_env)
+
+
+def test_step_simple_reward():
+  cases.case_step_simple_reward(make_env)
+
+
+def test_action_normalization():
+  cases.case_action_normalization(make_env)
+
+
+def test_reset():
+  cases.case_reset(make_env)
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_actions_rest_and_motion(dtype):
+  make_env.dtype = dtype
+  try:
+    cases.case_actions_rest_and_motion(make_env)
+  finally:
+    make_env.dtype = 'float64'
+
+
+def test_disjoint_environments():
+  cases.case_disjoint_environments(make_env)
+
+
+@pytest.mark.parametrize('normalize', [False, True])
+def test_fused_matches_python_and_oracle_f64(normalize):
+  cases.case_fused_matches_python_and_oracle(make_env, steps=40, tol=1e-9,
+                                             normalize_observations=normalize)
+
+
+def test_fused_matches_python_f32():
+  """f32 engine: fused obs/reward vs the pull-based python path on the same f32 state."""
+  import torch
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  cfg = Solo8VanillaConfig()
+  cfg.dtype = 'float32'
+  cfg._dtype_pinned = True
+  env = make_env(config=cfg)
+  cases.register_benchmark_workload(env, max_steps=1000)
+  rng = np.random.default_rng(5)
+  for k in range(50):
+    a = torch.as_tensor(rng.uniform(-2 * np.pi, 2 * np.pi, (env.num_envs, 12)))
+    o, r, d, _ = env.step(a)
+    py_o = env.obs_factory.get_obs_python()
+    py_r = env.reward_factory.get_reward_python()
+    np.testing.assert_allclose(cases.np_(o), cases.np_(py_o), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(cases.np_(r), cases.np_(py_r), rtol=0, atol=2e-5)
+    assert not cases.np_(d).any()
+
+
+def test_auto_reset_and_stats():
+  """Build extension: in-kernel auto-reset + episodic-return statistics."""
+  import torch
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  cfg = Solo8VanillaConfig()
+  cfg.auto_reset = True
+  env = make_env(config=cfg)
+  cases.register_benchmark_workload(env, max_steps=9)
+  n = env.num_envs
+  home = cases.np_(env.engine.snapshot).copy()
+  total = np.zeros(n)
+  a = torch.zeros(n, 12, dtype=torch.float64)
+  for k in range(10):
+    o, r, d, _ = env.step(a)
+    total += cases.np_(r)
+    assert bool(cases.np_(d).all()) == (k == 9)
+  env.engine.synchronize()
+  st = cases.np_(env.engine.state)
+  np.testing.assert_array_equal(st, home)          # restored from the snapshot, counters cleared
+  assert (cases.np_(env.engine.term_count) == 0).all()
+  stats = cases.np_(env.engine.stats)
+  np.testing.assert_allclose(stats[0], total.sum(), rtol=1e-12)
+  np.testing.assert_allclose(stats[1], (total ** 2).sum(), rtol=1e-12)
+  assert stats[2] == n and stats[3] == 10 * n and stats[4] == 10 * n and stats[5] == 0
