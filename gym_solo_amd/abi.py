@@ -18,6 +18,8 @@ STATE_STRIDE = 32
 MAX_OBS = 64
 MAX_REWARD_OPS = 32
 MAX_TERMS = 4
+STATS_SHARDS = 64
+STATS_WIDTH = 8
 
 S_POS, S_QUAT, S_Q, S_ANGVEL, S_LINVEL, S_QD, S_RETURN, S_EPLEN, S_SPARE = (
   0, 3, 7, 15, 18, 21, 29, 30, 31)

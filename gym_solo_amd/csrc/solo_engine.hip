@@ -40,6 +40,8 @@ struct EngineBase {
     }                                                                                 \
   } while (0)
 
+constexpr size_t kStatsBytes = (size_t)SOLO_STATS_SHARDS * SOLO_STATS_WIDTH * sizeof(double);
+
 template <typename T>
 struct Engine final : EngineBase {
   SoloConfig cfg;
@@ -77,12 +79,12 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMalloc((void**)&reward, (size_t)n * sizeof(T)));
     HIP_TRY(hipMalloc((void**)&done, (size_t)n));
     HIP_TRY(hipMalloc((void**)&term_count, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void**)&stats, 8 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&stats, kStatsBytes));
     HIP_TRY(hipMemset(obs, 0, (size_t)n * SOLO_MAX_OBS * sizeof(T)));
     HIP_TRY(hipMemset(reward, 0, (size_t)n * sizeof(T)));
     HIP_TRY(hipMemset(done, 0, (size_t)n));
     HIP_TRY(hipMemset(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t)));
-    HIP_TRY(hipMemset(stats, 0, 8 * sizeof(double)));
+    HIP_TRY(hipMemset(stats, 0, kStatsBytes));
     std::vector<T> hp((size_t)n * 4, T(0));
     std::vector<T> ha((size_t)n * SOLO_NUM_JOINTS);
     for (int e = 0; e < n; ++e) {
@@ -126,7 +128,7 @@ struct Engine final : EngineBase {
       if (int rc = launch(settle_actions, SOLO_STEP_PHYSICS, s)) return rc;
     HIP_TRY(hipMemcpyAsync(snapshot, state, (size_t)total * sizeof(T), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemsetAsync(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t), s));
-    HIP_TRY(hipMemsetAsync(stats, 0, 8 * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(stats, 0, kStatsBytes, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SOLO_OK;
   }

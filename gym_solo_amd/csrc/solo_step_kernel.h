@@ -105,82 +105,110 @@ __device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
   return within ? T(1) : v;
 }
 
-// ---- PGS row steps: LANE is the (compile-time) lane that owns the row -------------------
+// ---- projected Gauss-Seidel on the Delassus matrix ------------------------------------------
+// Lane s iterates on its UNCLAMPED candidate  v_s = lam_s - w_s / A_ss  (w = constraint-space
+// velocity error).  v_s is invariant under row s's own update, so with the scaled row
+// An[s][r] = -A_sr / A_ss (r != s), An[s][s] = 0 a row update is, for ALL lanes at once,
+//     v += An[.][r] * (lam_r_new - lam_r_old).
+// The impulse of row r is wave-uniform, so it lives in an SGPR (sl[r]) - no per-lane select,
+// and the change is applied as two fused multiply-adds with one SGPR operand each (gfx950 VALU
+// instructions take a single scalar operand; there is no scalar float subtract):
+//     t    = v - An[r] * sl[r]       (v_fma_f32, off the critical path)
+//     cand = clamp(v)                (v_med3_f32, every lane, only lane r matters)
+//     sl[r] = readlane(cand, r)      (v_readlane_b32)
+//     v    = t + An[r] * sl[r]       (v_fma_f32)
+// LANE is the compile-time lane that owns the row.
 template <typename T, int LANE>
-__device__ __forceinline__ void pgs_row_box(T& lam, T& w, T inv_d, T lo, T hi, const T (&A)[kNumRowSlots], int lane) {
-  T cand = lam - w * inv_d;
-  cand = Real<T>::min(Real<T>::max(cand, lo), hi);
-  const T delta = wave_readlane(cand - lam, LANE);
-  lam = (lane == LANE) ? cand : lam;
-  w += A[slot_of_lane(LANE)] * delta;
+__device__ __forceinline__ void pgs_row_box(T& v, T lo, T hi, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
+  const T a = An[slot_of_lane(LANE)];
+  const T t = Real<T>::fma(-a, sl[slot_of_lane(LANE)], v);
+  sl[slot_of_lane(LANE)] = wave_readlane(Real<T>::clamp(v, lo, hi), LANE);
+  v = Real<T>::fma(a, sl[slot_of_lane(LANE)], t);
 }
-// one touching sphere: normal row at lane BASE, tangents at BASE+1, BASE+2
+// one touching sphere: normal row at lane BASE, tangents at BASE+1, BASE+2 (friction pyramid
+// with the limit mu * lam_n of the freshly updated normal impulse)
 template <typename T, int BASE>
-__device__ __forceinline__ void pgs_contact(T& lam, T& w, T inv_d, T mu, const T (&A)[kNumRowSlots], int lane) {
-  T cand = Real<T>::max(lam - w * inv_d, T(0));
-  const T ln = wave_readlane(cand, BASE);
-  const T dn = wave_readlane(cand - lam, BASE);
-  lam = (lane == BASE) ? cand : lam;
-  w += A[slot_of_lane(BASE)] * dn;
-  const T lim = mu * ln;
-  pgs_row_box<T, BASE + 1>(lam, w, inv_d, -lim, lim, A, lane);
-  pgs_row_box<T, BASE + 2>(lam, w, inv_d, -lim, lim, A, lane);
+__device__ __forceinline__ void pgs_contact(T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
+  pgs_row_box<T, BASE>(v, T(0), Real<T>::big(), sl, An);
+  const T lim = mu * sl[slot_of_lane(BASE)];
+  pgs_row_box<T, BASE + 1>(v, -lim, lim, sl, An);
+  pgs_row_box<T, BASE + 2>(v, -lim, lim, sl, An);
 }
 
-// A[slot(R)] for the three rows of sphere S (skipped when the sphere does not touch)
+// An[slot(R)] = -(ghat_me.ghat_R + [same leg] hhat_me.hhat_R) / A_me,me   (0 on the diagonal)
 template <typename T, int R>
-__device__ __forceinline__ void build_a_entry(T (&A)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, int lane) {
+__device__ __forceinline__ void build_a_entry(T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T neg_inv_d, int lane) {
   const T* rv = rowvec[R];
-  T a = gh[0] * rv[0] + gh[1] * rv[1] + gh[2] * rv[2] + gh[3] * rv[3] + gh[4] * rv[4] + gh[5] * rv[5];
+  const T a = gh[0] * rv[0] + gh[1] * rv[1] + gh[2] * rv[2] + gh[3] * rv[3] + gh[4] * rv[4] + gh[5] * rv[5];
   const T b = hh[0] * rv[6] + hh[1] * rv[7];
-  A[slot_of_lane(R)] = ((lane >> 4) == (R >> 4)) ? (a + b) : a;
+  const T full = ((lane >> 4) == (R >> 4)) ? (a + b) : a;
+  An[slot_of_lane(R)] = (lane == R) ? T(0) : full * neg_inv_d;
+}
+template <typename T, int R>
+__device__ __forceinline__ T pick_lambda(T lam, const T (&sl)[kNumRowSlots], int lane) {
+  return (lane == R) ? sl[slot_of_lane(R)] : lam;
 }
 
 template <typename T, int S>
 struct ForSpheres {
-  static __device__ __forceinline__ void build(unsigned long long mask, T (&A)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, int lane) {
+  static __device__ __forceinline__ void build(unsigned long long mask, T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
     constexpr int B = sphere_lane(S);
     if ((mask >> B) & 1ull) {
-      build_a_entry<T, B>(A, rowvec, gh, hh, lane);
-      build_a_entry<T, B + 1>(A, rowvec, gh, hh, lane);
-      build_a_entry<T, B + 2>(A, rowvec, gh, hh, lane);
+      build_a_entry<T, B>(An, rowvec, gh, hh, nid, lane);
+      build_a_entry<T, B + 1>(An, rowvec, gh, hh, nid, lane);
+      build_a_entry<T, B + 2>(An, rowvec, gh, hh, nid, lane);
     }
-    ForSpheres<T, S + 1>::build(mask, A, rowvec, gh, hh, lane);
+    ForSpheres<T, S + 1>::build(mask, An, rowvec, gh, hh, nid, lane);
   }
-  static __device__ __forceinline__ void solve(unsigned long long mask, T& lam, T& w, T inv_d, T mu, const T (&A)[kNumRowSlots], int lane) {
+  static __device__ __forceinline__ void solve(unsigned long long mask, T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
     constexpr int B = sphere_lane(S);
-    if ((mask >> B) & 1ull) pgs_contact<T, B>(lam, w, inv_d, mu, A, lane);
-    ForSpheres<T, S + 1>::solve(mask, lam, w, inv_d, mu, A, lane);
+    if ((mask >> B) & 1ull) pgs_contact<T, B>(v, mu, sl, An);
+    ForSpheres<T, S + 1>::solve(mask, v, mu, sl, An);
+  }
+  static __device__ __forceinline__ T gather(unsigned long long mask, T lam, const T (&sl)[kNumRowSlots], int lane) {
+    constexpr int B = sphere_lane(S);
+    if ((mask >> B) & 1ull) {
+      lam = pick_lambda<T, B>(lam, sl, lane);
+      lam = pick_lambda<T, B + 1>(lam, sl, lane);
+      lam = pick_lambda<T, B + 2>(lam, sl, lane);
+    }
+    return ForSpheres<T, S + 1>::gather(mask, lam, sl, lane);
   }
 };
 template <typename T>
 struct ForSpheres<T, SOLO_MAX_SPHERES> {
-  static __device__ __forceinline__ void build(unsigned long long, T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, int) {}
-  static __device__ __forceinline__ void solve(unsigned long long, T&, T&, T, T, const T (&)[kNumRowSlots], int) {}
+  static __device__ __forceinline__ void build(unsigned long long, T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, T, int) {}
+  static __device__ __forceinline__ void solve(unsigned long long, T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
+  static __device__ __forceinline__ T gather(unsigned long long, T lam, const T (&)[kNumRowSlots], int) { return lam; }
 };
 template <typename T, int D>
 struct ForMotors {
-  static __device__ __forceinline__ void build(T (&A)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, int lane) {
-    build_a_entry<T, motor_lane(D)>(A, rowvec, gh, hh, lane);
-    ForMotors<T, D + 1>::build(A, rowvec, gh, hh, lane);
+  static __device__ __forceinline__ void build(T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
+    build_a_entry<T, motor_lane(D)>(An, rowvec, gh, hh, nid, lane);
+    ForMotors<T, D + 1>::build(An, rowvec, gh, hh, nid, lane);
   }
-  static __device__ __forceinline__ void solve(T& lam, T& w, T inv_d, T imp, const T (&A)[kNumRowSlots], int lane) {
-    pgs_row_box<T, motor_lane(D)>(lam, w, inv_d, -imp, imp, A, lane);
-    ForMotors<T, D + 1>::solve(lam, w, inv_d, imp, A, lane);
+  static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
+    pgs_row_box<T, motor_lane(D)>(v, -imp, imp, sl, An);
+    ForMotors<T, D + 1>::solve(v, imp, sl, An);
+  }
+  static __device__ __forceinline__ T gather(T lam, const T (&sl)[kNumRowSlots], int lane) {
+    return ForMotors<T, D + 1>::gather(pick_lambda<T, motor_lane(D)>(lam, sl, lane), sl, lane);
   }
 };
 template <typename T>
 struct ForMotors<T, SOLO_NUM_DOF> {
-  static __device__ __forceinline__ void build(T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, int) {}
-  static __device__ __forceinline__ void solve(T&, T&, T, T, const T (&)[kNumRowSlots], int) {}
+  static __device__ __forceinline__ void build(T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, T, int) {}
+  static __device__ __forceinline__ void solve(T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
+  static __device__ __forceinline__ T gather(T lam, const T (&)[kNumRowSlots], int) { return lam; }
 };
 
 // ------------------------------------------------------------------------------------------
-// physics: A3 + A4 of SURVEY.md §8a.  Reads s_state (old), writes s_state (new).
+// physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
+// constraint impulse; physics_finish writes s_state (new).
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void physics_step(const KParams<T>* __restrict__ P, T* s_state, const T* s_tgt,
-                                             T (*s_rowvec)[8], T mu, T mass_scale, int lane) {
+__device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, const T* s_state, const T* s_tgt,
+                                           T (*s_rowvec)[8], T* s_keep, T (*s_leg)[20], T mu, T mass_scale, int lane) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = P->dt;
@@ -411,40 +439,85 @@ __device__ __forceinline__ void physics_step(const KParams<T>* __restrict__ P, T
   s_rowvec[lane][6] = hh[0];
   s_rowvec[lane][7] = hh[1];
   const unsigned long long touching = wave_ballot(live && type == ROW_NORMAL);
+  // Park everything the post-solve phase needs in LDS so that the Gauss-Seidel loop keeps only
+  // the Delassus row (56 VGPRs) + 4 scalars live: 4 waves/SIMD in f32, i.e. all 4096 robots
+  // of a 4096-env batch resident at once on the 1024 SIMDs.
+  if (lane == 0) {
+    int o = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) s_keep[o++] = S[i][j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { s_keep[15 + i] = iC[i]; s_keep[21 + i] = ub[i]; }
+  }
+  if (k == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { s_leg[leg][i] = K1[i]; s_leg[leg][6 + i] = K2[i]; }
+    s_leg[leg][12] = iL11; s_leg[leg][13] = L21; s_leg[leg][14] = iL22;
+    s_leg[leg][15] = us1; s_leg[leg][16] = us2; s_leg[leg][17] = q1; s_leg[leg][18] = q2;
+  }
   wave_sync();
 
-  // ---- Delassus row of this lane, then projected Gauss-Seidel -------------------------------
-  T A[kNumRowSlots];
+  // ---- scaled Delassus row of this lane, then projected Gauss-Seidel --------------------------
+  T An[kNumRowSlots];
 #pragma unroll
-  for (int i = 0; i < kNumRowSlots; ++i) A[i] = T(0);
-  ForMotors<T, 0>::build(A, s_rowvec, gh, hh, lane);
-  ForSpheres<T, 0>::build(touching, A, s_rowvec, gh, hh, lane);
-  T lam = T(0);
+  for (int i = 0; i < kNumRowSlots; ++i) An[i] = T(0);
+  const T nid = -inv_d;
+  ForMotors<T, 0>::build(An, s_rowvec, gh, hh, nid, lane);
+  ForSpheres<T, 0>::build(touching, An, s_rowvec, gh, hh, nid, lane);
+  T sl[kNumRowSlots];  // impulses: wave-uniform -> scalar registers
+#pragma unroll
+  for (int i = 0; i < kNumRowSlots; ++i) sl[i] = T(0);
+  T v = w * nid;       // lam = 0
   const T imp = P->motor_impulse;
+  const int iters = P->iterations;
 #pragma unroll 1
-  for (int it = 0; it < P->iterations; ++it) {
-    ForMotors<T, 0>::solve(lam, w, inv_d, imp, A, lane);
-    ForSpheres<T, 0>::solve(touching, lam, w, inv_d, mu, A, lane);
+  for (int it = 0; it < iters; ++it) {
+    ForMotors<T, 0>::solve(v, imp, sl, An);
+    ForSpheres<T, 0>::solve(touching, v, mu, sl, An);
   }
+  T lam = ForMotors<T, 0>::gather(T(0), sl, lane);
+  lam = ForSpheres<T, 0>::gather(touching, lam, sl, lane);
+  return lam;
+}
 
-  // ---- apply the impulses: du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam - K du_b ---
+// post-solve half: apply the impulses (du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam -
+// K du_b), go back to world-frame velocities and integrate.  Everything is re-read from LDS.
+template <typename T>
+__device__ __forceinline__ void physics_finish(const KParams<T>* __restrict__ P, T* s_state, const T (*s_rowvec)[8],
+                                               const T* s_keep, const T (*s_leg)[20], T lam, int lane) {
+  using R = Real<T>;
+  const int leg = lane >> 4, k = lane & 15;
+  const T dt = P->dt;
   T z[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) z[i] = sum_over_legs(sum_over_group16(gh[i] * lam));
-  const T yl1 = sum_over_group16(hh[0] * lam), yl2 = sum_over_group16(hh[1] * lam);
+  for (int i = 0; i < 6; ++i) z[i] = sum_over_legs(sum_over_group16(s_rowvec[lane][i] * lam));
+  const T yl1 = sum_over_group16(s_rowvec[lane][6] * lam), yl2 = sum_over_group16(s_rowvec[lane][7] * lam);
+  // C^T x = z (back substitution with the parked Cholesky factor)
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
     T s = z[i];
 #pragma unroll
-    for (int m = i + 1; m < 6; ++m) s -= S[m][i] * z[m];
-    z[i] = s * iC[i];
+    for (int m = i + 1; m < 6; ++m) s -= s_keep[m * (m - 1) / 2 + i] * z[m];
+    z[i] = s * s_keep[15 + i];
   }
+  const T iL11 = s_leg[leg][12], L21 = s_leg[leg][13], iL22 = s_leg[leg][14];
   const T t2 = yl2 * iL22, t1 = (yl1 - L21 * t2) * iL11;
-  T kz1 = T(0), kz2 = T(0);
+  T kz1 = T(0), kz2 = T(0), ub[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { kz1 += K1[i] * z[i]; kz2 += K2[i] * z[i]; ub[i] += z[i]; }
-  us1 += t1 - kz1;
-  us2 += t2 - kz2;
+  for (int i = 0; i < 6; ++i) {
+    kz1 += s_leg[leg][i] * z[i];
+    kz2 += s_leg[leg][6 + i] * z[i];
+    ub[i] = s_keep[21 + i] + z[i];
+  }
+  const T us1 = s_leg[leg][15] + t1 - kz1;
+  const T us2 = s_leg[leg][16] + t2 - kz2;
+  const T q1 = s_leg[leg][17], q2 = s_leg[leg][18];
+  const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
+  const T r00 = T(1) - T(2) * (qy * qy + qz * qz), r01 = T(2) * (qx * qy - qw * qz), r02 = T(2) * (qx * qz + qw * qy);
+  const T r10 = T(2) * (qx * qy + qw * qz), r11 = T(1) - T(2) * (qx * qx + qz * qz), r12 = T(2) * (qy * qz - qw * qx);
+  const T r20 = T(2) * (qx * qz - qw * qy), r21 = T(2) * (qy * qz + qw * qx), r22 = T(1) - T(2) * (qx * qx + qy * qy);
 
   // ---- back to world-frame velocities, integrate positions ----------------------------------
   const V3<T> wn = {r00 * ub[0] + r01 * ub[1] + r02 * ub[2], r10 * ub[0] + r11 * ub[1] + r12 * ub[2], r20 * ub[0] + r21 * ub[1] + r22 * ub[2]};
@@ -479,12 +552,16 @@ __device__ __forceinline__ void physics_step(const KParams<T>* __restrict__ P, T
 // ------------------------------------------------------------------------------------------
 // the fused kernel
 // ------------------------------------------------------------------------------------------
+// __launch_bounds__(64, W): W waves per SIMD -> 512/W VGPRs.  f32: 4 (128 VGPRs, a whole 4096-robot
+// batch resident on the 1024 SIMDs); f64: 2 (the Delassus row alone is 112 VGPRs).
 template <typename T>
-__global__ __launch_bounds__(64) void solo_step_kernel(const KParams<T>* __restrict__ P, KBuffers<T> B) {
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(const KParams<T>* __restrict__ P, KBuffers<T> B) {
   using R = Real<T>;
   __shared__ T s_state[SOLO_STATE_STRIDE];
   __shared__ T s_tgt[16];
   __shared__ T s_rowvec[64][8];
+  __shared__ T s_keep[32];
+  __shared__ T s_leg[4][20];
   __shared__ T s_src[48];
   __shared__ T s_stack[8];
 
@@ -492,6 +569,9 @@ __global__ __launch_bounds__(64) void solo_step_kernel(const KParams<T>* __restr
   const int env = block_id();
   if (env >= B.num_envs) return;
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
+  // episodic statistics are sharded over SOLO_STATS_SHARDS rows: all robots of a batch finish
+  // their episodes in the same step, and same-address atomics serialise at ~12 ns each
+  double* stats = B.stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH;
 
   if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.state[rec + lane];
   if (lane < SOLO_NUM_JOINTS) {
@@ -511,13 +591,14 @@ __global__ __launch_bounds__(64) void solo_step_kernel(const KParams<T>* __restr
 
   bool diverged = false;
   if (B.flags & SOLO_STEP_PHYSICS) {
-    physics_step<T>(P, s_state, s_tgt, s_rowvec, mu, mass_scale, lane);
+    const T lam = physics_solve<T>(P, s_state, s_tgt, s_rowvec, s_keep, s_leg, mu, mass_scale, lane);
+    physics_finish<T>(P, s_state, s_rowvec, s_keep, s_leg, lam, lane);
     // a robot whose state went non-finite is restored from its snapshot and counted
     const bool bad = lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31]);
     diverged = wave_ballot(bad) != 0ull;
     if (diverged) {
       if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
-      if (lane == 0) stats_add(&B.stats[5], 1.0);
+      if (lane == 0) stats_add(&stats[5], 1.0);
       wave_sync();
     }
   }
@@ -616,10 +697,10 @@ __global__ __launch_bounds__(64) void solo_step_kernel(const KParams<T>* __restr
     if (restart) {
       if (lane == 0 && done) {
         const double ret = (double)s_state[SOLO_S_RETURN];
-        stats_add(&B.stats[0], ret);
-        stats_add(&B.stats[1], ret * ret);
-        stats_add(&B.stats[2], 1.0);
-        stats_add(&B.stats[3], (double)s_state[SOLO_S_EPLEN]);
+        stats_add(&stats[0], ret);
+        stats_add(&stats[1], ret * ret);
+        stats_add(&stats[2], 1.0);
+        stats_add(&stats[3], (double)s_state[SOLO_S_EPLEN]);
       }
       wave_sync();
       if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.snapshot[rec + lane];
@@ -633,7 +714,6 @@ __global__ __launch_bounds__(64) void solo_step_kernel(const KParams<T>* __restr
       for (int t = 0; t < SOLO_MAX_TERMS; ++t) B.term_count[(size_t)env * SOLO_MAX_TERMS + t] = cnt[t];
     }
   }
-  if (lane == 0 && (B.flags & SOLO_STEP_PHYSICS)) stats_add(&B.stats[4], 1.0);
   if (lane < SOLO_STATE_STRIDE) B.state[rec + lane] = s_state[lane];
 }
 

@@ -39,7 +39,9 @@ template <> struct Real<float> {
   static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
   static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
   static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+  static __device__ __forceinline__ float clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
   static __device__ __forceinline__ bool finite(float x) { return isfinite(x); }
+  static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
   static __device__ __forceinline__ float big() { return 3.0e38f; }
 };
 template <> struct Real<double> {
@@ -52,7 +54,9 @@ template <> struct Real<double> {
   static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
   static __device__ __forceinline__ double min(double a, double b) { return ::fmin(a, b); }
   static __device__ __forceinline__ double max(double a, double b) { return ::fmax(a, b); }
+  static __device__ __forceinline__ double clamp(double x, double lo, double hi) { return ::fmin(::fmax(x, lo), hi); }
   static __device__ __forceinline__ bool finite(double x) { return isfinite(x); }
+  static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
   static __device__ __forceinline__ double big() { return 1.0e300; }
 };
 

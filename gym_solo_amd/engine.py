@@ -94,7 +94,7 @@ class Engine:
     self.done = view(v.done, (n,), '|u1')
     self.term_count = view(v.term_count, (n, abi.MAX_TERMS), '<i4')
     self.params = view(v.params, (n, 4), real)
-    self.stats = view(v.stats, (8,), '<f8')
+    self.stats_shards = view(v.stats, (abi.STATS_SHARDS, abi.STATS_WIDTH), '<f8')
     self.obs_dim = v.obs_dim
     self._obs_ptr, self._real = v.obs, real
     self.obs = view(v.obs, (n, max(v.obs_dim, 1)), real) if v.obs_dim else None
@@ -158,6 +158,12 @@ class Engine:
     self._check(self.lib.solo_engine_set_params(self._h, which, p, self._stream()), 'set_params')
 
   @property
+  def stats(self):
+    """[sum return, sum return^2, episodes, sum length, -, diverged, -, -] (float64, summed over
+    the shards the kernel accumulates into)."""
+    return self.stats_shards.sum(dim=0)
+
+  @property
   def kernel_name(self):
     return self.lib.solo_engine_kernel_name(self._h).decode()
 
@@ -168,7 +174,7 @@ class Engine:
     if getattr(self, '_h', None):
       self._torch.cuda.synchronize(self.device)
       for name in ('state', 'snapshot', 'targets', 'reward', 'done', 'term_count', 'params',
-                   'stats', 'obs'):
+                   'stats_shards', 'obs'):
         setattr(self, name, None)
       self.lib.solo_engine_destroy(self._h)
       self._h = None

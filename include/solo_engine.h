@@ -50,6 +50,8 @@ extern "C" {
 #define SOLO_MAX_OBS 64       /* observation elements per env                          */
 #define SOLO_MAX_REWARD_OPS 32
 #define SOLO_MAX_TERMS 4
+#define SOLO_STATS_SHARDS 64  /* episodic statistics are accumulated in 64 rows (sum them) */
+#define SOLO_STATS_WIDTH 8
 
 /* env record layout (reals), AoS so that one wavefront reads its robot's whole
  * state as ONE coalesced 128-B (f32) / 256-B (f64) line: */
@@ -193,7 +195,8 @@ typedef struct SoloStateView {
   void* done;           /* uint8 [N]                                      */
   void* term_count;     /* int32 [N][SOLO_MAX_TERMS]                      */
   void* params;         /* real  [N][4]: lateral friction, base-mass scale, 2 spare */
-  void* stats;          /* double[8]: sum return, sum return^2, episodes, sum length, steps, diverged, 2 spare */
+  void* stats;          /* double[SOLO_STATS_SHARDS][8], sum over the shard axis: sum return, sum return^2,
+                           episodes, sum length, (unused), diverged robots restored, 2 spare */
 } SoloStateView;
 
 typedef struct SoloEngine SoloEngine;

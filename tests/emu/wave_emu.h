@@ -47,7 +47,7 @@ solo_emu_switch:
 #define __global__
 #define __forceinline__ inline
 #define __shared__ static
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 
 struct EmuDim3 { int x = 0, y = 0, z = 0; };
 static EmuDim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -154,7 +154,9 @@ template <> struct Real<float> {
   static float abs(float x) { return std::fabs(x); }
   static float min(float a, float b) { return std::fmin(a, b); }
   static float max(float a, float b) { return std::fmax(a, b); }
+  static float clamp(float x, float lo, float hi) { return std::fmin(std::fmax(x, lo), hi); }
   static bool finite(float x) { return std::isfinite(x); }
+  static float fma(float a, float b, float c) { return std::fma(a, b, c); }
   static float big() { return 3.0e38f; }
 };
 template <> struct Real<double> {
@@ -167,7 +169,9 @@ template <> struct Real<double> {
   static double abs(double x) { return std::fabs(x); }
   static double min(double a, double b) { return std::fmin(a, b); }
   static double max(double a, double b) { return std::fmax(a, b); }
+  static double clamp(double x, double lo, double hi) { return std::fmin(std::fmax(x, lo), hi); }
   static bool finite(double x) { return std::isfinite(x); }
+  static double fma(double a, double b, double c) { return std::fma(a, b, c); }
   static double big() { return 1.0e300; }
 };
 

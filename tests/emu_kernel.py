@@ -53,7 +53,7 @@ class EmuEngine:
     self.reward = np.zeros(n)
     self.done = np.zeros(n, dtype=np.uint8)
     self.term_count = np.zeros((n, abi.MAX_TERMS), dtype=np.int32)
-    self.stats = np.zeros(8)
+    self.stats = np.zeros((abi.STATS_SHARDS, abi.STATS_WIDTH))
 
   def step(self, actions=None, flags=abi.STEP_ALL):
     if self.program is None:
@@ -105,8 +105,9 @@ class EmuTorchEngine:
     self.tdtype = torch.float64  # emulator buffers are double; kernel arithmetic is cfg.dtype
     self.program = None
     self.obs_dim = 0
-    for name in ('state', 'snapshot', 'targets', 'params', 'reward', 'done', 'term_count', 'stats'):
+    for name in ('state', 'snapshot', 'targets', 'params', 'reward', 'done', 'term_count'):
       setattr(self, name, torch.from_numpy(getattr(self._e, name)))
+    self.stats_shards = torch.from_numpy(self._e.stats)
     self.obs = None
 
   def set_program(self, program):
@@ -158,6 +159,10 @@ class EmuTorchEngine:
 
   def close(self):
     pass
+
+  @property
+  def stats(self):
+    return self.stats_shards.sum(dim=0)
 
   @property
   def kernel_name(self):

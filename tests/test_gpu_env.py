@@ -102,4 +102,4 @@ def test_auto_reset_and_stats():
   stats = cases.np_(env.engine.stats)
   np.testing.assert_allclose(stats[0], total.sum(), rtol=1e-12)
   np.testing.assert_allclose(stats[1], (total ** 2).sum(), rtol=1e-12)
-  assert stats[2] == n and stats[3] == 10 * n and stats[4] == 10 * n and stats[5] == 0
+  assert stats[2] == n and stats[3] == 10 * n and stats[5] == 0
