@@ -55,6 +55,9 @@ struct Engine final : EngineBase {
   uint8_t* done = nullptr;
   int32_t* term_count = nullptr;
   double* stats = nullptr;
+#ifdef SOLO_STAMPS
+  unsigned long long* stamps = nullptr;
+#endif
 
   ~Engine() override {
     (void)hipSetDevice(device);
@@ -85,6 +88,10 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMemset(done, 0, (size_t)n));
     HIP_TRY(hipMemset(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t)));
     HIP_TRY(hipMemset(stats, 0, kStatsBytes));
+#ifdef SOLO_STAMPS
+    HIP_TRY(hipMalloc((void**)&stamps, (size_t)n * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(stamps, 0, (size_t)n * 16 * sizeof(unsigned long long)));
+#endif
     std::vector<T> hp((size_t)n * 4, T(0));
     std::vector<T> ha((size_t)n * SOLO_NUM_JOINTS);
     for (int e = 0; e < n; ++e) {
@@ -105,6 +112,9 @@ struct Engine final : EngineBase {
     b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
     b.params = params; b.obs = obs; b.reward = reward; b.done = done; b.term_count = term_count;
     b.stats = stats; b.num_envs = n; b.flags = flags;
+#ifdef SOLO_STAMPS
+    b.stamps = stamps;
+#endif
     return b;
   }
 
@@ -252,6 +262,17 @@ int check_config(const SoloConfig* c, std::string* err) {
 struct SoloEngine { EngineBase* impl; };
 
 extern "C" {
+
+#ifdef SOLO_STAMPS
+// DIAGNOSTIC build only: copies the [N][16] s_memtime stamps of the last launch to the host.
+int solo_engine_debug_stamps(SoloEngine* eng, unsigned long long* host, int is_f32) {
+  if (!eng || !eng->impl) return SOLO_ERR_INVALID_ARG;
+  hipDeviceSynchronize();
+  if (is_f32) { auto* e = static_cast<Engine<float>*>(eng->impl); return hipMemcpy(host, e->stamps, (size_t)e->n * 128, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SOLO_ERR_HIP; }
+  auto* e = static_cast<Engine<double>*>(eng->impl);
+  return hipMemcpy(host, e->stamps, (size_t)e->n * 128, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SOLO_ERR_HIP;
+}
+#endif
 
 int solo_abi_version(void) { return SOLO_ABI_VERSION; }
 const char* solo_last_create_error(void) { return g_create_error.c_str(); }

@@ -16,9 +16,10 @@ namespace solo {
 
 // lane layout of one wavefront = one robot.  lane = 16*leg + k:
 //   k 0,1      motor rows of the leg's HFE / KFE
-//   k 2..4     knee sphere (model sphere 8+leg): normal, tangent x, tangent y
-//   k 5..7     foot sphere (model sphere 12+leg)
-//   k 8..10    base sphere 2*leg          k 11..13  base sphere 2*leg+1
+//   k 2+3j..4+3j  model sphere 4*leg+j (j = 0..3): normal, tangent x, tangent y.  Spheres 4l and
+//              4l+1 ride on leg l (knee, foot), 4l+2 and 4l+3 on the base.  Model sphere order ==
+//              ascending lane order, so "the touching spheres in solve order" is simply the set
+//              bits of the touching-lanes ballot, lowest first.
 //   k 14,15    idle
 enum RowType : int32_t { ROW_IDLE = 0, ROW_MOTOR = 1, ROW_NORMAL = 2, ROW_TAN1 = 3, ROW_TAN2 = 4 };
 enum BodyKind : int32_t { BODY_BASE = 0, BODY_UPPER = 1, BODY_LOWER = 2 };
@@ -27,9 +28,7 @@ constexpr int kRowsPerLeg = 14;
 constexpr int kNumRowSlots = 4 * kRowsPerLeg;  // 56 live row slots (A-matrix columns)
 __host__ __device__ constexpr int slot_of_lane(int lane) { return (lane >> 4) * kRowsPerLeg + (lane & 15); }
 __host__ __device__ constexpr int motor_lane(int dof) { return 16 * (dof >> 1) + (dof & 1); }
-__host__ __device__ constexpr int sphere_lane(int s) {
-  return s < 8 ? 16 * (s >> 1) + 8 + 3 * (s & 1) : (s < 12 ? 16 * (s - 8) + 2 : 16 * (s - 12) + 5);
-}
+__host__ __device__ constexpr int sphere_lane(int s) { return 16 * (s >> 2) + 2 + 3 * (s & 3); }
 
 template <typename T>
 struct LegConst {
@@ -95,6 +94,9 @@ struct KBuffers {
   double* stats;      // [8]
   int32_t num_envs;
   uint32_t flags;
+#ifdef SOLO_STAMPS
+  unsigned long long* stamps;  // [N][16] s_memtime stamps, DIAGNOSTIC builds only (make stamps)
+#endif
 };
 
 // ---- host side: SoloConfig + SoloModel -> KParams ---------------------------------------
@@ -110,12 +112,13 @@ inline int validate_model(const SoloModel& m, std::string* err) {
   for (int a = 0; a < 3; ++a)
     if (m.com[0][a] != 0.0) return fail("base frame must be the base CoM frame");
   if (m.num_spheres != SOLO_MAX_SPHERES) return fail("expected 16 collision spheres");
-  for (int s = 0; s < 8; ++s)
-    if (m.sphere_body[s] != 0) return fail("spheres 0..7 must be attached to the base");
-  for (int leg = 0; leg < 4; ++leg)
-    for (int s : {8 + leg, 12 + leg})
+  for (int leg = 0; leg < 4; ++leg) {
+    for (int s : {4 * leg, 4 * leg + 1})
       if (m.sphere_body[s] != 1 + 2 * leg && m.sphere_body[s] != 2 + 2 * leg)
-        return fail("spheres 8+l / 12+l must be attached to leg l");
+        return fail("spheres 4l and 4l+1 must be attached to leg l");
+    for (int s : {4 * leg + 2, 4 * leg + 3})
+      if (m.sphere_body[s] != 0) return fail("spheres 4l+2 and 4l+3 must be attached to the base");
+  }
   return SOLO_OK;
 }
 

@@ -26,10 +26,21 @@
 // No MFMA: there is no dense contraction here (14 dofs, <= 56 rows per robot).
 //
 // The including translation unit must provide solo::lane_id/block_id/wave_sync/wave_readlane/
-// wave_shfl_xor/wave_ballot/Real<T>/stats_add (solo_wave_ops.h on the GPU).
+// wave_sum_legs/wave_sum_group16/wave_ballot/Real<T>/stats_add (solo_wave_ops.h on the GPU).
 #pragma once
 
 #include "solo_kernel_params.h"
+
+// In-kernel phase stamps exist only in the diagnostic build (make -C gym_solo_amd/csrc stamps);
+// in the product build the macro expands to nothing.
+#ifdef SOLO_STAMPS
+#define SOLO_STAMP(B, i)                                                                          \
+  do {                                                                                            \
+    if (solo::lane_id() == 0) (B).stamps[(size_t)solo::block_id() * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define SOLO_STAMP(B, i) do {} while (0)
+#endif
 
 namespace solo {
 
@@ -62,18 +73,8 @@ template <typename T> __device__ __forceinline__ void rot_inertia_y(T c, T s, co
   o[4] = cs * (I[2] - I[0]) + (cc - ss) * I[4];
   o[5] = c * I[5] - s * I[3];
 }
-template <typename T> __device__ __forceinline__ T sum_over_legs(T x) {
-  x += wave_shfl_xor(x, 16);
-  x += wave_shfl_xor(x, 32);
-  return x;
-}
-template <typename T> __device__ __forceinline__ T sum_over_group16(T x) {
-  x += wave_shfl_xor(x, 1);
-  x += wave_shfl_xor(x, 2);
-  x += wave_shfl_xor(x, 4);
-  x += wave_shfl_xor(x, 8);
-  return x;
-}
+template <typename T> __device__ __forceinline__ T sum_over_legs(T x) { return wave_sum_legs(x); }
+template <typename T> __device__ __forceinline__ T sum_over_group16(T x) { return wave_sum_group16(x); }
 
 // Euler angles of pybullet.getEulerFromQuaternion ([recalled] pybullet.c; call sites
 // gym_solo/core/obs.py:271, rewards.py:233,265; known answer test_obs_observations.py:67-88)
@@ -117,82 +118,42 @@ __device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
 //     cand = clamp(v)                (v_med3_f32, every lane, only lane r matters)
 //     sl[r] = readlane(cand, r)      (v_readlane_b32)
 //     v    = t + An[r] * sl[r]       (v_fma_f32)
-// LANE is the compile-time lane that owns the row.
-template <typename T, int LANE>
-__device__ __forceinline__ void pgs_row_box(T& v, T lo, T hi, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
-  const T a = An[slot_of_lane(LANE)];
-  const T t = Real<T>::fma(-a, sl[slot_of_lane(LANE)], v);
-  sl[slot_of_lane(LANE)] = wave_readlane(Real<T>::clamp(v, lo, hi), LANE);
-  v = Real<T>::fma(a, sl[slot_of_lane(LANE)], t);
+// `lane_r` is the lane that owns the row (compile-time for motors, an SGPR for contacts); SLOT is
+// the compile-time register slot of the row in An / sl.
+template <typename T, int SLOT>
+__device__ __forceinline__ void pgs_row(T& v, T lo, T hi, int lane_r, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
+  const T a = An[SLOT];
+  const T t = Real<T>::fma(-a, sl[SLOT], v);
+  sl[SLOT] = wave_readlane(Real<T>::clamp(v, lo, hi), lane_r);
+  v = Real<T>::fma(a, sl[SLOT], t);
 }
-// one touching sphere: normal row at lane BASE, tangents at BASE+1, BASE+2 (friction pyramid
-// with the limit mu * lam_n of the freshly updated normal impulse)
-template <typename T, int BASE>
-__device__ __forceinline__ void pgs_contact(T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
-  pgs_row_box<T, BASE>(v, T(0), Real<T>::big(), sl, An);
-  const T lim = mu * sl[slot_of_lane(BASE)];
-  pgs_row_box<T, BASE + 1>(v, -lim, lim, sl, An);
-  pgs_row_box<T, BASE + 2>(v, -lim, lim, sl, An);
-}
-
-// An[slot(R)] = -(ghat_me.ghat_R + [same leg] hhat_me.hhat_R) / A_me,me   (0 on the diagonal)
-template <typename T, int R>
-__device__ __forceinline__ void build_a_entry(T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T neg_inv_d, int lane) {
-  const T* rv = rowvec[R];
+// An[SLOT] = -(ghat_me.ghat_r + [same leg] hhat_me.hhat_r) / A_me,me   (0 on the diagonal)
+template <typename T, int SLOT>
+__device__ __forceinline__ void build_a_entry(T (&An)[kNumRowSlots], const T (*rowvec)[8], int lane_r, const T* gh, const T* hh, T neg_inv_d, int lane) {
+  const T* rv = rowvec[lane_r];
   const T a = gh[0] * rv[0] + gh[1] * rv[1] + gh[2] * rv[2] + gh[3] * rv[3] + gh[4] * rv[4] + gh[5] * rv[5];
   const T b = hh[0] * rv[6] + hh[1] * rv[7];
-  const T full = ((lane >> 4) == (R >> 4)) ? (a + b) : a;
-  An[slot_of_lane(R)] = (lane == R) ? T(0) : full * neg_inv_d;
-}
-template <typename T, int R>
-__device__ __forceinline__ T pick_lambda(T lam, const T (&sl)[kNumRowSlots], int lane) {
-  return (lane == R) ? sl[slot_of_lane(R)] : lam;
+  const T full = ((lane >> 4) == (lane_r >> 4)) ? (a + b) : a;
+  An[SLOT] = (lane == lane_r) ? T(0) : full * neg_inv_d;
+  wave_sched_fence();  // keep the next entry's LDS reads below this one: bounds the live registers
 }
 
-template <typename T, int S>
-struct ForSpheres {
-  static __device__ __forceinline__ void build(unsigned long long mask, T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
-    constexpr int B = sphere_lane(S);
-    if ((mask >> B) & 1ull) {
-      build_a_entry<T, B>(An, rowvec, gh, hh, nid, lane);
-      build_a_entry<T, B + 1>(An, rowvec, gh, hh, nid, lane);
-      build_a_entry<T, B + 2>(An, rowvec, gh, hh, nid, lane);
-    }
-    ForSpheres<T, S + 1>::build(mask, An, rowvec, gh, hh, nid, lane);
-  }
-  static __device__ __forceinline__ void solve(unsigned long long mask, T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
-    constexpr int B = sphere_lane(S);
-    if ((mask >> B) & 1ull) pgs_contact<T, B>(v, mu, sl, An);
-    ForSpheres<T, S + 1>::solve(mask, v, mu, sl, An);
-  }
-  static __device__ __forceinline__ T gather(unsigned long long mask, T lam, const T (&sl)[kNumRowSlots], int lane) {
-    constexpr int B = sphere_lane(S);
-    if ((mask >> B) & 1ull) {
-      lam = pick_lambda<T, B>(lam, sl, lane);
-      lam = pick_lambda<T, B + 1>(lam, sl, lane);
-      lam = pick_lambda<T, B + 2>(lam, sl, lane);
-    }
-    return ForSpheres<T, S + 1>::gather(mask, lam, sl, lane);
-  }
-};
-template <typename T>
-struct ForSpheres<T, SOLO_MAX_SPHERES> {
-  static __device__ __forceinline__ void build(unsigned long long, T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, T, int) {}
-  static __device__ __forceinline__ void solve(unsigned long long, T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
-  static __device__ __forceinline__ T gather(unsigned long long, T lam, const T (&)[kNumRowSlots], int) { return lam; }
-};
+// Register slots: 0..7 = motor rows (dof order), 8+3c+q = row q of the c-th TOUCHING sphere (in
+// model sphere order).  Only touching spheres get slots, so the solver loop never visits - or
+// branches around - a sphere that is in the air (a skipped branch costs ~20 cycles of a
+// latency-bound wave).  cl[c] = lane of the normal row of the c-th touching sphere.
 template <typename T, int D>
 struct ForMotors {
   static __device__ __forceinline__ void build(T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
-    build_a_entry<T, motor_lane(D)>(An, rowvec, gh, hh, nid, lane);
+    build_a_entry<T, D>(An, rowvec, motor_lane(D), gh, hh, nid, lane);
     ForMotors<T, D + 1>::build(An, rowvec, gh, hh, nid, lane);
   }
   static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
-    pgs_row_box<T, motor_lane(D)>(v, -imp, imp, sl, An);
+    pgs_row<T, D>(v, -imp, imp, motor_lane(D), sl, An);
     ForMotors<T, D + 1>::solve(v, imp, sl, An);
   }
   static __device__ __forceinline__ T gather(T lam, const T (&sl)[kNumRowSlots], int lane) {
-    return ForMotors<T, D + 1>::gather(pick_lambda<T, motor_lane(D)>(lam, sl, lane), sl, lane);
+    return ForMotors<T, D + 1>::gather((lane == motor_lane(D)) ? sl[D] : lam, sl, lane);
   }
 };
 template <typename T>
@@ -201,14 +162,63 @@ struct ForMotors<T, SOLO_NUM_DOF> {
   static __device__ __forceinline__ void solve(T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
   static __device__ __forceinline__ T gather(T lam, const T (&)[kNumRowSlots], int) { return lam; }
 };
+template <typename T, int C>
+struct ForContacts {
+  static constexpr int S0 = SOLO_NUM_DOF + 3 * C;
+  static __device__ __forceinline__ void build(int nc, const int (&cl)[SOLO_MAX_SPHERES], T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
+    if (C >= nc) return;
+    build_a_entry<T, S0>(An, rowvec, cl[C], gh, hh, nid, lane);
+    build_a_entry<T, S0 + 1>(An, rowvec, cl[C] + 1, gh, hh, nid, lane);
+    build_a_entry<T, S0 + 2>(An, rowvec, cl[C] + 2, gh, hh, nid, lane);
+    ForContacts<T, C + 1>::build(nc, cl, An, rowvec, gh, hh, nid, lane);
+  }
+  // normal row, then the two friction rows limited by mu * (fresh normal impulse)
+  static __device__ __forceinline__ void solve(int nc, const int (&cl)[SOLO_MAX_SPHERES], T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
+    if (C >= nc) return;
+    pgs_row<T, S0>(v, T(0), Real<T>::big(), cl[C], sl, An);
+    const T lim = mu * sl[S0];
+    pgs_row<T, S0 + 1>(v, -lim, lim, cl[C] + 1, sl, An);
+    pgs_row<T, S0 + 2>(v, -lim, lim, cl[C] + 2, sl, An);
+    ForContacts<T, C + 1>::solve(nc, cl, v, mu, sl, An);
+  }
+  static __device__ __forceinline__ T gather(int nc, const int (&cl)[SOLO_MAX_SPHERES], T lam, const T (&sl)[kNumRowSlots], int lane) {
+    if (C >= nc) return lam;
+    lam = (lane == cl[C]) ? sl[S0] : lam;
+    lam = (lane == cl[C] + 1) ? sl[S0 + 1] : lam;
+    lam = (lane == cl[C] + 2) ? sl[S0 + 2] : lam;
+    return ForContacts<T, C + 1>::gather(nc, cl, lam, sl, lane);
+  }
+};
+template <typename T>
+struct ForContacts<T, SOLO_MAX_SPHERES> {
+  static __device__ __forceinline__ void build(int, const int (&)[SOLO_MAX_SPHERES], T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, T, int) {}
+  static __device__ __forceinline__ void solve(int, const int (&)[SOLO_MAX_SPHERES], T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
+  static __device__ __forceinline__ T gather(int, const int (&)[SOLO_MAX_SPHERES], T lam, const T (&)[kNumRowSlots], int) { return lam; }
+};
+// touching spheres in solve order -> lanes of their normal rows: the set bits of the ballot,
+// lowest first (wave-uniform scalar code: s_ff1 / s_bitset per touching sphere)
+template <int C>
+struct CompactSpheres {
+  static __device__ __forceinline__ void run(unsigned long long m, int& nc, int (&cl)[SOLO_MAX_SPHERES]) {
+    if (m == 0ull) return;
+    cl[C] = __builtin_ctzll(m);
+    nc = C + 1;
+    CompactSpheres<C + 1>::run(m & (m - 1ull), nc, cl);
+  }
+};
+template <>
+struct CompactSpheres<SOLO_MAX_SPHERES> {
+  static __device__ __forceinline__ void run(unsigned long long, int&, int (&)[SOLO_MAX_SPHERES]) {}
+};
 
 // ------------------------------------------------------------------------------------------
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
 // constraint impulse; physics_finish writes s_state (new).
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, const T* s_state, const T* s_tgt,
-                                           T (*s_rowvec)[8], T* s_keep, T (*s_leg)[20], T mu, T mass_scale, int lane) {
+__device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, const KBuffers<T>& B, const LegConst<T>& L,
+                                           const RowConst<T>& rc, const T* s_state, const T* s_tgt, T (*s_rowvec)[8],
+                                           T* s_keep, T (*s_leg)[20], T mu, T mass_scale, int lane) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = P->dt;
@@ -228,7 +238,6 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   const V3<T> nb = {r20, r21, r22};  // world z (ground normal) in base coordinates
 
   // ---- leg-local kinematics (each 16-lane group works on its own leg) -----------------------
-  const LegConst<T>& L = P->leg[leg];
   const T q1 = s_state[SOLO_S_Q + 2 * leg], q2 = s_state[SOLO_S_Q + 2 * leg + 1];
   const T qd1 = s_state[SOLO_S_QD + 2 * leg], qd2 = s_state[SOLO_S_QD + 2 * leg + 1];
   T s1, c1, s12, c12;
@@ -243,6 +252,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   rot_inertia_y(c12, s12, L.IL, IL);
   const T mU = L.mU, mL = L.mL;
 
+  SOLO_STAMP(B, 2);
   // ---- joint-space inertia blocks of the leg (composite-rigid-body, closed form) -----------
   const V3<T> rU1 = cU - o1, rL1 = cL - o1, rL2 = cL - o2;
   const V3<T> tU1 = ycross(rU1), tL1 = ycross(rL1), tL2 = ycross(rL2);
@@ -268,6 +278,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     K1[i] = (W1[i] - L21 * K2[i]) * iL11;
   }
 
+  SOLO_STAMP(B, 3);
   // ---- bias forces of the leg: Newton-Euler with classical accelerations in the frame that
   //      coincides with the base at this instant (gravity + Bullet-style damping included) ----
   const V3<T> yh = {T(0), T(1), T(0)};
@@ -297,6 +308,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   const T e1 = h1 * iL11, e2 = (h2 - L21 * e1) * iL22;
   const T y2 = e2 * iL22, y1 = (e1 - L21 * y2) * iL11;
 
+  SOLO_STAMP(B, 4);
   // ---- base level: Schur complement S and right-hand side, summed over the four legs -------
   // leg composite about the base origin
   const T mleg = mU + mL;
@@ -335,6 +347,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     rhs[0] -= N0.x; rhs[1] -= N0.y; rhs[2] -= N0.z;
     rhs[3] -= F0.x; rhs[4] -= F0.y; rhs[5] -= F0.z;
   }
+  SOLO_STAMP(B, 5);
   // Cholesky S = C C^T (C lower, stored in S; iC = 1/diag)
   T iC[6];
 #pragma unroll
@@ -375,8 +388,8 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
              vb.x + dt * xb[3], vb.y + dt * xb[4], vb.z + dt * xb[5]};
   T us1 = qd1 + dt * (-y1 - kx1), us2 = qd2 + dt * (-y2 - kx2);
 
+  SOLO_STAMP(B, 6);
   // ---- constraint rows: one per lane --------------------------------------------------------
-  const RowConst<T>& rc = P->row[lane];
   const int type = rc.type;
   const bool is_motor = type == ROW_MOTOR, is_contact = type >= ROW_NORMAL;
   V3<T> cb = {rc.center[0], rc.center[1], rc.center[2]};
@@ -459,26 +472,34 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   }
   wave_sync();
 
+  SOLO_STAMP(B, 7);
   // ---- scaled Delassus row of this lane, then projected Gauss-Seidel --------------------------
+  int nc = 0;
+  int cl[SOLO_MAX_SPHERES];
+#pragma unroll
+  for (int i = 0; i < SOLO_MAX_SPHERES; ++i) cl[i] = 0;
+  CompactSpheres<0>::run(touching, nc, cl);
   T An[kNumRowSlots];
 #pragma unroll
   for (int i = 0; i < kNumRowSlots; ++i) An[i] = T(0);
   const T nid = -inv_d;
   ForMotors<T, 0>::build(An, s_rowvec, gh, hh, nid, lane);
-  ForSpheres<T, 0>::build(touching, An, s_rowvec, gh, hh, nid, lane);
+  ForContacts<T, 0>::build(nc, cl, An, s_rowvec, gh, hh, nid, lane);
   T sl[kNumRowSlots];  // impulses: wave-uniform -> scalar registers
 #pragma unroll
   for (int i = 0; i < kNumRowSlots; ++i) sl[i] = T(0);
   T v = w * nid;       // lam = 0
+  SOLO_STAMP(B, 8);
   const T imp = P->motor_impulse;
   const int iters = P->iterations;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     ForMotors<T, 0>::solve(v, imp, sl, An);
-    ForSpheres<T, 0>::solve(touching, v, mu, sl, An);
+    ForContacts<T, 0>::solve(nc, cl, v, mu, sl, An);
   }
+  SOLO_STAMP(B, 9);
   T lam = ForMotors<T, 0>::gather(T(0), sl, lane);
-  lam = ForSpheres<T, 0>::gather(touching, lam, sl, lane);
+  lam = ForContacts<T, 0>::gather(nc, cl, lam, sl, lane);
   return lam;
 }
 
@@ -564,15 +585,22 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_leg[4][20];
   __shared__ T s_src[48];
   __shared__ T s_stack[8];
+  __shared__ RewardInstrK<T> s_rprog[SOLO_MAX_REWARD_OPS];
 
   const int lane = lane_id();
   const int env = block_id();
   if (env >= B.num_envs) return;
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
+  SOLO_STAMP(B, 0);
   // episodic statistics are sharded over SOLO_STATS_SHARDS rows: all robots of a batch finish
   // their episodes in the same step, and same-address atomics serialise at ~12 ns each
   double* stats = B.stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH;
 
+  // Issue every global load of the step up front, so that their latencies overlap instead of
+  // being paid one after the other behind the LDS hand-offs below.
+  const LegConst<T>& L = P->leg[lane >> 4];
+  const RowConst<T>& rc = P->row[lane];
+  if ((B.flags & SOLO_STEP_REWARD) && lane < SOLO_MAX_REWARD_OPS) s_rprog[lane] = P->reward[lane];
   if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.state[rec + lane];
   if (lane < SOLO_NUM_JOINTS) {
     T t;
@@ -589,9 +617,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   const T mass_scale = B.params[(size_t)env * 4 + 1];
   wave_sync();
 
+  SOLO_STAMP(B, 1);
   bool diverged = false;
   if (B.flags & SOLO_STEP_PHYSICS) {
-    const T lam = physics_solve<T>(P, s_state, s_tgt, s_rowvec, s_keep, s_leg, mu, mass_scale, lane);
+    const T lam = physics_solve<T>(P, B, L, rc, s_state, s_tgt, s_rowvec, s_keep, s_leg, mu, mass_scale, lane);
     physics_finish<T>(P, s_state, s_rowvec, s_keep, s_leg, lam, lane);
     // a robot whose state went non-finite is restored from its snapshot and counted
     const bool bad = lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31]);
@@ -603,6 +632,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     }
   }
 
+  SOLO_STAMP(B, 10);
   // ---- source vector for the observation program (see include/solo_engine.h) ---------------
   const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
   T roll, pitch, yaw;
@@ -631,12 +661,13 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     }
   }
 
+  SOLO_STAMP(B, 11);
   // ---- reward: postfix program, evaluated redundantly by every lane (wave-uniform) -----------
   T reward = T(0);
   if (B.flags & SOLO_STEP_REWARD) {
     int sp = 0;
     for (int i = 0; i < P->num_reward_ops; ++i) {
-      const RewardInstrK<T>& in = P->reward[i];
+      const RewardInstrK<T> in = s_rprog[i];
       const T gs = P->gauss_scale;
       switch (in.op) {
         case SOLO_R_CONST: s_stack[sp++] = in.a; break;
@@ -671,6 +702,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     if (lane == 0) B.reward[env] = reward;
   }
 
+  SOLO_STAMP(B, 12);
   // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83)
   bool done = false;
   if (B.flags & SOLO_STEP_DONE) {
@@ -714,7 +746,9 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
       for (int t = 0; t < SOLO_MAX_TERMS; ++t) B.term_count[(size_t)env * SOLO_MAX_TERMS + t] = cnt[t];
     }
   }
+  SOLO_STAMP(B, 13);
   if (lane < SOLO_STATE_STRIDE) B.state[rec + lane] = s_state[lane];
+  SOLO_STAMP(B, 14);
 }
 
 // setJointMotorControlArray without a step (solo8v2vanilla.py:87-90)

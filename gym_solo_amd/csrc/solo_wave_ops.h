@@ -14,6 +14,8 @@ __device__ __forceinline__ int block_id() { return blockIdx.x; }
 
 // Orders this wave's LDS writes before the following LDS reads of other lanes.
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// compiler scheduling fence (no instruction): instructions are not moved across it
+__device__ __forceinline__ void wave_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ float wave_readlane(float x, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
@@ -24,8 +26,50 @@ __device__ __forceinline__ double wave_readlane(double x, int lane) {
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ float wave_shfl_xor(float x, int mask) { return __shfl_xor(x, mask, 64); }
-__device__ __forceinline__ double wave_shfl_xor(double x, int mask) { return __shfl_xor(x, mask, 64); }
+// ---- cross-lane sums without LDS traffic ---------------------------------------------------
+// v_permlane16_swap / v_permlane32_swap (new on gfx950) exchange odd<->even 16-lane rows and
+// the two 32-lane halves inside the VALU; DPP row rotations fold into the v_add itself.
+__device__ __forceinline__ unsigned swap_rows16_add_helper(unsigned u, unsigned* other) {
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  *other = r[1];
+  return r[0];
+}
+// x[lane] + x[lane^16] + x[lane^32] + x[lane^48]: sum over the four 16-lane leg groups
+__device__ __forceinline__ float wave_sum_legs(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ double wave_sum_legs(double x) {
+  unsigned lo = (unsigned)(__double_as_longlong(x) & 0xffffffffll), hi = (unsigned)(__double_as_longlong(x) >> 32);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double s = __longlong_as_double(((long long)a[0] & 0xffffffffll) | ((long long)b[0] << 32)) +
+                   __longlong_as_double(((long long)a[1] & 0xffffffffll) | ((long long)b[1] << 32));
+  lo = (unsigned)(__double_as_longlong(s) & 0xffffffffll); hi = (unsigned)(__double_as_longlong(s) >> 32);
+  auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)c[0] & 0xffffffffll) | ((long long)d[0] << 32)) +
+         __longlong_as_double(((long long)c[1] & 0xffffffffll) | ((long long)d[1] << 32));
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 16 lanes of the caller's row, result in every lane (row_ror 8,4,2,1 all-reduce)
+template <typename T> __device__ __forceinline__ T wave_sum_group16(T x) {
+  x += dpp_mov<0x128>(x);
+  x += dpp_mov<0x124>(x);
+  x += dpp_mov<0x122>(x);
+  x += dpp_mov<0x121>(x);
+  return x;
+}
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 
 template <typename T> struct Real;

@@ -13,7 +13,8 @@ import numpy as np
 
 from gym_solo_amd import abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libsolo_hip.so')
+_LIB_PATH = os.environ.get('SOLO_HIP_LIB') or os.path.join(
+  os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libsolo_hip.so')
 
 
 class EngineError(RuntimeError):

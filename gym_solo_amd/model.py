@@ -159,26 +159,26 @@ class Solo8Model:
         put6(m.inertia[b], li.inertia)
       m.dof_to_joint[ju] = DOF_TO_JOINT[ju]
       m.dof_to_joint[jl] = DOF_TO_JOINT[jl]
-    # spheres: 0-7 base corners, 8-11 knees (lower-leg origin), 12-15 feet
+    # spheres, 4 per leg l (model order = contact solve order): 4l knee (lower-leg origin),
+    # 4l+1 foot, 4l+2 / 4l+3 the two base-box corners (bottom, top) next to that leg's hip
     hx, hy, hz = self.base_sphere_half_extents
-    s = 0
-    for sx in (1, -1):
-      for sy in (1, -1):
-        for sz in (-1, 1):
-          m.sphere_body[s] = 0
-          for a, v in enumerate((sx * hx, sy * hy, sz * hz)):
-            m.sphere_center[s][a] = v
-          m.sphere_radius[s] = self.base_sphere_radius
-          s += 1
     for leg in range(abi.NUM_LEGS):
-      m.sphere_body[8 + leg] = 2 + 2 * leg
+      sx, sy = self.leg_signs(leg)
+      k, f = 4 * leg, 4 * leg + 1
+      m.sphere_body[k] = 2 + 2 * leg
       for a in range(3):
-        m.sphere_center[8 + leg][a] = 0.0
-      m.sphere_radius[8 + leg] = self.knee_radius
-      m.sphere_body[12 + leg] = 2 + 2 * leg
+        m.sphere_center[k][a] = 0.0
+      m.sphere_radius[k] = self.knee_radius
+      m.sphere_body[f] = 2 + 2 * leg
       for a in range(3):
-        m.sphere_center[12 + leg][a] = self.ankle_origin(leg)[a]
-      m.sphere_radius[12 + leg] = self.foot_radius
+        m.sphere_center[f][a] = self.ankle_origin(leg)[a]
+      m.sphere_radius[f] = self.foot_radius
+      for q, sz in enumerate((-1, 1)):
+        b = 4 * leg + 2 + q
+        m.sphere_body[b] = 0
+        for a, v in enumerate((sx * hx, sy * hy, sz * hz)):
+          m.sphere_center[b][a] = v
+        m.sphere_radius[b] = self.base_sphere_radius
     m.num_spheres = 16
     return m
 

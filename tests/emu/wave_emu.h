@@ -120,6 +120,7 @@ class WaveEmu {
 inline int lane_id() { return WaveEmu::get().lane(); }
 inline int block_id() { return blockIdx.x; }
 inline void wave_sync() { WaveEmu::get().yield(); }
+inline void wave_sched_fence() {}
 
 inline float wave_readlane(float x, int lane) {
   uint32_t b; std::memcpy(&b, &x, 4);
@@ -131,8 +132,19 @@ inline double wave_readlane(double x, int lane) {
   b = WaveEmu::get().exchange(b, lane);
   std::memcpy(&x, &b, 8); return x;
 }
-inline float wave_shfl_xor(float x, int mask) { return wave_readlane(x, lane_id() ^ mask); }
-inline double wave_shfl_xor(double x, int mask) { return wave_readlane(x, lane_id() ^ mask); }
+template <typename T> inline T emu_shfl_xor(T x, int mask) { return wave_readlane(x, lane_id() ^ mask); }
+template <typename T> inline T wave_sum_legs(T x) {
+  x += emu_shfl_xor(x, 16);
+  x += emu_shfl_xor(x, 32);
+  return x;
+}
+template <typename T> inline T wave_sum_group16(T x) {
+  x += emu_shfl_xor(x, 8);
+  x += emu_shfl_xor(x, 4);
+  x += emu_shfl_xor(x, 2);
+  x += emu_shfl_xor(x, 1);
+  return x;
+}
 inline unsigned long long wave_ballot(bool p) {
   WaveEmu& e = WaveEmu::get();
   e.post(p ? 1 : 0);

@@ -133,7 +133,7 @@ def test_standing_height_and_static_force_balance():
   st = ph.initial_state(1)
   st[0, abi.S_POS + 2] = 0.32 + model.foot_radius
   centers = ph.sphere_centers(st[0])
-  np.testing.assert_allclose(centers[12:, 2], model.foot_radius, atol=1e-12)
+  np.testing.assert_allclose(centers[1::4, 2], model.foot_radius, atol=1e-12)  # feet = spheres 4l+1
   for _ in range(1500):
     ph.step(st, np.zeros((1, 12)))
   dbg = ph.step_debug(st[0].copy(), np.zeros(8))

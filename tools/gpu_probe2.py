@@ -19,3 +19,18 @@ for dtype, tdt in (('float32', torch.float32),):
       z = eng.state[:, 2].mean().item()
       print(f'{dtype} N={n} iters={iters}: {ms*1e3:.1f} us/launch  mean base z {z:.3f}', flush=True)
       eng.close()
+# average number of touching spheres per robot in the benchmark regime (CPU oracle FK on a sample)
+from oracle import solo_oracle as so
+ca, ma = make_abi('float32')
+eng = Engine(ca, ma, 4096)
+g = torch.Generator(device='cuda').manual_seed(1234)
+acts = (torch.rand(300, 4096, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
+eng.rollout(acts, abi.STEP_PHYSICS)
+st = eng.state.cpu().numpy().astype(np.float64)
+ph = so.OraclePhysics(ca, ma)
+rad = np.array(list(ma.sphere_radius))
+cnt = []
+for e in range(512):
+  c = ph.sphere_centers(st[e])
+  cnt.append(int(((c[:, 2] - rad) < ca.contact_margin).sum()))
+print('touching spheres per robot: mean %.2f  max %d  hist %s' % (np.mean(cnt), max(cnt), np.bincount(cnt).tolist()), flush=True)

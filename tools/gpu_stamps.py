@@ -1,0 +1,28 @@
+"""DIAGNOSTIC: per-phase cycle shares of the step kernel from in-kernel s_memtime stamps
+(libsolo_hip_stamps.so; never quote this build's run time, only its shares)."""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ['SOLO_HIP_LIB'] = os.path.join(ROOT, 'gym_solo_amd', 'csrc', 'libsolo_hip_stamps.so')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch
+from gym_solo_amd import abi
+from bench import build_env
+names = ['loads+sync', 'kinematics', 'crba', 'rne bias', 'schur+sum', 'chol+solve', 'rows', 'A build', 'PGS', 'gather+finish', 'euler+obs', 'reward', 'done', 'store']
+for n in (256, 4096):
+  env = build_env(n, 0, 'float32')
+  eng = env.engine
+  g = torch.Generator(device='cuda').manual_seed(1234)
+  acts = (torch.rand(64, n, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
+  eng.rollout(acts, abi.STEP_ALL)
+  eng.step(acts[0], abi.STEP_ALL)
+  buf = np.zeros((n, 16), dtype=np.uint64)
+  eng.lib.solo_engine_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
+  d = np.diff(buf[:, :15].astype(np.int64), axis=1)
+  med = np.median(d, axis=0)
+  tot = np.median(buf[:, 14].astype(np.int64) - buf[:, 0].astype(np.int64))
+  span = (buf[:, 14].max() - buf[:, 0].min())
+  print(f'N={n}: median wave lifetime {tot} ticks, whole-grid span {span} ticks')
+  for k, nm in enumerate(names):
+    print(f'   {nm:14s} {med[k]:9.0f}  {100*med[k]/tot:5.1f}%')
+  env._close()
