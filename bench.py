@@ -45,6 +45,19 @@ def build_env(num_envs, device, dtype, max_steps=1000):
   return env
 
 
+def host_cores():
+  """Cores this process may actually use: the GPU box exposes 256 logical CPUs but gives a
+  1-GPU job a 16-CPU share (cgroup quota), and oversubscribed OpenMP threads crawl."""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+    if quota != 'max':
+      n = min(n, max(1, int(int(quota) / int(period))))
+  except Exception:  # noqa: BLE001
+    pass
+  return max(1, min(n, int(os.environ.get('SOLO_CPU_BASELINE_THREADS', '16'))))
+
+
 def cpu_baseline(num_envs, seconds_target=12.0):
   """The CPU oracle (double-precision scalar C restatement + numpy reductions) on the host
   cores, bounded sample of the same workload.  kind = "port": PyBullet itself is not
@@ -55,7 +68,7 @@ def cpu_baseline(num_envs, seconds_target=12.0):
   from helpers import make_abi
   from oracle import solo_oracle as so
   import env_cases
-  cores = os.cpu_count() or 1
+  cores = host_cores()
   tmp = tempfile.mkdtemp(prefix='solo_oracle_native_')
   lib_path = os.path.join(tmp, 'libsolo_oracle_native.so')
   try:
@@ -104,6 +117,7 @@ def main():
   import torch
   import torch.distributed as dist
   from gym_solo_amd import abi
+  from gym_solo_amd.distributed import all_reduce_stats, rank_seed, summarize
 
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -124,7 +138,7 @@ def main():
   tdtype = torch.float32 if args.dtype == 'float32' else torch.float64
   env = build_env(n, local_rank, args.dtype)
   eng = env.engine
-  gen = torch.Generator(device='cuda:%d' % local_rank).manual_seed(1234 + rank)
+  gen = torch.Generator(device='cuda:%d' % local_rank).manual_seed(rank_seed(1234, rank))
   two_pi = 2 * 3.141592653589793
 
   def action_pool(steps):
@@ -143,9 +157,8 @@ def main():
   barrier()
   t0 = time.perf_counter()
   eng.rollout(acts, abi.STEP_ALL)
-  stats = eng.stats - stats_before
-  if distributed:
-    dist.all_reduce(stats)  # episodic-return statistics over xGMI
+  # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI
+  stats = all_reduce_stats(eng.stats - stats_before)
   barrier()
   elapsed = time.perf_counter() - t0
   t = torch.tensor([elapsed], dtype=torch.float64, device='cuda:%d' % local_rank)
@@ -187,8 +200,7 @@ def main():
                            '%.0e flop/env-step -> %.3f of the %.1f TFLOP/s f32 vector peak'
                            % (FLOP_PER_ENV_STEP_EST, FLOP_PER_ENV_STEP_EST * n / (kern_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                               FP32_VECTOR_PEAK_TFLOPS)},
-      'episodes': {'count': float(st[2]), 'mean_return': float(st[0] / st[2]) if st[2] else None,
-                   'mean_length': float(st[3] / st[2]) if st[2] else None, 'diverged': float(st[5])},
+      'episodes': summarize(st),
       'env_api_env_steps_per_s_rank0': api_rate,
     }
     if world == 1 and not args.no_cpu_baseline:
