@@ -9,8 +9,9 @@ One process per GPU.  A "step" is one pass of the whole hot path over one batch 
 per GPU (BASELINE.json configs[1]): fresh random actions -> action
 de-normalisation -> POSITION_CONTROL motors -> articulated forward dynamics -> ground contact PGS
 -> integration -> TorsoIMU+MotorEncoder observations (21 floats) -> the examples' stand reward
--> TimeBasedTermination(1000) with auto-reset; ONE fused kernel launch per step through the
-C-ABI (solo_engine_rollout).  The action pool is generated on the device before the timed
+-> TimeBasedTermination(1000) with auto-reset, all in ONE fused kernel through the C-ABI
+(solo_engine_rollout: open-loop, --steps-per-launch consecutive steps of each robot per launch,
+the batch cut into --rollout-streams independent launch chains).  The action pool is generated on the device before the timed
 region.  The env batch is sharded over ranks with no data-path collective; the only
 communication is one RCCL all-reduce of the 8-double episodic-return statistics vector at the
 end of the interval (inside the timed region).
@@ -33,12 +34,13 @@ FLOP_PER_ENV_STEP_EST = 3.0e5                           # SURVEY.md §8d estimat
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
 
-def build_env(num_envs, device, dtype, max_steps=1000):
+def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1):
   import numpy as np
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
   cfg = Solo8VanillaConfig()
   cfg.num_envs, cfg.device, cfg.dtype, cfg.auto_reset = num_envs, device, dtype, True
+  cfg.steps_per_launch, cfg.rollout_streams = steps_per_launch, rollout_streams
   env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
   register_benchmark_workload(env, max_steps=max_steps)
   env._ensure_program()
@@ -112,6 +114,13 @@ def main():
   ap.add_argument('--envs-per-gpu', type=int, default=4096)
   ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--steps-per-launch', type=int, default=100,
+                  help='env steps of every robot fused into one kernel launch by the open-loop rollout '
+                       '(1 = one launch per step, the closed-loop granularity)')
+  ap.add_argument('--rollout-streams', type=int, default=2,
+                  help='batch slices advancing as independent launch chains on separate HIP streams')
+  ap.add_argument('--api-rate', action='store_true',
+                  help='also time Solo8VanillaEnv.step() in a python loop (one launch per step)')
   args = ap.parse_args()
 
   import torch
@@ -136,7 +145,8 @@ def main():
 
   n, k, w = args.envs_per_gpu, args.steps, args.warmup
   tdtype = torch.float32 if args.dtype == 'float32' else torch.float64
-  env = build_env(n, local_rank, args.dtype)
+  spl, streams = max(1, args.steps_per_launch), max(1, args.rollout_streams)
+  env = build_env(n, local_rank, args.dtype, steps_per_launch=spl, rollout_streams=streams)
   eng = env.engine
   gen = torch.Generator(device='cuda:%d' % local_rank).manual_seed(rank_seed(1234, rank))
   two_pi = 2 * 3.141592653589793
@@ -166,22 +176,26 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   elapsed = float(t.item())
 
-  # dominant kernel: HIP-event timing on the launch stream, same workload
-  reps = min(k, 200)
-  kern_ms = eng.time_step(acts[0], abi.STEP_ALL, reps=reps)
-  # API-level rate through Solo8VanillaEnv.step (python loop, zero-copy outputs)
-  api_steps = min(k, 200)
-  torch.cuda.synchronize(local_rank)
-  ta = time.perf_counter()
-  for i in range(api_steps):
-    env.step(acts[i])
-  torch.cuda.synchronize(local_rank)
-  api_rate = n * api_steps / (time.perf_counter() - ta)
+  # dominant kernel: HIP events on the stream its launches are issued on, same rollout path and
+  # workload (fresh actions every step); one launch = (n / streams) robots x spl steps
+  reps = max(1, min(k, 300) // spl)
+  kern_ms = eng.time_step(acts[:reps * spl], abi.STEP_ALL)
+  api_rate = None
+  if args.api_rate:  # API-level rate through Solo8VanillaEnv.step (python loop, zero-copy outputs)
+    api_steps = min(k, 200)
+    torch.cuda.synchronize(local_rank)
+    ta = time.perf_counter()
+    for i in range(api_steps):
+      env.step(acts[i])
+    torch.cuda.synchronize(local_rank)
+    api_rate = n * api_steps / (time.perf_counter() - ta)
 
   st = stats.cpu().numpy()
   if rank == 0:
     value = world * n * k / elapsed
-    bytes_per_launch = BYTES_PER_ENV_STEP[args.dtype] * n
+    robots_per_launch = n // streams if (streams > 1 and n >= 2 * streams and k > 1) else n
+    env_steps_per_launch = robots_per_launch * spl
+    bytes_per_launch = BYTES_PER_ENV_STEP[args.dtype] * env_steps_per_launch
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     line = {
       'metric': 'env-steps/s (whole node), 4096 Solo8 envs/GPU', 'value': value, 'unit': 'env-steps/s',
@@ -191,14 +205,16 @@ def main():
       'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
                              'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
                              'TimeBasedTermination(1000)+auto-reset, dt=1e-3, 50 PGS iterations' % n,
-                 'envs_per_gpu': n, 'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
+                 'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': streams, 'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_traffic(args.dtype),
                    'kernel': eng.kernel_name, 'kernel_ms': kern_ms,
-                   'algorithmic_bytes_per_launch': bytes_per_launch,
+                   'algorithmic_bytes_per_launch': bytes_per_launch, 'env_steps_per_launch': env_steps_per_launch,
+                   'concurrent_launch_chains': n // robots_per_launch,
+                   'achieved_all_chains': achieved * (n // robots_per_launch),
                    'note': 'latency/VALU-bound by construction (SURVEY.md §8d); secondary bound: est. '
                            '%.0e flop/env-step -> %.3f of the %.1f TFLOP/s f32 vector peak'
-                           % (FLOP_PER_ENV_STEP_EST, FLOP_PER_ENV_STEP_EST * n / (kern_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                           % (FLOP_PER_ENV_STEP_EST, FLOP_PER_ENV_STEP_EST * env_steps_per_launch / (kern_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                               FP32_VECTOR_PEAK_TFLOPS)},
       'episodes': summarize(st),
       'env_api_env_steps_per_s_rank0': api_rate,

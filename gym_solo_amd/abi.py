@@ -88,6 +88,8 @@ class SoloConfig(C.Structure):
     ('settle_targets', C.c_double * NUM_JOINTS),
     ('action_scale', C.c_double),
     ('auto_reset', C.c_int32),
+    ('steps_per_launch', C.c_int32),
+    ('rollout_streams', C.c_int32),
     ('reserved', C.c_int32),
   ]
 
@@ -156,6 +158,8 @@ ENTRY_POINTS = {
   'solo_engine_set_targets': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
   'solo_engine_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
   'solo_engine_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]),
+  'solo_engine_rollout_record': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
   'solo_engine_get_view': (C.c_int, [C.c_void_p, C.POINTER(SoloStateView)]),
   'solo_engine_set_params': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
   'solo_engine_kernel_name': (C.c_char_p, [C.c_void_p]),

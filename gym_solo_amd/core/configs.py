@@ -53,6 +53,8 @@ class Solo8BaseConfig:
   contact_margin: float = 0.005
   settle_steps: int = 500         # gym_solo/envs/solo8v2vanilla.py:130
   auto_reset: bool = False
+  steps_per_launch: int = 1       # rollouts fuse this many env steps per kernel launch
+  rollout_streams: int = 1        # rollouts advance this many batch slices on separate HIP streams
 
   @property
   def urdf(self):
@@ -105,4 +107,6 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
       c.settle_targets[j] = float(starting_joint_pos[name])
   c.action_scale = float(config.max_motor_rotation) if normalize_actions else 1.0
   c.auto_reset = 1 if config.auto_reset else 0
+  c.steps_per_launch = max(1, int(getattr(config, 'steps_per_launch', 1)))
+  c.rollout_streams = max(1, int(getattr(config, 'rollout_streams', 1)))
   return c

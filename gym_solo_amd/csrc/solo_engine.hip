@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,7 +24,7 @@ struct EngineBase {
   virtual int settle(hipStream_t s) = 0;
   virtual int set_targets(const void* a, hipStream_t s) = 0;
   virtual int step(const void* a, uint32_t flags, hipStream_t s) = 0;
-  virtual int rollout(const void* a, int k, uint32_t flags, hipStream_t s) = 0;
+  virtual int rollout(const void* a, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out, hipStream_t s) = 0;
   virtual int view(SoloStateView* v) = 0;
   virtual int set_params(int which, const void* p, hipStream_t s) = 0;
   virtual int time_step(const void* a, uint32_t flags, int reps, hipStream_t s, double* ms) = 0;
@@ -61,6 +62,11 @@ struct Engine final : EngineBase {
 
   ~Engine() override {
     (void)hipSetDevice(device);
+    for (int g = 0; g < kMaxStreams; ++g) {
+      if (sub[g]) (void)hipStreamDestroy(sub[g]);
+      if (ev_join[g]) (void)hipEventDestroy(ev_join[g]);
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : {(void*)dparams, (void*)state, (void*)snapshot, (void*)targets, (void*)params,
                     (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
                     (void*)term_count, (void*)stats})
@@ -69,6 +75,7 @@ struct Engine final : EngineBase {
 
   int init(const SoloConfig& c, const SoloModel& m, int num_envs, int dev) {
     cfg = c; model = m; n = num_envs; device = dev;
+    rollout_streams = cfg.rollout_streams < 1 ? 1 : (cfg.rollout_streams > kMaxStreams ? kMaxStreams : cfg.rollout_streams);
     HIP_TRY(hipSetDevice(device));
     solo::pack_params<T>(cfg, model, &hparams);
     const size_t ns = (size_t)n * SOLO_STATE_STRIDE;
@@ -111,7 +118,8 @@ struct Engine final : EngineBase {
     solo::KBuffers<T> b;
     b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
     b.params = params; b.obs = obs; b.reward = reward; b.done = done; b.term_count = term_count;
-    b.stats = stats; b.num_envs = n; b.flags = flags;
+    b.stats = stats; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
+    b.action_stride = b.obs_stride = b.reward_stride = b.done_stride = 0;
 #ifdef SOLO_STAMPS
     b.stamps = stamps;
 #endif
@@ -119,10 +127,8 @@ struct Engine final : EngineBase {
   }
 
   int launch(const T* actions, uint32_t flags, hipStream_t s) {
-    // one 64-lane workgroup (= one wavefront) per robot
-    hipLaunchKernelGGL(solo::solo_step_kernel<T>, dim3(n), dim3(64), 0, s, dparams, buffers(actions, flags));
-    HIP_TRY(hipGetLastError());
-    return SOLO_OK;
+    // one 64-lane workgroup (= one wavefront) per robot, one env step
+    return launch_chain(actions, 0, 1, flags, nullptr, nullptr, nullptr, s, 0, n);
   }
 
   int settle(hipStream_t s) override {
@@ -134,8 +140,8 @@ struct Engine final : EngineBase {
     HIP_TRY(hipGetLastError());
     // the snapshot doubles as the divergence fallback during the settle loop itself
     HIP_TRY(hipMemcpyAsync(snapshot, state, (size_t)total * sizeof(T), hipMemcpyDeviceToDevice, s));
-    for (int i = 0; i < cfg.settle_steps; ++i)
-      if (int rc = launch(settle_actions, SOLO_STEP_PHYSICS, s)) return rc;
+    // the settle loop repeats one action: action stride 0 inside the fused launches
+    if (int rc = launch_chain(settle_actions, 0, cfg.settle_steps, SOLO_STEP_PHYSICS, nullptr, nullptr, nullptr, s, 0, n)) return rc;
     HIP_TRY(hipMemcpyAsync(snapshot, state, (size_t)total * sizeof(T), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemsetAsync(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t), s));
     HIP_TRY(hipMemsetAsync(stats, 0, kStatsBytes, s));
@@ -194,13 +200,87 @@ struct Engine final : EngineBase {
     return launch((const T*)a, flags, s);
   }
 
-  int rollout(const void* a, int k, uint32_t flags, hipStream_t s) override {
+  int spl() const { return cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1; }
+
+  // one chain of launches covering steps [0, k) for robots [lo, lo+count)
+  int launch_chain(const T* act, long long act_stride, int k, uint32_t flags, T* obs_out, T* reward_out,
+                   uint8_t* done_out, hipStream_t s, int lo, int count) {
+    const int S = spl();
+    for (int i = 0; i < k; i += S) {
+      solo::KBuffers<T> b = buffers(act ? act + (size_t)i * act_stride : nullptr, flags);
+      b.env_base = lo;
+      b.steps = (k - i < S) ? (k - i) : S;
+      b.action_stride = act_stride;
+      if (obs_out) { b.obs = obs_out + (size_t)i * n * obs_dim; b.obs_stride = (long long)n * obs_dim; }
+      if (reward_out) { b.reward = reward_out + (size_t)i * n; b.reward_stride = n; }
+      if (done_out) { b.done = done_out + (size_t)i * n; b.done_stride = n; }
+      // stepSimulation-only calls (settle loop, client.stepSimulation()) run the physics-only
+      // instantiation: no obs / reward / termination code, and a separate name in profiles
+      if (flags == SOLO_STEP_PHYSICS)
+        hipLaunchKernelGGL((solo::solo_step_kernel<T, false>), dim3(count), dim3(64), 0, s, dparams, b);
+      else
+        hipLaunchKernelGGL((solo::solo_step_kernel<T, true>), dim3(count), dim3(64), 0, s, dparams, b);
+      HIP_TRY(hipGetLastError());
+    }
+    return SOLO_OK;
+  }
+
+  int rollout(const void* a, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out, hipStream_t s) override {
     if (int rc = check_flags(flags)) return rc;
     if (!a || k < 0) { err = "rollout needs actions [K][N][12]"; return SOLO_ERR_INVALID_ARG; }
+    return rollout_impl((const T*)a, k, flags, obs_out, reward_out, done_out, s, nullptr, nullptr);
+  }
+
+  // t0 / t1 (optional): timing events recorded on the stream slice 0's kernels are launched on
+  int rollout_impl(const T* act, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out,
+                   hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     HIP_TRY(hipSetDevice(device));
-    const T* act = (const T*)a;
-    for (int i = 0; i < k; ++i)
-      if (int rc = launch(act + (size_t)i * n * SOLO_NUM_JOINTS, flags, s)) return rc;
+    const long long stride = act ? (long long)n * SOLO_NUM_JOINTS : 0;
+    T* oo = (flags & SOLO_STEP_OBS) ? (T*)obs_out : nullptr;
+    T* ro = (flags & SOLO_STEP_REWARD) ? (T*)reward_out : nullptr;
+    uint8_t* dn = (flags & SOLO_STEP_DONE) ? (uint8_t*)done_out : nullptr;
+    const int groups = (rollout_streams > 1 && n >= 2 * rollout_streams && k > 1) ? rollout_streams : 1;
+    if (groups == 1) {
+      if (t0) HIP_TRY(hipEventRecord(t0, s));
+      if (int rc = launch_chain(act, stride, k, flags, oo, ro, dn, s, 0, n)) return rc;
+      if (t1) HIP_TRY(hipEventRecord(t1, s));
+      return SOLO_OK;
+    }
+    // Robots are independent, so the batch can be cut into `groups` slices that advance through
+    // the K steps as independent launch chains on their own HIP streams: one slice's kernel
+    // boundary / tail overlaps the other slices' work.  Fork from and join into the caller's stream.
+    if (int rc = ensure_streams(groups)) return rc;
+    HIP_TRY(hipEventRecord(ev_fork, s));
+    for (int g = 0; g < groups; ++g) HIP_TRY(hipStreamWaitEvent(sub[g], ev_fork, 0));
+    if (t0) HIP_TRY(hipEventRecord(t0, sub[0]));
+    const int S = spl();
+    for (int i = 0; i < k; i += S)
+      for (int g = 0; g < groups; ++g) {
+        const int lo = (int)((long long)n * g / groups), hi = (int)((long long)n * (g + 1) / groups);
+        const int kk = (k - i < S) ? (k - i) : S;
+        if (int rc = launch_chain(act ? act + (size_t)i * stride : nullptr, stride, kk, flags,
+                                  oo ? oo + (size_t)i * n * obs_dim : nullptr, ro ? ro + (size_t)i * n : nullptr,
+                                  dn ? dn + (size_t)i * n : nullptr, sub[g], lo, hi - lo))
+          return rc;
+      }
+    if (t1) HIP_TRY(hipEventRecord(t1, sub[0]));
+    for (int g = 0; g < groups; ++g) {
+      HIP_TRY(hipEventRecord(ev_join[g], sub[g]));
+      HIP_TRY(hipStreamWaitEvent(s, ev_join[g], 0));
+    }
+    return SOLO_OK;
+  }
+
+  static constexpr int kMaxStreams = 8;
+  int rollout_streams = 1;
+  hipStream_t sub[kMaxStreams] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {};
+  int ensure_streams(int groups) {
+    if (!ev_fork) HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    for (int g = 0; g < groups; ++g) {
+      if (!sub[g]) HIP_TRY(hipStreamCreateWithFlags(&sub[g], hipStreamNonBlocking));
+      if (!ev_join[g]) HIP_TRY(hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming));
+    }
     return SOLO_OK;
   }
 
@@ -211,11 +291,9 @@ struct Engine final : EngineBase {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i)
-      if (int rc = launch((const T*)a, flags, s)) return rc;
-    HIP_TRY(hipEventRecord(e1, s));
+    if (int rc = rollout_impl((const T*)a, reps * spl(), flags, nullptr, nullptr, nullptr, s, e0, e1)) return rc;
     HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipStreamSynchronize(s));
     float t = 0;
     HIP_TRY(hipEventElapsedTime(&t, e0, e1));
     (void)hipEventDestroy(e0);
@@ -241,7 +319,7 @@ struct Engine final : EngineBase {
     return SOLO_OK;
   }
 
-  const char* kernel_name() override { return sizeof(T) == 4 ? "solo_step_kernel<float>" : "solo_step_kernel<double>"; }
+  const char* kernel_name() override { return sizeof(T) == 4 ? "solo_step_kernel<float, true>" : "solo_step_kernel<double, true>"; }
 };
 
 int check_config(const SoloConfig* c, std::string* err) {
@@ -251,6 +329,7 @@ int check_config(const SoloConfig* c, std::string* err) {
   if (!(c->dt > 0)) return fail("dt must be positive");
   if (c->solver_iterations < 1 || c->solver_iterations > 10000) return fail("solver_iterations out of range");
   if (c->settle_steps < 0 || c->settle_steps > 100000) return fail("settle_steps out of range");
+  if (c->steps_per_launch < 0 || c->steps_per_launch > 100000) return fail("steps_per_launch out of range");
   if (c->restitution != 0.0) return fail("only restitution 0 is supported (gym_solo configs.py:23)");
   if (!(c->action_scale > 0)) return fail("action_scale must be positive");
   if (c->lateral_friction < 0 || c->contact_margin < 0 || c->contact_erp < 0) return fail("negative contact parameter");
@@ -327,7 +406,13 @@ int solo_engine_reset(SoloEngine* eng, const uint8_t* mask_dev, void* stream) { 
 int solo_engine_settle(SoloEngine* eng, void* stream) { return ENG_CALL(settle((hipStream_t)stream)); }
 int solo_engine_set_targets(SoloEngine* eng, const void* a, void* stream) { return ENG_CALL(set_targets(a, (hipStream_t)stream)); }
 int solo_engine_step(SoloEngine* eng, const void* a, uint32_t flags, void* stream) { return ENG_CALL(step(a, flags, (hipStream_t)stream)); }
-int solo_engine_rollout(SoloEngine* eng, const void* a, int32_t k, uint32_t flags, void* stream) { return ENG_CALL(rollout(a, k, flags, (hipStream_t)stream)); }
+int solo_engine_rollout(SoloEngine* eng, const void* a, int32_t k, uint32_t flags, void* stream) {
+  return ENG_CALL(rollout(a, k, flags, nullptr, nullptr, nullptr, (hipStream_t)stream));
+}
+int solo_engine_rollout_record(SoloEngine* eng, const void* a, int32_t k, uint32_t flags, void* obs_out, void* reward_out,
+                               void* done_out, void* stream) {
+  return ENG_CALL(rollout(a, k, flags, obs_out, reward_out, done_out, (hipStream_t)stream));
+}
 int solo_engine_get_view(SoloEngine* eng, SoloStateView* out) {
   if (!out) return SOLO_ERR_INVALID_ARG;
   return ENG_CALL(view(out));

@@ -36,7 +36,7 @@
 #ifdef SOLO_STAMPS
 #define SOLO_STAMP(B, i)                                                                          \
   do {                                                                                            \
-    if (solo::lane_id() == 0) (B).stamps[(size_t)solo::block_id() * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (solo::lane_id() == 0) (B).stamps[(size_t)(solo::block_id() + (B).env_base) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define SOLO_STAMP(B, i) do {} while (0)
@@ -127,16 +127,45 @@ __device__ __forceinline__ void pgs_row(T& v, T lo, T hi, int lane_r, T (&sl)[kN
   sl[SLOT] = wave_readlane(Real<T>::clamp(v, lo, hi), lane_r);
   v = Real<T>::fma(a, sl[SLOT], t);
 }
-// An[SLOT] = -(ghat_me.ghat_r + [same leg] hhat_me.hhat_r) / A_me,me   (0 on the diagonal)
-template <typename T, int SLOT>
-__device__ __forceinline__ void build_a_entry(T (&An)[kNumRowSlots], const T (*rowvec)[8], int lane_r, const T* gh, const T* hh, T neg_inv_d, int lane) {
+// -(ghat_me.ghat_r + [same leg] hhat_me.hhat_r) / A_me,me   (0 on the diagonal): the entry of
+// this lane's scaled Delassus row for the row owned by lane_r.  `me` = own whitened row (regs),
+// the other row is a wave-uniform LDS broadcast.
+template <typename T>
+__device__ __forceinline__ T delassus_entry(const T (*rowvec)[8], int lane_r, const T* gh, const T* hh, T neg_inv_d, int lane) {
   const T* rv = rowvec[lane_r];
   const T a = gh[0] * rv[0] + gh[1] * rv[1] + gh[2] * rv[2] + gh[3] * rv[3] + gh[4] * rv[4] + gh[5] * rv[5];
   const T b = hh[0] * rv[6] + hh[1] * rv[7];
   const T full = ((lane >> 4) == (lane_r >> 4)) ? (a + b) : a;
-  An[SLOT] = (lane == lane_r) ? T(0) : full * neg_inv_d;
-  wave_sched_fence();  // keep the next entry's LDS reads below this one: bounds the live registers
+  return (lane == lane_r) ? T(0) : full * neg_inv_d;
 }
+// writes the three entries of touching sphere c into its compile-time register slots; c is
+// wave-uniform, so this is a scalar jump, not divergence
+template <typename T, int C>
+struct StoreContactEntries {
+  static __device__ __forceinline__ void run(int c, T (&An)[kNumRowSlots], T e0, T e1, T e2) {
+    if (c == C) {
+      An[SOLO_NUM_DOF + 3 * C] = e0;
+      An[SOLO_NUM_DOF + 3 * C + 1] = e1;
+      An[SOLO_NUM_DOF + 3 * C + 2] = e2;
+    } else {
+      StoreContactEntries<T, C + 1>::run(c, An, e0, e1, e2);
+    }
+  }
+};
+template <typename T>
+struct StoreContactEntries<T, kMaxContacts> {
+  static __device__ __forceinline__ void run(int, T (&)[kNumRowSlots], T, T, T) {}
+};
+template <int C>
+struct PickLane {
+  static __device__ __forceinline__ int run(int c, const int (&cl)[kMaxContacts]) {
+    return c == C ? cl[C] : PickLane<C + 1>::run(c, cl);
+  }
+};
+template <>
+struct PickLane<kMaxContacts> {
+  static __device__ __forceinline__ int run(int, const int (&)[kMaxContacts]) { return 0; }
+};
 
 // Register slots: 0..7 = motor rows (dof order), 8+3c+q = row q of the c-th TOUCHING sphere (in
 // model sphere order).  Only touching spheres get slots, so the solver loop never visits - or
@@ -145,7 +174,9 @@ __device__ __forceinline__ void build_a_entry(T (&An)[kNumRowSlots], const T (*r
 template <typename T, int D>
 struct ForMotors {
   static __device__ __forceinline__ void build(T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
-    build_a_entry<T, D>(An, rowvec, motor_lane(D), gh, hh, nid, lane);
+    // pinned: the entry is computed HERE, next to its two LDS row reads (otherwise the arithmetic
+    // sinks to the solver loop while all 16 row reads (64 VGPRs) stay up front and spill)
+    An[D] = wave_pin(delassus_entry<T>(rowvec, motor_lane(D), gh, hh, nid, lane));
     ForMotors<T, D + 1>::build(An, rowvec, gh, hh, nid, lane);
   }
   static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
@@ -165,15 +196,8 @@ struct ForMotors<T, SOLO_NUM_DOF> {
 template <typename T, int C>
 struct ForContacts {
   static constexpr int S0 = SOLO_NUM_DOF + 3 * C;
-  static __device__ __forceinline__ void build(int nc, const int (&cl)[SOLO_MAX_SPHERES], T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
-    if (C >= nc) return;
-    build_a_entry<T, S0>(An, rowvec, cl[C], gh, hh, nid, lane);
-    build_a_entry<T, S0 + 1>(An, rowvec, cl[C] + 1, gh, hh, nid, lane);
-    build_a_entry<T, S0 + 2>(An, rowvec, cl[C] + 2, gh, hh, nid, lane);
-    ForContacts<T, C + 1>::build(nc, cl, An, rowvec, gh, hh, nid, lane);
-  }
   // normal row, then the two friction rows limited by mu * (fresh normal impulse)
-  static __device__ __forceinline__ void solve(int nc, const int (&cl)[SOLO_MAX_SPHERES], T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
+  static __device__ __forceinline__ void solve(int nc, const int (&cl)[kMaxContacts], T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
     if (C >= nc) return;
     pgs_row<T, S0>(v, T(0), Real<T>::big(), cl[C], sl, An);
     const T lim = mu * sl[S0];
@@ -181,7 +205,7 @@ struct ForContacts {
     pgs_row<T, S0 + 2>(v, -lim, lim, cl[C] + 2, sl, An);
     ForContacts<T, C + 1>::solve(nc, cl, v, mu, sl, An);
   }
-  static __device__ __forceinline__ T gather(int nc, const int (&cl)[SOLO_MAX_SPHERES], T lam, const T (&sl)[kNumRowSlots], int lane) {
+  static __device__ __forceinline__ T gather(int nc, const int (&cl)[kMaxContacts], T lam, const T (&sl)[kNumRowSlots], int lane) {
     if (C >= nc) return lam;
     lam = (lane == cl[C]) ? sl[S0] : lam;
     lam = (lane == cl[C] + 1) ? sl[S0 + 1] : lam;
@@ -190,16 +214,15 @@ struct ForContacts {
   }
 };
 template <typename T>
-struct ForContacts<T, SOLO_MAX_SPHERES> {
-  static __device__ __forceinline__ void build(int, const int (&)[SOLO_MAX_SPHERES], T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, T, int) {}
-  static __device__ __forceinline__ void solve(int, const int (&)[SOLO_MAX_SPHERES], T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
-  static __device__ __forceinline__ T gather(int, const int (&)[SOLO_MAX_SPHERES], T lam, const T (&)[kNumRowSlots], int) { return lam; }
+struct ForContacts<T, kMaxContacts> {
+  static __device__ __forceinline__ void solve(int, const int (&)[kMaxContacts], T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
+  static __device__ __forceinline__ T gather(int, const int (&)[kMaxContacts], T lam, const T (&)[kNumRowSlots], int) { return lam; }
 };
 // touching spheres in solve order -> lanes of their normal rows: the set bits of the ballot,
 // lowest first (wave-uniform scalar code: s_ff1 / s_bitset per touching sphere)
 template <int C>
 struct CompactSpheres {
-  static __device__ __forceinline__ void run(unsigned long long m, int& nc, int (&cl)[SOLO_MAX_SPHERES]) {
+  static __device__ __forceinline__ void run(unsigned long long m, int& nc, int (&cl)[kMaxContacts]) {
     if (m == 0ull) return;
     cl[C] = __builtin_ctzll(m);
     nc = C + 1;
@@ -207,8 +230,8 @@ struct CompactSpheres {
   }
 };
 template <>
-struct CompactSpheres<SOLO_MAX_SPHERES> {
-  static __device__ __forceinline__ void run(unsigned long long, int&, int (&)[SOLO_MAX_SPHERES]) {}
+struct CompactSpheres<kMaxContacts> {
+  static __device__ __forceinline__ void run(unsigned long long, int&, int (&)[kMaxContacts]) {}
 };
 
 // ------------------------------------------------------------------------------------------
@@ -384,9 +407,30 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
 #pragma unroll
   for (int i = 0; i < 6; ++i) { kx1 += K1[i] * xb[i]; kx2 += K2[i] * xb[i]; }
   // velocities after the unconstrained update (semi-implicit Euler)
-  T ub[6] = {om.x + dt * xb[0], om.y + dt * xb[1], om.z + dt * xb[2],
+  const T ub[6] = {om.x + dt * xb[0], om.y + dt * xb[1], om.z + dt * xb[2],
              vb.x + dt * xb[3], vb.y + dt * xb[4], vb.z + dt * xb[5]};
-  T us1 = qd1 + dt * (-y1 - kx1), us2 = qd2 + dt * (-y2 - kx2);
+  const T us1 = qd1 + dt * (-y1 - kx1), us2 = qd2 + dt * (-y2 - kx2);
+
+  // Park the factors and the unconstrained velocities in LDS NOW: the row phase below and the
+  // post-solve phase read them back from there (wave-uniform / per-leg broadcasts), so that
+  // ~45 values stop occupying VGPRs while the rows and the Delassus matrix are built and the
+  // Gauss-Seidel loop keeps only its Delassus row live (128 VGPRs -> 4 waves/SIMD in f32).
+  if (lane == 0) {
+    int o = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) s_keep[o++] = S[i][j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { s_keep[15 + i] = iC[i]; s_keep[21 + i] = ub[i]; }
+  }
+  if (k == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { s_leg[leg][i] = K1[i]; s_leg[leg][6 + i] = K2[i]; }
+    s_leg[leg][12] = iL11; s_leg[leg][13] = L21; s_leg[leg][14] = iL22;
+    s_leg[leg][15] = us1; s_leg[leg][16] = us2; s_leg[leg][17] = q1; s_leg[leg][18] = q2;
+  }
+  wave_sync();
 
   SOLO_STAMP(B, 6);
   // ---- constraint rows: one per lane --------------------------------------------------------
@@ -415,27 +459,27 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     const int jt = 3 * leg + k;  // pybullet joint index of this dof
     jl1 = (k == 0) ? T(1) : T(0);
     jl2 = (k == 1) ? T(1) : T(0);
-    const T qj = (k == 0) ? q1 : q2, uj = (k == 0) ? us1 : us2;
+    const T qj = s_leg[leg][17 + k], uj = s_leg[leg][15 + k];
     bias = P->kp_over_dt * (s_tgt[jt] - qj) + P->one_minus_kd * uj;
   }
   T gh[6], hh[2];
   {
     T g[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) g[i] = jb[i] - K1[i] * jl1 - K2[i] * jl2;
+    for (int i = 0; i < 6; ++i) g[i] = jb[i] - s_leg[leg][i] * jl1 - s_leg[leg][6 + i] * jl2;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       T s = g[i];
 #pragma unroll
-      for (int m = 0; m < i; ++m) s -= S[i][m] * gh[m];
-      gh[i] = s * iC[i];
+      for (int m = 0; m < i; ++m) s -= s_keep[i * (i - 1) / 2 + m] * gh[m];
+      gh[i] = s * s_keep[15 + i];
     }
-    hh[0] = jl1 * iL11;
-    hh[1] = (jl2 - L21 * hh[0]) * iL22;
+    hh[0] = jl1 * s_leg[leg][12];
+    hh[1] = (jl2 - s_leg[leg][13] * hh[0]) * s_leg[leg][14];
   }
-  T w = jl1 * us1 + jl2 * us2 - bias;
+  T w = jl1 * s_leg[leg][15] + jl2 * s_leg[leg][16] - bias;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) w += jb[i] * ub[i];
+  for (int i = 0; i < 6; ++i) w += jb[i] * s_keep[21 + i];
   T diag = hh[0] * hh[0] + hh[1] * hh[1];
 #pragma unroll
   for (int i = 0; i < 6; ++i) diag += gh[i] * gh[i];
@@ -452,46 +496,40 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   s_rowvec[lane][6] = hh[0];
   s_rowvec[lane][7] = hh[1];
   const unsigned long long touching = wave_ballot(live && type == ROW_NORMAL);
-  // Park everything the post-solve phase needs in LDS so that the Gauss-Seidel loop keeps only
-  // the Delassus row (56 VGPRs) + 4 scalars live: 4 waves/SIMD in f32, i.e. all 4096 robots
-  // of a 4096-env batch resident at once on the 1024 SIMDs.
-  if (lane == 0) {
-    int o = 0;
-#pragma unroll
-    for (int i = 1; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j < i; ++j) s_keep[o++] = S[i][j];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { s_keep[15 + i] = iC[i]; s_keep[21 + i] = ub[i]; }
-  }
-  if (k == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { s_leg[leg][i] = K1[i]; s_leg[leg][6 + i] = K2[i]; }
-    s_leg[leg][12] = iL11; s_leg[leg][13] = L21; s_leg[leg][14] = iL22;
-    s_leg[leg][15] = us1; s_leg[leg][16] = us2; s_leg[leg][17] = q1; s_leg[leg][18] = q2;
-  }
   wave_sync();
 
-  SOLO_STAMP(B, 7);
   // ---- scaled Delassus row of this lane, then projected Gauss-Seidel --------------------------
   int nc = 0;
-  int cl[SOLO_MAX_SPHERES];
+  int cl[kMaxContacts];
 #pragma unroll
-  for (int i = 0; i < SOLO_MAX_SPHERES; ++i) cl[i] = 0;
+  for (int i = 0; i < kMaxContacts; ++i) cl[i] = 0;
   CompactSpheres<0>::run(touching, nc, cl);
+  if (__builtin_popcountll(touching) > kMaxContacts && lane == 0)
+    stats_add(&B.stats[(size_t)((block_id() + B.env_base) % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH + 6], 1.0);
   T An[kNumRowSlots];
 #pragma unroll
   for (int i = 0; i < kNumRowSlots; ++i) An[i] = T(0);
   const T nid = -inv_d;
+  // one runtime loop over the touching spheres (a single copy of the LDS reads + dot products);
+  // the results land in compile-time register slots through a scalar switch
+#pragma unroll 1
+  for (int c = 0; c < nc; ++c) {
+    const int lr = PickLane<0>::run(c, cl);
+    const T e0 = wave_pin(delassus_entry<T>(s_rowvec, lr, gh, hh, nid, lane));
+    const T e1 = wave_pin(delassus_entry<T>(s_rowvec, lr + 1, gh, hh, nid, lane));
+    const T e2 = wave_pin(delassus_entry<T>(s_rowvec, lr + 2, gh, hh, nid, lane));
+    StoreContactEntries<T, 0>::run(c, An, e0, e1, e2);
+  }
+  // (motor entries last, right before the solver that consumes them: keeps their rows' LDS
+  // reads from being issued before - and spilled across - the loop above)
   ForMotors<T, 0>::build(An, s_rowvec, gh, hh, nid, lane);
-  ForContacts<T, 0>::build(nc, cl, An, s_rowvec, gh, hh, nid, lane);
   T sl[kNumRowSlots];  // impulses: wave-uniform -> scalar registers
 #pragma unroll
   for (int i = 0; i < kNumRowSlots; ++i) sl[i] = T(0);
   T v = w * nid;       // lam = 0
   SOLO_STAMP(B, 8);
   const T imp = P->motor_impulse;
-  const int iters = P->iterations;
+  const int iters = wave_uniform(P->iterations);  // scalar trip count: keeps the loop (and sl[]) on the SALU side
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     ForMotors<T, 0>::solve(v, imp, sl, An);
@@ -575,8 +613,11 @@ __device__ __forceinline__ void physics_finish(const KParams<T>* __restrict__ P,
 // ------------------------------------------------------------------------------------------
 // __launch_bounds__(64, W): W waves per SIMD -> 512/W VGPRs.  f32: 4 (128 VGPRs, a whole 4096-robot
 // batch resident on the 1024 SIMDs); f64: 2 (the Delassus row alone is 112 VGPRs).
-template <typename T>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(const KParams<T>* __restrict__ P, KBuffers<T> B) {
+// kFull = false: physics-only instantiation (flags are treated as SOLO_STEP_PHYSICS).
+template <typename T, bool kFull>
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(const KParams<T>* __restrict__ Pin, KBuffers<T> Bin) {
+  KBuffers<T> B = Bin;
+  if (!kFull) B.flags = SOLO_STEP_PHYSICS;
   using R = Real<T>;
   __shared__ T s_state[SOLO_STATE_STRIDE];
   __shared__ T s_tgt[16];
@@ -587,8 +628,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_stack[8];
   __shared__ RewardInstrK<T> s_rprog[SOLO_MAX_REWARD_OPS];
 
-  const int lane = lane_id();
-  const int env = block_id();
+  const int lane0 = lane_id();
+  const int env = block_id() + B.env_base;
   if (env >= B.num_envs) return;
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
   SOLO_STAMP(B, 0);
@@ -596,158 +637,171 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   // their episodes in the same step, and same-address atomics serialise at ~12 ns each
   double* stats = B.stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH;
 
-  // Issue every global load of the step up front, so that their latencies overlap instead of
-  // being paid one after the other behind the LDS hand-offs below.
-  const LegConst<T>& L = P->leg[lane >> 4];
-  const RowConst<T>& rc = P->row[lane];
-  if ((B.flags & SOLO_STEP_REWARD) && lane < SOLO_MAX_REWARD_OPS) s_rprog[lane] = P->reward[lane];
-  if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.state[rec + lane];
-  if (lane < SOLO_NUM_JOINTS) {
-    T t;
-    if (B.actions != nullptr) {
-      // action de-normalisation (solo8v2vanilla.py:84-85) + setJointMotorControlArray (:87-90)
-      t = B.actions[(size_t)env * SOLO_NUM_JOINTS + lane] * P->action_scale;
-      B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = t;
-    } else {
-      t = B.targets[(size_t)env * SOLO_NUM_JOINTS + lane];
-    }
-    s_tgt[lane] = t;
-  }
+  const KParams<T>* __restrict__ const P0 = Pin;
+  if ((B.flags & SOLO_STEP_REWARD) && lane0 < SOLO_MAX_REWARD_OPS) s_rprog[lane0] = P0->reward[lane0];
+  if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = B.state[rec + lane0];
   const T mu = B.params[(size_t)env * 4 + 0];
   const T mass_scale = B.params[(size_t)env * 4 + 1];
-  wave_sync();
+  int cnt[SOLO_MAX_TERMS];
+#pragma unroll
+  for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = B.term_count[(size_t)env * SOLO_MAX_TERMS + t];
 
-  SOLO_STAMP(B, 1);
-  bool diverged = false;
-  if (B.flags & SOLO_STEP_PHYSICS) {
-    const T lam = physics_solve<T>(P, B, L, rc, s_state, s_tgt, s_rowvec, s_keep, s_leg, mu, mass_scale, lane);
-    physics_finish<T>(P, s_state, s_rowvec, s_keep, s_leg, lam, lane);
-    // a robot whose state went non-finite is restored from its snapshot and counted
-    const bool bad = lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31]);
-    diverged = wave_ballot(bad) != 0ull;
-    if (diverged) {
-      if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
-      if (lane == 0) stats_add(&stats[5], 1.0);
-      wave_sync();
-    }
-  }
-
-  SOLO_STAMP(B, 10);
-  // ---- source vector for the observation program (see include/solo_engine.h) ---------------
-  const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
-  T roll, pitch, yaw;
-  euler_from_quat<T>(qx, qy, qz, qw, &roll, &pitch, &yaw);
-  if (B.flags & SOLO_STEP_OBS) {
-    if (lane < SOLO_SRC_COUNT) {
-      T v;
-      if (lane < 3) v = lane == 0 ? roll : (lane == 1 ? pitch : yaw);
-      else if (lane < 6) v = s_state[SOLO_S_LINVEL + lane - 3];
-      else if (lane < 9) v = s_state[SOLO_S_ANGVEL + lane - 6];
-      else if (lane < 33) {
-        const int j = (lane - 9) % 12, off = lane < 21 ? SOLO_S_Q : SOLO_S_QD;
-        v = (j % 3 == 2) ? T(0) : s_state[off + 2 * (j / 3) + (j % 3)];
-      } else if (lane < 36) v = s_state[SOLO_S_POS + lane - 33];
-      else if (lane < 40) v = s_state[SOLO_S_QUAT + lane - 36];
-      else v = T(1);
-      s_src[lane] = v;
+  // B.steps consecutive env steps of THIS robot in one launch: the state record stays in LDS,
+  // only actions come in and obs / reward / done go out per step.  Robots are independent, so
+  // no wave ever waits for another one; a launch lasts as long as its slowest robot's SUM over
+  // the steps, which averages out the contact-count imbalance between robots.
+#pragma unroll 1
+  for (int step = 0; step < B.steps; ++step) {
+    // Re-derive the parameter pointer opaquely every step: otherwise the compiler hoists the ~60
+    // per-lane constant loads out of the step loop and keeps them live across it (spills).
+    const KParams<T>* __restrict__ P = wave_opaque(P0);  // NB: values loaded through it that steer
+    // control flow must be re-declared uniform (wave_uniform), or loops turn divergent
+    const int lane = wave_opaque_lane(lane0);  // same reason: per-lane address arithmetic stays in the step
+    const LegConst<T>& L = P->leg[lane >> 4];
+    const RowConst<T>& rc = P->row[lane];
+    if (lane < SOLO_NUM_JOINTS) {
+      T t;
+      if (B.actions != nullptr) {
+        // action de-normalisation (solo8v2vanilla.py:84-85) + setJointMotorControlArray (:87-90)
+        t = B.actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * P->action_scale;
+        if (step == B.steps - 1) B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = t;
+      } else {
+        t = B.targets[(size_t)env * SOLO_NUM_JOINTS + lane];
+      }
+      s_tgt[lane] = t;
     }
     wave_sync();
-    if (lane < P->num_obs) {
-      const ObsElemK<T>& e = P->obs[lane];
-      T v = s_src[e.src] * e.scale;
-      if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
-      if (e.flags & 2) v = (T(2) * (v - e.nlo)) / e.range - T(1);
-      B.obs[(size_t)env * P->num_obs + lane] = v;
-    }
-  }
 
-  SOLO_STAMP(B, 11);
-  // ---- reward: postfix program, evaluated redundantly by every lane (wave-uniform) -----------
-  T reward = T(0);
-  if (B.flags & SOLO_STEP_REWARD) {
-    int sp = 0;
-    for (int i = 0; i < P->num_reward_ops; ++i) {
-      const RewardInstrK<T> in = s_rprog[i];
-      const T gs = P->gauss_scale;
-      switch (in.op) {
-        case SOLO_R_CONST: s_stack[sp++] = in.a; break;
-        case SOLO_R_UPRIGHT: {
-          const T fu = T(-1.5707963267948966);
-          s_stack[sp++] = fu * pitch / (fu * fu);
-        } break;
-        case SOLO_R_FLAT_TORSO:
-          s_stack[sp++] = tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -in.a, in.a, in.b, gs);
-          break;
-        case SOLO_R_TORSO_HEIGHT:
-          s_stack[sp++] = tolerance<T>(s_state[SOLO_S_POS + 2], in.a - in.b, in.a + in.b, in.c, gs);
-          break;
-        case SOLO_R_HORIZ_SPEED: {
-          const T vx = s_state[SOLO_S_LINVEL], vy = s_state[SOLO_S_LINVEL + 1];
-          s_stack[sp++] = tolerance<T>(R::sqrt(vx * vx + vy * vy), in.a - in.b, in.a + in.b, in.c, gs);
-        } break;
-        case SOLO_R_SMALL_CONTROL: {
-          T s = T(0);
-#pragma unroll
-          for (int j = 0; j < SOLO_NUM_DOF; ++j) s += R::abs(s_state[SOLO_S_QD + j]);
-          // mean over all 12 pybullet joints incl. the 4 fixed ones (rewards.py:297-300)
-          s_stack[sp++] = tolerance<T>(s / T(SOLO_NUM_JOINTS), T(0), T(0), in.a, gs);
-        } break;
-        case SOLO_R_SCALE: s_stack[sp - 1] = in.a * s_stack[sp - 1]; break;
-        case SOLO_R_ADD: s_stack[sp - 2] = s_stack[sp - 2] + s_stack[sp - 1]; --sp; break;
-        case SOLO_R_MUL: s_stack[sp - 2] = s_stack[sp - 2] * s_stack[sp - 1]; --sp; break;
-        default: break;
+    SOLO_STAMP(B, 1);
+    bool diverged = false;
+    if (B.flags & SOLO_STEP_PHYSICS) {
+      const T lam = physics_solve<T>(P, B, L, rc, s_state, s_tgt, s_rowvec, s_keep, s_leg, mu, mass_scale, lane);
+      physics_finish<T>(P, s_state, s_rowvec, s_keep, s_leg, lam, lane);
+      // a robot whose state went non-finite is restored from its snapshot and counted
+      const bool bad = lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31]);
+      diverged = wave_ballot(bad) != 0ull;
+      if (diverged) {
+        if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
+        if (lane == 0) stats_add(&stats[5], 1.0);
+        wave_sync();
       }
     }
-    reward = s_stack[0];
-    if (lane == 0) B.reward[env] = reward;
-  }
 
-  SOLO_STAMP(B, 12);
-  // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83)
-  bool done = false;
-  if (B.flags & SOLO_STEP_DONE) {
-    int cnt[SOLO_MAX_TERMS];
+    SOLO_STAMP(B, 10);
+    // ---- source vector for the observation program (see include/solo_engine.h) -------------
+    const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
+    T roll, pitch, yaw;
+    euler_from_quat<T>(qx, qy, qz, qw, &roll, &pitch, &yaw);
+    if (B.flags & SOLO_STEP_OBS) {
+      if (lane < SOLO_SRC_COUNT) {
+        T v;
+        if (lane < 3) v = lane == 0 ? roll : (lane == 1 ? pitch : yaw);
+        else if (lane < 6) v = s_state[SOLO_S_LINVEL + lane - 3];
+        else if (lane < 9) v = s_state[SOLO_S_ANGVEL + lane - 6];
+        else if (lane < 33) {
+          const int j = (lane - 9) % 12, off = lane < 21 ? SOLO_S_Q : SOLO_S_QD;
+          v = (j % 3 == 2) ? T(0) : s_state[off + 2 * (j / 3) + (j % 3)];
+        } else if (lane < 36) v = s_state[SOLO_S_POS + lane - 33];
+        else if (lane < 40) v = s_state[SOLO_S_QUAT + lane - 36];
+        else v = T(1);
+        s_src[lane] = v;
+      }
+      wave_sync();
+      if (lane < P->num_obs) {
+        const ObsElemK<T>& e = P->obs[lane];
+        T v = s_src[e.src] * e.scale;
+        if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
+        if (e.flags & 2) v = (T(2) * (v - e.nlo)) / e.range - T(1);
+        B.obs[(size_t)step * B.obs_stride + (size_t)env * P->num_obs + lane] = v;
+      }
+    }
+
+    SOLO_STAMP(B, 11);
+    // ---- reward: postfix program, evaluated redundantly by every lane (wave-uniform) ---------
+    T reward = T(0);
+    if (B.flags & SOLO_STEP_REWARD) {
+      int sp = 0;
+      for (int i = 0; i < P->num_reward_ops; ++i) {
+        const RewardInstrK<T> in = s_rprog[i];
+        const T gs = P->gauss_scale;
+        switch (in.op) {
+          case SOLO_R_CONST: s_stack[sp++] = in.a; break;
+          case SOLO_R_UPRIGHT: {
+            const T fu = T(-1.5707963267948966);
+            s_stack[sp++] = fu * pitch / (fu * fu);
+          } break;
+          case SOLO_R_FLAT_TORSO:
+            s_stack[sp++] = tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -in.a, in.a, in.b, gs);
+            break;
+          case SOLO_R_TORSO_HEIGHT:
+            s_stack[sp++] = tolerance<T>(s_state[SOLO_S_POS + 2], in.a - in.b, in.a + in.b, in.c, gs);
+            break;
+          case SOLO_R_HORIZ_SPEED: {
+            const T vx = s_state[SOLO_S_LINVEL], vy = s_state[SOLO_S_LINVEL + 1];
+            s_stack[sp++] = tolerance<T>(R::sqrt(vx * vx + vy * vy), in.a - in.b, in.a + in.b, in.c, gs);
+          } break;
+          case SOLO_R_SMALL_CONTROL: {
+            T sum = T(0);
 #pragma unroll
-    for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = B.term_count[(size_t)env * SOLO_MAX_TERMS + t];
-#pragma unroll
-    for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
-      if (t < P->num_terms && !done) {
-        if (P->term_kind[t] == SOLO_T_TIME) {
-          cnt[t] += 1;
-          done = cnt[t] > P->term_param[t];
-        } else if (P->term_kind[t] == SOLO_T_CONST) {
-          done = P->term_param[t] != 0;
+            for (int j = 0; j < SOLO_NUM_DOF; ++j) sum += R::abs(s_state[SOLO_S_QD + j]);
+            // mean over all 12 pybullet joints incl. the 4 fixed ones (rewards.py:297-300)
+            s_stack[sp++] = tolerance<T>(sum / T(SOLO_NUM_JOINTS), T(0), T(0), in.a, gs);
+          } break;
+          case SOLO_R_SCALE: s_stack[sp - 1] = in.a * s_stack[sp - 1]; break;
+          case SOLO_R_ADD: s_stack[sp - 2] = s_stack[sp - 2] + s_stack[sp - 1]; --sp; break;
+          case SOLO_R_MUL: s_stack[sp - 2] = s_stack[sp - 2] * s_stack[sp - 1]; --sp; break;
+          default: break;
         }
       }
+      reward = s_stack[0];
+      if (lane == 0) B.reward[(size_t)step * B.reward_stride + env] = reward;
     }
-    if (B.flags & SOLO_STEP_REWARD) {
-      // episodic-return bookkeeping kept in the env record (same 128-B line as the state)
-      if (lane == 0) { s_state[SOLO_S_RETURN] += reward; s_state[SOLO_S_EPLEN] += T(1); }
-      wave_sync();
-    }
-    const bool restart = (done || diverged) && P->auto_reset != 0;
-    if (restart) {
-      if (lane == 0 && done) {
-        const double ret = (double)s_state[SOLO_S_RETURN];
-        stats_add(&stats[0], ret);
-        stats_add(&stats[1], ret * ret);
-        stats_add(&stats[2], 1.0);
-        stats_add(&stats[3], (double)s_state[SOLO_S_EPLEN]);
+
+    SOLO_STAMP(B, 12);
+    // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83)
+    if (B.flags & SOLO_STEP_DONE) {
+      bool done = false;
+#pragma unroll
+      for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
+        if (t < P->num_terms && !done) {
+          if (P->term_kind[t] == SOLO_T_TIME) {
+            cnt[t] += 1;
+            done = cnt[t] > P->term_param[t];
+          } else if (P->term_kind[t] == SOLO_T_CONST) {
+            done = P->term_param[t] != 0;
+          }
+        }
       }
-      wave_sync();
-      if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.snapshot[rec + lane];
+      if (B.flags & SOLO_STEP_REWARD) {
+        // episodic-return bookkeeping kept in the env record (same 128-B line as the state)
+        if (lane == 0) { s_state[SOLO_S_RETURN] += reward; s_state[SOLO_S_EPLEN] += T(1); }
+        wave_sync();
+      }
+      const bool restart = (done || diverged) && P->auto_reset != 0;
+      if (restart) {
+        if (lane == 0 && done) {
+          const double ret = (double)s_state[SOLO_S_RETURN];
+          stats_add(&stats[0], ret);
+          stats_add(&stats[1], ret * ret);
+          stats_add(&stats[2], 1.0);
+          stats_add(&stats[3], (double)s_state[SOLO_S_EPLEN]);
+        }
+        wave_sync();
+        if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.snapshot[rec + lane];
 #pragma unroll
-      for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = 0;
-      wave_sync();
+        for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = 0;
+      }
+      if (lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
     }
-    if (lane == 0) {
-      B.done[env] = done ? 1 : 0;
-#pragma unroll
-      for (int t = 0; t < SOLO_MAX_TERMS; ++t) B.term_count[(size_t)env * SOLO_MAX_TERMS + t] = cnt[t];
-    }
+    wave_sync();  // this step's LDS state is complete before the next step reads it
   }
   SOLO_STAMP(B, 13);
-  if (lane < SOLO_STATE_STRIDE) B.state[rec + lane] = s_state[lane];
+  const int lane1 = wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
+  if ((B.flags & SOLO_STEP_DONE) && lane1 == 0) {
+#pragma unroll
+    for (int t = 0; t < SOLO_MAX_TERMS; ++t) B.term_count[(size_t)env * SOLO_MAX_TERMS + t] = cnt[t];
+  }
+  if (lane1 < SOLO_STATE_STRIDE) B.state[rec + lane1] = s_state[lane1];
   SOLO_STAMP(B, 14);
 }
 

@@ -14,6 +14,21 @@ __device__ __forceinline__ int block_id() { return blockIdx.x; }
 
 // Orders this wave's LDS writes before the following LDS reads of other lanes.
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// wave-uniform pointer made opaque to the optimiser (no instruction): loads through the result
+// are not hoisted above this point
+template <typename P> __device__ __forceinline__ P* wave_opaque(P* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+__device__ __forceinline__ int wave_opaque_lane(int lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+// pins a per-lane value: it is materialised at this point of the program (no instruction)
+__device__ __forceinline__ float wave_pin(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double wave_pin(double x) { asm volatile("" : "+v"(x)); return x; }
+// declares an int wave-uniform (v_readfirstlane -> SGPR)
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // compiler scheduling fence (no instruction): instructions are not moved across it
 __device__ __forceinline__ void wave_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

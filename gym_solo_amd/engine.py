@@ -139,16 +139,38 @@ class Engine:
       p = self._dev_ptr(actions, (self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
     self._check(self.lib.solo_engine_step(self._h, p, flags, self._stream()), 'step')
 
-  def rollout(self, actions, flags=abi.STEP_ALL):
+  @property
+  def steps_per_launch(self):
+    return max(1, int(self.cfg.steps_per_launch))
+
+  def rollout(self, actions, flags=abi.STEP_ALL, record=False):
+    """K open-loop env steps with actions [K, N, 12]; ceil(K / steps_per_launch) fused launches.
+    record=True returns every step's (obs [K,N,D], reward [K,N], done [K,N] uint8)."""
+    torch = self._torch
     k = int(actions.shape[0])
     p = self._dev_ptr(actions, (k, self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
-    self._check(self.lib.solo_engine_rollout(self._h, p, k, flags, self._stream()), 'rollout')
+    if not record:
+      self._check(self.lib.solo_engine_rollout(self._h, p, k, flags, self._stream()), 'rollout')
+      return None
+    dev = self.state.device
+    obs = torch.empty(k, self.num_envs, max(self.obs_dim, 1), device=dev, dtype=self.tdtype)
+    rew = torch.empty(k, self.num_envs, device=dev, dtype=self.tdtype)
+    done = torch.empty(k, self.num_envs, device=dev, dtype=torch.uint8)
+    self._check(self.lib.solo_engine_rollout_record(
+      self._h, p, k, flags, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
+      C.c_void_p(done.data_ptr()), self._stream()), 'rollout_record')
+    return obs, rew, done
 
   def time_step(self, actions=None, flags=abi.STEP_ALL, reps=100):
-    """Mean ms per launch of the step kernel, measured with HIP events on the launch stream."""
+    """Mean ms per LAUNCH of the step kernel (each launch fuses steps_per_launch env steps),
+    measured with HIP events on the launch stream.  actions: [reps * steps_per_launch, N, 12]
+    (fresh actions every step) or None."""
     p = None
     if actions is not None:
-      p = self._dev_ptr(actions, (self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
+      spl = self.steps_per_launch
+      reps = int(actions.shape[0]) // spl
+      p = self._dev_ptr(actions[:reps * spl], (reps * spl, self.num_envs, abi.NUM_JOINTS),
+                        self.tdtype, 'actions')
     ms = C.c_double()
     self._check(self.lib.solo_engine_time_step(self._h, p, flags, reps, self._stream(),
                                                C.byref(ms)), 'time_step')

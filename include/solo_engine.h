@@ -118,6 +118,10 @@ typedef struct SoloConfig {
   double settle_targets[SOLO_NUM_JOINTS]; /* solo8v2vanilla.py:21-34, pybullet joint order */
   double action_scale;       /* normalize_actions ? max_motor_rotation : 1 (solo8v2vanilla.py:84-85) */
   int32_t auto_reset;        /* 1: envs whose `done` fires are restored from the snapshot in-kernel */
+  int32_t steps_per_launch;  /* rollouts / settle fuse this many consecutive env steps of each robot
+                                into one kernel launch (state stays in LDS); 0 or 1 = one step */
+  int32_t rollout_streams;   /* rollouts cut the batch into this many slices that advance as
+                                independent launch chains on internal HIP streams (0/1 = off) */
   int32_t reserved;
 } SoloConfig;
 
@@ -196,7 +200,8 @@ typedef struct SoloStateView {
   void* term_count;     /* int32 [N][SOLO_MAX_TERMS]                      */
   void* params;         /* real  [N][4]: lateral friction, base-mass scale, 2 spare */
   void* stats;          /* double[SOLO_STATS_SHARDS][8], sum over the shard axis: sum return, sum return^2,
-                           episodes, sum length, (unused), diverged robots restored, 2 spare */
+                           episodes, sum length, (unused), diverged robots restored, steps with >12 touching
+                           spheres (extras dropped; impossible on a plane), spare */
 } SoloStateView;
 
 typedef struct SoloEngine SoloEngine;
@@ -232,10 +237,20 @@ int solo_engine_set_targets(SoloEngine* eng, const void* actions_dev, void* stre
 /* One env step for all N robots (solo8v2vanilla.py:72-102).  actions_dev may be NULL
  * (keep the last targets).  flags: SOLO_STEP_*.  One kernel launch. */
 int solo_engine_step(SoloEngine* eng, const void* actions_dev, uint32_t flags, void* stream);
-/* K consecutive env steps with per-step actions real [K][N][12]; one launch per step,
- * enqueued back-to-back (rollout helper used by bench.py). */
+/* K consecutive env steps with per-step actions real [K][N][12] (open-loop rollout, used by
+ * bench.py): ceil(K / steps_per_launch) launches enqueued back-to-back; the view's obs / reward /
+ * done hold the LAST step's values afterwards.  With cfg.rollout_streams = G > 1 the batch is cut
+ * into G slices that advance as independent launch chains on G internal HIP streams, forked from
+ * / joined into `stream` (robots are independent: one slice's launch boundary and tail overlap
+ * the other slices' work). */
 int solo_engine_rollout(SoloEngine* eng, const void* actions_dev, int32_t num_steps,
                         uint32_t flags, void* stream);
+/* Same, but every step's outputs are kept: obs_out real [K][N][D], reward_out real [K][N],
+ * done_out uint8 [K][N] (caller-owned device buffers; a NULL pointer = that output is only left
+ * in the engine's view for the last step).  This is what an RL rollout collector reads. */
+int solo_engine_rollout_record(SoloEngine* eng, const void* actions_dev, int32_t num_steps,
+                               uint32_t flags, void* obs_out, void* reward_out, void* done_out,
+                               void* stream);
 int solo_engine_get_view(SoloEngine* eng, SoloStateView* out);
 /* changeDynamics(lateralFriction=...) per env + base-mass randomisation
  * (solo8v2vanilla.py:158-163; BASELINE config 4).  which: 0 = friction, 1 = base mass scale.
@@ -243,8 +258,11 @@ int solo_engine_get_view(SoloEngine* eng, SoloStateView* out);
 int solo_engine_set_params(SoloEngine* eng, int32_t which, const void* per_env_dev, void* stream);
 /* name of the dominant kernel (for rocprof cross-checks) and its last launch geometry */
 const char* solo_engine_kernel_name(SoloEngine* eng);
-/* Times `reps` back-to-back launches of the step kernel with hipEvents on `stream`
- * (the stream the kernel runs on) and returns the mean milliseconds per launch. */
+/* Times a rollout of reps * steps_per_launch steps exactly as solo_engine_rollout runs it (same
+ * slicing, same fused launches) with hipEvents recorded ON THE STREAM THE KERNELS ARE LAUNCHED ON
+ * (slice 0's internal stream when rollout_streams > 1, else `stream`) and returns the mean
+ * milliseconds per LAUNCH of that chain; one launch covers N / max(1, rollout_streams) robots x
+ * steps_per_launch steps.  actions_dev: real [reps * steps_per_launch][N][12] or NULL. */
 int solo_engine_time_step(SoloEngine* eng, const void* actions_dev, uint32_t flags,
                           int32_t reps, void* stream, double* ms_per_launch);
 const char* solo_engine_last_error(SoloEngine* eng);

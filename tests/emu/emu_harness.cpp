@@ -39,10 +39,11 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   B.state = st.data(); B.snapshot = snap.data(); B.targets = tg.data();
   B.actions = actions ? act.data() : nullptr; B.params = par.data(); B.obs = ob.data();
   B.reward = rew.data(); B.done = done; B.term_count = term_count; B.stats = stats;
-  B.num_envs = n; B.flags = flags;
+  B.num_envs = n; B.flags = flags; B.env_base = 0; B.steps = 1;
+  B.action_stride = B.obs_stride = B.reward_stride = B.done_stride = 0;
   const KParams<T>* Pp = &P;
   for (int b = 0; b < n; ++b)
-    WaveEmu::get().run_block(b, n, [&]() { solo_step_kernel<T>(Pp, B); });
+    WaveEmu::get().run_block(b, n, [&]() { solo_step_kernel<T, true>(Pp, B); });
   for (size_t i = 0; i < st.size(); ++i) state[i] = (double)st[i];
   for (size_t i = 0; i < tg.size(); ++i) targets[i] = (double)tg[i];
   if (flags & SOLO_STEP_OBS) for (size_t i = 0; i < (size_t)n * D; ++i) obs[i] = (double)ob[i];

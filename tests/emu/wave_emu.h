@@ -121,6 +121,10 @@ inline int lane_id() { return WaveEmu::get().lane(); }
 inline int block_id() { return blockIdx.x; }
 inline void wave_sync() { WaveEmu::get().yield(); }
 inline void wave_sched_fence() {}
+template <typename P> inline P* wave_opaque(P* p) { return p; }
+inline int wave_opaque_lane(int lane) { return lane; }
+template <typename T> inline T wave_pin(T x) { return x; }
+inline int wave_uniform(int x) { return x; }
 
 inline float wave_readlane(float x, int lane) {
   uint32_t b; std::memcpy(&b, &x, 4);

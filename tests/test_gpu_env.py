@@ -103,3 +103,40 @@ def test_auto_reset_and_stats():
   np.testing.assert_allclose(stats[0], total.sum(), rtol=1e-12)
   np.testing.assert_allclose(stats[1], (total ** 2).sum(), rtol=1e-12)
   assert stats[2] == n and stats[3] == 10 * n and stats[5] == 0
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_fused_rollout_equals_single_steps(dtype):
+  """solo_engine_rollout_record with steps_per_launch = 7 (fused multi-step launches, state kept
+  in LDS) vs one launch per step: same kernel arithmetic -> identical trajectories, outputs
+  and auto-reset behaviour."""
+  import torch
+  from gym_solo_amd import abi
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  from gym_solo_amd.workloads import register_benchmark_workload
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  out = {}
+  for spl in (1, 7):
+    cfg = Solo8VanillaConfig()
+    cfg.dtype, cfg._dtype_pinned, cfg.auto_reset, cfg.steps_per_launch = dtype, True, True, spl
+    env = make_env(config=cfg)
+    register_benchmark_workload(env, max_steps=11)
+    env._ensure_program()
+    g = torch.Generator(device='cuda').manual_seed(7)
+    acts = (torch.rand(30, env.num_envs, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.28
+    if spl == 1:
+      obs, rew, done = [], [], []
+      for k in range(30):
+        env.engine.step(acts[k], abi.STEP_ALL)
+        obs.append(env.engine.obs.clone()); rew.append(env.engine.reward.clone()); done.append(env.engine.done.clone())
+      rec = (torch.stack(obs), torch.stack(rew), torch.stack(done))
+    else:
+      assert env.engine.steps_per_launch == 7
+      rec = env.engine.rollout(acts, abi.STEP_ALL, record=True)
+    env.engine.synchronize()
+    out[spl] = [t.cpu().numpy() for t in rec] + [env.engine.state.cpu().numpy(), env.engine.term_count.cpu().numpy(),
+                                                 env.engine.stats.cpu().numpy()]
+    env._close()
+  for a, b in zip(out[1], out[7]):
+    np.testing.assert_array_equal(a, b)
+  assert out[1][2].sum() == 2 * 64  # two episode ends (steps 12 and 24) per robot

@@ -19,7 +19,7 @@ for dtype, tdt in (('float32', torch.float32), ('float64', torch.float64)):
     acts = (torch.rand(64, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
     for i in range(64):
       eng.step(acts[i], abi.STEP_PHYSICS)
-    ms = eng.time_step(acts[0], abi.STEP_PHYSICS, reps=200)
+    ms = eng.time_step(acts[:100], abi.STEP_PHYSICS)
     print(f'{dtype} N={n}: create+settle {t_create:.2f}s  {ms*1e3:.1f} us/launch  '
           f'{n/ms*1e3:.3e} env-steps/s', flush=True)
     eng.close()

@@ -15,7 +15,7 @@ for dtype, tdt in (('float32', torch.float32),):
       acts = (torch.rand(128, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
       eng.rollout(acts, abi.STEP_PHYSICS)
       # average touching spheres per env at this point
-      ms = eng.time_step(acts[0], abi.STEP_PHYSICS, reps=200)
+      ms = eng.time_step(acts[:100], abi.STEP_PHYSICS)
       z = eng.state[:, 2].mean().item()
       print(f'{dtype} N={n} iters={iters}: {ms*1e3:.1f} us/launch  mean base z {z:.3f}', flush=True)
       eng.close()

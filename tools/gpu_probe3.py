@@ -12,8 +12,8 @@ for dtype, tdt in (('float32', torch.float32), ('float64', torch.float64)):
     g = torch.Generator(device='cuda').manual_seed(1234)
     acts = (torch.rand(128, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
     eng.rollout(acts, abi.STEP_ALL)
-    ms_all = eng.time_step(acts[0], abi.STEP_ALL, reps=200)
-    ms_phy = eng.time_step(acts[0], abi.STEP_PHYSICS, reps=200)
+    ms_all = eng.time_step(acts[:100], abi.STEP_ALL)
+    ms_phy = eng.time_step(acts[:100], abi.STEP_PHYSICS)
     ms_red = eng.time_step(None, abi.STEP_OBS | abi.STEP_REWARD, reps=200)
     print(f'{dtype} N={n}: all {ms_all*1e3:.1f} us  physics {ms_phy*1e3:.1f} us  obs+reward only {ms_red*1e3:.1f} us  -> {n/ms_all*1e3:.3e} env-steps/s', flush=True)
     env._close()
