@@ -163,10 +163,11 @@ def main():
   if w > 0:
     eng.rollout(action_pool(w), abi.STEP_ALL)
   acts = action_pool(k)
+  out = eng.rollout_buffers(k)  # every step's obs / reward / done is written out (to HBM)
   stats_before = eng.stats.clone()
   barrier()
   t0 = time.perf_counter()
-  eng.rollout(acts, abi.STEP_ALL)
+  eng.rollout(acts, abi.STEP_ALL, out=out)
   # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI
   stats = all_reduce_stats(eng.stats - stats_before)
   barrier()

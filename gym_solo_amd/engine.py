@@ -143,19 +143,29 @@ class Engine:
   def steps_per_launch(self):
     return max(1, int(self.cfg.steps_per_launch))
 
-  def rollout(self, actions, flags=abi.STEP_ALL, record=False):
+  def rollout_buffers(self, k):
+    """Trajectory buffers for rollout(record=True): obs [K,N,D], reward [K,N], done [K,N] uint8."""
+    torch = self._torch
+    dev = self.state.device
+    return (torch.empty(k, self.num_envs, max(self.obs_dim, 1), device=dev, dtype=self.tdtype),
+            torch.empty(k, self.num_envs, device=dev, dtype=self.tdtype),
+            torch.empty(k, self.num_envs, device=dev, dtype=torch.uint8))
+
+  def rollout(self, actions, flags=abi.STEP_ALL, record=False, out=None):
     """K open-loop env steps with actions [K, N, 12]; ceil(K / steps_per_launch) fused launches.
-    record=True returns every step's (obs [K,N,D], reward [K,N], done [K,N] uint8)."""
+    record=True (or out=rollout_buffers(K)) keeps every step's (obs [K,N,D], reward [K,N],
+    done [K,N] uint8) — what a rollout collector reads; otherwise only the last step's outputs
+    remain in the engine's view."""
     torch = self._torch
     k = int(actions.shape[0])
     p = self._dev_ptr(actions, (k, self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
-    if not record:
+    if not record and out is None:
       self._check(self.lib.solo_engine_rollout(self._h, p, k, flags, self._stream()), 'rollout')
       return None
-    dev = self.state.device
-    obs = torch.empty(k, self.num_envs, max(self.obs_dim, 1), device=dev, dtype=self.tdtype)
-    rew = torch.empty(k, self.num_envs, device=dev, dtype=self.tdtype)
-    done = torch.empty(k, self.num_envs, device=dev, dtype=torch.uint8)
+    obs, rew, done = out if out is not None else self.rollout_buffers(k)
+    self._dev_ptr(obs, (k, self.num_envs, max(self.obs_dim, 1)), self.tdtype, 'obs_out')
+    self._dev_ptr(rew, (k, self.num_envs), self.tdtype, 'reward_out')
+    self._dev_ptr(done, (k, self.num_envs), torch.uint8, 'done_out')
     self._check(self.lib.solo_engine_rollout_record(
       self._h, p, k, flags, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
       C.c_void_p(done.data_ptr()), self._stream()), 'rollout_record')

@@ -14,6 +14,7 @@ eng = env.engine
 tdt = torch.float32 if dtype == 'float32' else torch.float64
 g = torch.Generator(device='cuda').manual_seed(1234)
 acts = (torch.rand(600, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
-eng.rollout(acts, abi.STEP_ALL)
+out = eng.rollout_buffers(acts.shape[0])
+eng.rollout(acts, abi.STEP_ALL, out=out)
 torch.cuda.synchronize()
 print('done', eng.kernel_name)
