@@ -25,6 +25,10 @@ def load(variant=''):
   lib.solo_emu_step.argtypes = [C.POINTER(abi.SoloConfig), C.POINTER(abi.SoloModel), C.c_void_p,
                                 C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_void_p,
                                 C.c_void_p, dp, C.c_uint32]
+  lib.solo_emu_rollout.restype = C.c_int
+  lib.solo_emu_rollout.argtypes = [C.POINTER(abi.SoloConfig), C.POINTER(abi.SoloModel), C.c_void_p,
+                                   C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_void_p,
+                                   C.c_void_p, dp, C.c_uint32]
   return lib
 
 
@@ -71,6 +75,24 @@ class EmuEngine:
       _dp(self.reward), self.done.ctypes.data, self.term_count.ctypes.data, _dp(self.stats), flags)
     if rc:
       raise RuntimeError('emu step failed: %d' % rc)
+
+  def rollout(self, actions, flags=abi.STEP_ALL):
+    """One fused multi-step launch: actions [K, N, 12] -> (obs [K,N,D], reward [K,N], done [K,N])."""
+    a = np.ascontiguousarray(actions, dtype=np.float64)
+    k = a.shape[0]
+    d = self.program.num_obs if self.program is not None else 0
+    obs = np.zeros((k, self.n, max(d, 1)))
+    rew = np.zeros((k, self.n))
+    done = np.zeros((k, self.n), dtype=np.uint8)
+    rc = self.lib.solo_emu_rollout(
+      C.byref(self.cfg), C.byref(self.model),
+      C.cast(C.pointer(self.program), C.c_void_p) if self.program is not None else None,
+      self.cfg.dtype, self.n, k, _dp(self.state), _dp(self.snapshot), _dp(a), _dp(self.targets),
+      _dp(self.params), _dp(obs), _dp(rew), done.ctypes.data, self.term_count.ctypes.data,
+      _dp(self.stats), flags)
+    if rc:
+      raise RuntimeError('emu rollout failed: %d' % rc)
+    return obs, rew, done
 
   def settle(self):
     tg = np.tile(np.array(list(self.cfg.settle_targets)), (self.n, 1)) / self.cfg.action_scale

@@ -140,3 +140,65 @@ def test_fused_rollout_equals_single_steps(dtype):
   for a, b in zip(out[1], out[7]):
     np.testing.assert_array_equal(a, b)
   assert out[1][2].sum() == 2 * 64  # two episode ends (steps 12 and 24) per robot
+
+
+def test_domain_randomisation_matches_oracle():
+  """BASELINE config 4: per-env lateral friction and base-mass scale (changeDynamics per env,
+  solo8v2vanilla.py:158-163) — engine.set_params + re-settle vs the oracle with the same params."""
+  import torch
+  from gym_solo_amd import abi
+  from gym_solo_amd.engine import Engine
+  from helpers import make_abi
+  from oracle import solo_oracle as so
+  ca, ma = make_abi('float64')
+  n = 32
+  rng = np.random.default_rng(4321)
+  mu = rng.uniform(0.3, 1.0, n)
+  ms = rng.uniform(0.8, 1.2, n)
+  eng = Engine(ca, ma, n)
+  eng.set_params(abi.PARAM_FRICTION, torch.as_tensor(mu, device='cuda'))
+  eng.set_params(abi.PARAM_BASE_MASS_SCALE, torch.as_tensor(ms, device='cuda'))
+  eng.settle()
+  params = np.zeros((n, 4)); params[:, 0] = mu; params[:, 1] = ms
+  np.testing.assert_allclose(eng.params.cpu().numpy(), params)
+  ph = so.OraclePhysics(ca, ma)
+  st = ph.settle(n, params)
+  np.testing.assert_allclose(eng.snapshot.cpu().numpy()[:, :29], st[:, :29], rtol=0, atol=1e-9)
+  for k in range(40):
+    a = rng.uniform(-2 * np.pi, 2 * np.pi, (n, 12))
+    ph.step(st, a, params)
+    eng.step(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+  got = eng.state.cpu().numpy()
+  np.testing.assert_allclose(got[:, :29], st[:, :29], rtol=0, atol=1e-9)
+  # the randomisation matters: robots with different parameters end up in different states
+  assert np.abs(got[0, :29] - got[1, :29]).max() > 1e-4
+  eng.close()
+
+
+def test_client_facade_pull_path_equals_fused_step():
+  """The reference's call sequence through the BulletClient-shaped facade
+  (setJointMotorControlArray -> stepSimulation -> get_obs / get_reward, solo8v2vanilla.py:87-97)
+  gives the same state, observations and rewards as the fused env.step()."""
+  import torch
+  import gym_solo_amd.client as p
+  env_a, env_b = make_env(), make_env()
+  for env in (env_a, env_b):
+    cases.register_benchmark_workload(env, max_steps=1000)
+  rng = np.random.default_rng(11)
+  for k in range(15):
+    a = torch.as_tensor(rng.uniform(-2 * np.pi, 2 * np.pi, (env_a.num_envs, 12)))
+    o, r, d, _ = env_a.step(a)
+    env_b.client.setJointMotorControlArray(env_b.robot, np.arange(12), p.POSITION_CONTROL,
+                                           targetPositions=a, forces=[env_b.config.motor_torque_limit] * 12)
+    env_b.client.stepSimulation()
+    ob, _ = env_b.obs_factory.get_obs()
+    rb = env_b.reward_factory.get_reward()
+    np.testing.assert_array_equal(cases.np_(env_a.engine.state)[:, :29], cases.np_(env_b.engine.state)[:, :29])
+    np.testing.assert_array_equal(cases.np_(o), cases.np_(ob))
+    np.testing.assert_array_equal(cases.np_(r), cases.np_(rb))
+  pos, orn = env_b.client.getBasePositionAndOrientation(env_b.robot)
+  assert pos.shape == (env_b.num_envs, 3) and orn.shape == (env_b.num_envs, 4)
+  q, qd, _, _ = env_b.client.getJointState(env_b.robot, 2)  # fixed ANKLE joint reads 0
+  assert float(q.abs().max()) == 0.0 and float(qd.abs().max()) == 0.0
+  assert env_b.client.getNumJoints(env_b.robot) == 12
+  assert env_b.client.getJointInfo(env_b.robot, 4)[1] == b'FR_KFE'
