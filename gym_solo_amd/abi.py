@@ -129,6 +129,34 @@ class SoloProgram(C.Structure):
   ]
 
 
+class SoloTerrain(C.Structure):
+  _fields_ = [
+    ('nx', C.c_int32),
+    ('ny', C.c_int32),
+    ('cell', C.c_double),
+    ('origin', C.c_double * 2),
+    ('heights', C.POINTER(C.c_double)),
+  ]
+
+
+def make_terrain(heights, cell, origin=None):
+  """SoloTerrain over a numpy [ny, nx] height array (kept alive on the returned struct); the grid is
+  centred on the world origin unless `origin` (x, y of grid point (0, 0)) is given."""
+  import numpy as np
+  h = np.ascontiguousarray(heights, dtype=np.float64)
+  if h.ndim != 2 or h.shape[0] < 2 or h.shape[1] < 2:
+    raise ValueError('heights must be a [ny >= 2, nx >= 2] array')
+  t = SoloTerrain()
+  t.ny, t.nx = h.shape
+  t.cell = float(cell)
+  if origin is None:
+    origin = (-0.5 * (t.nx - 1) * t.cell, -0.5 * (t.ny - 1) * t.cell)
+  t.origin[0], t.origin[1] = float(origin[0]), float(origin[1])
+  t.heights = h.ctypes.data_as(C.POINTER(C.c_double))
+  t._keepalive = h
+  return t
+
+
 class SoloStateView(C.Structure):
   _fields_ = [
     ('num_envs', C.c_int32),
@@ -162,6 +190,7 @@ ENTRY_POINTS = {
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
   'solo_engine_get_view': (C.c_int, [C.c_void_p, C.POINTER(SoloStateView)]),
   'solo_engine_set_params': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+  'solo_engine_set_terrain': (C.c_int, [C.c_void_p, C.POINTER(SoloTerrain), C.c_void_p]),
   'solo_engine_kernel_name': (C.c_char_p, [C.c_void_p]),
   'solo_engine_time_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
                                       C.c_void_p, C.POINTER(C.c_double)]),

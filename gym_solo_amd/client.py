@@ -132,6 +132,9 @@ class BatchedBulletClient:
   def as_actions(self, a):
     import torch
     eng = self.engine
+    if (_is_tensor(a) and a.dtype == eng.tdtype and a.dim() == 2 and a.is_contiguous()
+        and a.device == eng.state.device and a.shape[0] == eng.num_envs and a.shape[1] == abi.NUM_JOINTS):
+      return a  # already what the engine takes: no torch ops on the hot path
     if not _is_tensor(a):
       a = torch.as_tensor(np.asarray(a, dtype=np.float64))
     a = a.to(device=eng.state.device, dtype=eng.tdtype)

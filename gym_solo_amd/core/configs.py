@@ -55,6 +55,9 @@ class Solo8BaseConfig:
   auto_reset: bool = False
   steps_per_launch: int = 1       # rollouts fuse this many env steps per kernel launch
   rollout_streams: int = 1        # rollouts advance this many batch slices on separate HIP streams
+  # ground: None = pybullet_data's flat plane.urdf (solo8_base_env.py:47); or a heightfield
+  # dict(heights=[ny, nx] array, cell=metres, origin=(x, y) of grid point (0, 0) or None = centred)
+  terrain = None
 
   @property
   def urdf(self):

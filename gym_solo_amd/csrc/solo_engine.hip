@@ -27,6 +27,7 @@ struct EngineBase {
   virtual int rollout(const void* a, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out, hipStream_t s) = 0;
   virtual int view(SoloStateView* v) = 0;
   virtual int set_params(int which, const void* p, hipStream_t s) = 0;
+  virtual int set_terrain(const SoloTerrain* t, hipStream_t s) = 0;
   virtual int time_step(const void* a, uint32_t flags, int reps, hipStream_t s, double* ms) = 0;
   virtual const char* kernel_name() = 0;
   std::string err;
@@ -56,6 +57,7 @@ struct Engine final : EngineBase {
   uint8_t* done = nullptr;
   int32_t* term_count = nullptr;
   double* stats = nullptr;
+  T* terrain = nullptr;
 #ifdef SOLO_STAMPS
   unsigned long long* stamps = nullptr;
 #endif
@@ -69,7 +71,7 @@ struct Engine final : EngineBase {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : {(void*)dparams, (void*)state, (void*)snapshot, (void*)targets, (void*)params,
                     (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
-                    (void*)term_count, (void*)stats})
+                    (void*)term_count, (void*)stats, (void*)terrain})
       if (p) (void)hipFree(p);
   }
 
@@ -118,7 +120,7 @@ struct Engine final : EngineBase {
     solo::KBuffers<T> b;
     b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
     b.params = params; b.obs = obs; b.reward = reward; b.done = done; b.term_count = term_count;
-    b.stats = stats; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
+    b.stats = stats; b.terrain = terrain; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
     b.action_stride = b.obs_stride = b.reward_stride = b.done_stride = 0;
 #ifdef SOLO_STAMPS
     b.stamps = stamps;
@@ -302,6 +304,29 @@ struct Engine final : EngineBase {
     return SOLO_OK;
   }
 
+  int set_terrain(const SoloTerrain* t, hipStream_t s) override {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (terrain) { (void)hipFree(terrain); terrain = nullptr; }
+    hparams.terr_nx = hparams.terr_ny = 0;
+    if (t) {
+      if (t->nx < 2 || t->ny < 2 || !(t->cell > 0) || !t->heights || (long long)t->nx * t->ny > (1ll << 26)) {
+        err = "terrain needs nx, ny >= 2, cell > 0 and a heights array";
+        return SOLO_ERR_INVALID_ARG;
+      }
+      const size_t cnt = (size_t)t->nx * t->ny;
+      std::vector<T> h(cnt);
+      for (size_t i = 0; i < cnt; ++i) h[i] = (T)t->heights[i];
+      HIP_TRY(hipMalloc((void**)&terrain, cnt * sizeof(T)));
+      HIP_TRY(hipMemcpy(terrain, h.data(), cnt * sizeof(T), hipMemcpyHostToDevice));
+      hparams.terr_nx = t->nx; hparams.terr_ny = t->ny;
+      hparams.terr_inv_cell = (T)(1.0 / t->cell);
+      hparams.terr_ox = (T)t->origin[0]; hparams.terr_oy = (T)t->origin[1];
+    }
+    HIP_TRY(hipMemcpy(dparams, &hparams, sizeof(hparams), hipMemcpyHostToDevice));
+    return settle(s);
+  }
+
   int view(SoloStateView* v) override {
     v->num_envs = n;
     v->dtype = sizeof(T) == 4 ? SOLO_F32 : SOLO_F64;
@@ -418,6 +443,7 @@ int solo_engine_get_view(SoloEngine* eng, SoloStateView* out) {
   return ENG_CALL(view(out));
 }
 int solo_engine_set_params(SoloEngine* eng, int32_t which, const void* p, void* stream) { return ENG_CALL(set_params(which, p, (hipStream_t)stream)); }
+int solo_engine_set_terrain(SoloEngine* eng, const SoloTerrain* t, void* stream) { return ENG_CALL(set_terrain(t, (hipStream_t)stream)); }
 const char* solo_engine_kernel_name(SoloEngine* eng) { return eng && eng->impl ? eng->impl->kernel_name() : ""; }
 int solo_engine_time_step(SoloEngine* eng, const void* a, uint32_t flags, int32_t reps, void* stream, double* ms) {
   return ENG_CALL(time_step(a, flags, reps, (hipStream_t)stream, ms));

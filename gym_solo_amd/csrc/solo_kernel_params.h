@@ -75,6 +75,9 @@ struct KParams {
   T action_scale;
   T gauss_scale;  // sqrt(-2 ln 0.1): rewards.py:427 with the default margin_value
   int32_t iterations, auto_reset;
+  // heightfield ground (SoloTerrain): grid size, 1/cell, origin; heights live in KBuffers::terrain
+  int32_t terr_nx, terr_ny;
+  T terr_inv_cell, terr_ox, terr_oy;
   T base_mass, base_I[6];
   LegConst<T> leg[4];
   RowConst<T> row[64];
@@ -96,7 +99,8 @@ struct KBuffers {
   T* reward;          // [N]
   uint8_t* done;      // [N]
   int32_t* term_count;  // [N][4]
-  double* stats;      // [8]
+  double* stats;      // [SOLO_STATS_SHARDS][8]
+  const T* terrain;   // [ny][nx] heights, or null = flat plane z = 0
   int32_t num_envs;    // total robots of the engine
   uint32_t flags;
   int32_t env_base;    // first robot of this launch (grid = robots of this launch)

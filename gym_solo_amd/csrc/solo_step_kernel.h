@@ -439,12 +439,44 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   V3<T> cb = {rc.center[0], rc.center[1], rc.center[2]};
   if (rc.body == BODY_UPPER) cb = o1 + roty(c1, s1, cb);
   else if (rc.body == BODY_LOWER) cb = o2 + roty(c12, s12, cb);
-  const T dist = s_state[SOLO_S_POS + 2] + dot(nb, cb) - rc.radius;
+  // ground under the sphere: flat plane z = 0 (plane.urdf, solo8_base_env.py:47) or the tangent
+  // plane of the heightfield under the sphere centre (SoloTerrain; wave-uniform choice)
+  T dist;
+  V3<T> nloc = nb;                      // ground normal in base coordinates
+  V3<T> d = nb;                         // this row's direction in base coordinates
+  if (B.terrain == nullptr) {
+    dist = s_state[SOLO_S_POS + 2] + dot(nb, cb) - rc.radius;
+    if (type == ROW_TAN1) d = V3<T>{r00, r01, r02};
+    if (type == ROW_TAN2) d = V3<T>{r10, r11, r12};
+  } else {
+    const T cwx = s_state[SOLO_S_POS] + r00 * cb.x + r01 * cb.y + r02 * cb.z;
+    const T cwy = s_state[SOLO_S_POS + 1] + r10 * cb.x + r11 * cb.y + r12 * cb.z;
+    const T cwz = s_state[SOLO_S_POS + 2] + r20 * cb.x + r21 * cb.y + r22 * cb.z;
+    const T gu = (cwx - P->terr_ox) * P->terr_inv_cell, gv = (cwy - P->terr_oy) * P->terr_inv_cell;
+    int gi = (int)R::floor(gu), gj = (int)R::floor(gv);
+    gi = gi < 0 ? 0 : (gi > P->terr_nx - 2 ? P->terr_nx - 2 : gi);
+    gj = gj < 0 ? 0 : (gj > P->terr_ny - 2 ? P->terr_ny - 2 : gj);
+    const T fu = R::clamp(gu - T(gi), T(0), T(1)), fv = R::clamp(gv - T(gj), T(0), T(1));
+    const T* H = B.terrain + (size_t)gj * P->terr_nx + gi;
+    const T h00 = H[0], h10 = H[1], h01 = H[P->terr_nx], h11 = H[P->terr_nx + 1];
+    const T hh0 = (T(1) - fu) * (T(1) - fv) * h00 + fu * (T(1) - fv) * h10 + (T(1) - fu) * fv * h01 + fu * fv * h11;
+    const T hx = ((T(1) - fv) * (h10 - h00) + fv * (h11 - h01)) * P->terr_inv_cell;
+    const T hy = ((T(1) - fu) * (h01 - h00) + fu * (h11 - h10)) * P->terr_inv_cell;
+    const T inv = R::rsqrt(hx * hx + hy * hy + T(1));
+    const V3<T> nw = {-hx * inv, -hy * inv, inv};
+    // friction directions: world x projected into the tangent plane, and n x t1
+    const T itn = R::rsqrt(T(1) - nw.x * nw.x);
+    const V3<T> t1w = {(T(1) - nw.x * nw.x) * itn, -nw.x * nw.y * itn, -nw.x * nw.z * itn};
+    const V3<T> t2w = cross(nw, t1w);
+    dist = (cwz - hh0) * nw.z - rc.radius;
+    V3<T> dw = nw;
+    if (type == ROW_TAN1) dw = t1w;
+    if (type == ROW_TAN2) dw = t2w;
+    nloc = V3<T>{r00 * nw.x + r10 * nw.y + r20 * nw.z, r01 * nw.x + r11 * nw.y + r21 * nw.z, r02 * nw.x + r12 * nw.y + r22 * nw.z};
+    d = V3<T>{r00 * dw.x + r10 * dw.y + r20 * dw.z, r01 * dw.x + r11 * dw.y + r21 * dw.z, r02 * dw.x + r12 * dw.y + r22 * dw.z};
+  }
   const bool live = is_motor || (is_contact && dist < P->margin);
-  const V3<T> x = cb - rc.radius * nb;  // contact point in base coordinates
-  V3<T> d = nb;
-  if (type == ROW_TAN1) d = V3<T>{r00, r01, r02};
-  if (type == ROW_TAN2) d = V3<T>{r10, r11, r12};
+  const V3<T> x = cb - rc.radius * nloc;  // contact point in base coordinates
   T jb[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   T jl1 = T(0), jl2 = T(0), bias = T(0);
   if (is_contact) {

@@ -101,6 +101,7 @@ template <> struct Real<float> {
   static __device__ __forceinline__ float clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
   static __device__ __forceinline__ bool finite(float x) { return isfinite(x); }
   static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+  static __device__ __forceinline__ float floor(float x) { return floorf(x); }
   static __device__ __forceinline__ float big() { return 3.0e38f; }
 };
 template <> struct Real<double> {
@@ -116,6 +117,7 @@ template <> struct Real<double> {
   static __device__ __forceinline__ double clamp(double x, double lo, double hi) { return ::fmin(::fmax(x, lo), hi); }
   static __device__ __forceinline__ bool finite(double x) { return isfinite(x); }
   static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+  static __device__ __forceinline__ double floor(double x) { return ::floor(x); }
   static __device__ __forceinline__ double big() { return 1.0e300; }
 };
 

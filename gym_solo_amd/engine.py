@@ -68,6 +68,7 @@ class Engine:
       self._h = None
       _raise(rc, 'solo_engine_create: ' + self.lib.solo_last_create_error().decode())
     self.program = None
+    self._action_shape = (self.num_envs, abi.NUM_JOINTS)
     self._views = {}
     self._make_views()
 
@@ -93,6 +94,7 @@ class Engine:
     self.targets = view(v.targets, (n, abi.NUM_JOINTS), real)
     self.reward = view(v.reward, (n,), real)
     self.done = view(v.done, (n,), '|u1')
+    self.done_bool = self.done.view(torch.bool)  # zero-copy bool alias of the uint8 flags
     self.term_count = view(v.term_count, (n, abi.MAX_TERMS), '<i4')
     self.params = view(v.params, (n, 4), real)
     self.stats_shards = view(v.stats, (abi.STATS_SHARDS, abi.STATS_WIDTH), '<f8')
@@ -136,8 +138,10 @@ class Engine:
   def step(self, actions=None, flags=abi.STEP_ALL):
     p = None
     if actions is not None:
-      p = self._dev_ptr(actions, (self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
-    self._check(self.lib.solo_engine_step(self._h, p, flags, self._stream()), 'step')
+      p = self._dev_ptr(actions, self._action_shape, self.tdtype, 'actions')
+    rc = self.lib.solo_engine_step(self._h, p, flags, self._stream())
+    if rc != abi.OK:
+      self._check(rc, 'step')
 
   @property
   def steps_per_launch(self):
@@ -186,6 +190,12 @@ class Engine:
                                                C.byref(ms)), 'time_step')
     return ms.value
 
+  def set_terrain(self, terrain):
+    """terrain: abi.SoloTerrain (abi.make_terrain(heights, cell)) or None for the flat plane;
+    re-settles (the reset snapshot depends on the ground)."""
+    self._check(self.lib.solo_engine_set_terrain(
+      self._h, C.byref(terrain) if terrain is not None else None, self._stream()), 'set_terrain')
+
   def set_params(self, which, per_env):
     p = self._dev_ptr(per_env, (self.num_envs,), self.tdtype, 'per_env')
     self._check(self.lib.solo_engine_set_params(self._h, which, p, self._stream()), 'set_params')
@@ -206,7 +216,7 @@ class Engine:
   def close(self):
     if getattr(self, '_h', None):
       self._torch.cuda.synchronize(self.device)
-      for name in ('state', 'snapshot', 'targets', 'reward', 'done', 'term_count', 'params',
+      for name in ('state', 'snapshot', 'targets', 'reward', 'done', 'done_bool', 'term_count', 'params',
                    'stats_shards', 'obs'):
         setattr(self, name, None)
       self.lib.solo_engine_destroy(self._h)

@@ -148,6 +148,7 @@ class Solo8BaseEnv(ABC, spaces.Env):
         prog.term_kind[k] = kind
         prog.term_param[k] = param
     self.engine.set_program(prog)
+    self._labels = of.labels if of._observations else []
     self._fused = fused
     self._valid = dict(obs=-1, reward=-1, done=-1)
     self._dirty = False

@@ -57,7 +57,14 @@ class Solo8VanillaEnv(Solo8BaseEnv):
     from gym_solo_amd.engine import Engine
     cfg = config_to_abi(self.config, self.config.starting_joint_pos, JOINT_NAMES,
                         normalize_actions=self._normalize)
-    return Engine(cfg, self.solo_model.to_abi(), self.config.num_envs, self.config.device)
+    engine = Engine(cfg, self.solo_model.to_abi(), self.config.num_envs, self.config.device)
+    terrain = getattr(self.config, 'terrain', None)
+    if terrain is not None:
+      # loadURDF('plane.urdf') -> heightfield (BASELINE configs[4]); re-settles on the new ground
+      if isinstance(terrain, dict):
+        terrain = abi.make_terrain(terrain['heights'], terrain['cell'], terrain.get('origin'))
+      engine.set_terrain(terrain)
+    return engine
 
   @property
   def action_space(self):
@@ -91,8 +98,16 @@ class Solo8VanillaEnv(Solo8BaseEnv):
     eng.step(actions, self._flags(physics=True))
     self.client.state_version += 1
     v = self.client.state_version
+    fused = self._fused
+    if fused['obs'] and fused['reward'] and fused['done'] and not self._realtime:
+      # everything was produced by that launch: hand the engine's buffers out without going
+      # through the three pull-style factory calls (host time per step matters in closed loop)
+      self._valid['obs'] = self._valid['reward'] = self._valid['done'] = v
+      if self._copy_outputs:
+        return eng.obs.clone(), eng.reward.clone(), eng.done.bool(), {'labels': self._labels}
+      return eng.obs, eng.reward, eng.done_bool, {'labels': self._labels}
     for key in ('obs', 'reward', 'done'):
-      if self._fused[key]:
+      if fused[key]:
         self._valid[key] = v
 
     if self._realtime:

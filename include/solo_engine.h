@@ -185,6 +185,17 @@ typedef struct SoloProgram {
   int32_t term_param[SOLO_MAX_TERMS]; /* max_step_delta / flag */
 } SoloProgram;
 
+/* ---- ground: the reference loads pybullet_data's flat `plane.urdf` (solo8_base_env.py:47);
+ * BASELINE configs[4] asks for inclined / stair terrain.  A heightfield z = h(x, y) on a regular
+ * grid, bilinearly interpolated (clamped to the border outside the grid); every collision sphere
+ * collides with the tangent plane of the terrain under its centre. ------------------------- */
+typedef struct SoloTerrain {
+  int32_t nx, ny;          /* grid points along x and y (>= 2 each)                       */
+  double cell;             /* grid spacing [m]                                            */
+  double origin[2];        /* world (x, y) of grid point (0, 0)                           */
+  const double* heights;   /* HOST pointer, [ny][nx] row-major (y major), copied by the call */
+} SoloTerrain;
+
 /* ---- zero-copy view of engine-owned device buffers ----------------------- */
 typedef struct SoloStateView {
   int32_t num_envs;
@@ -256,6 +267,9 @@ int solo_engine_get_view(SoloEngine* eng, SoloStateView* out);
  * (solo8v2vanilla.py:158-163; BASELINE config 4).  which: 0 = friction, 1 = base mass scale.
  * per_env_dev: real [N]. */
 int solo_engine_set_params(SoloEngine* eng, int32_t which, const void* per_env_dev, void* stream);
+/* Replaces loadURDF('plane.urdf') (solo8_base_env.py:47): NULL = the flat plane z = 0.  Re-runs the
+ * settle loop (the reset snapshot depends on the ground).  Synchronises the device. */
+int solo_engine_set_terrain(SoloEngine* eng, const SoloTerrain* terrain, void* stream);
 /* name of the dominant kernel (for rocprof cross-checks) and its last launch geometry */
 const char* solo_engine_kernel_name(SoloEngine* eng);
 /* Times a rollout of reps * steps_per_launch steps exactly as solo_engine_rollout runs it (same

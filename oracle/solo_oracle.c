@@ -412,7 +412,29 @@ static void point_jacobian(const SoloModel* mdl, const Kin* k, int b, const doub
   }
 }
 
-static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const Kin* k,
+/* ground under the world point (x, y): height and unit normal of the tangent plane.  terrain ==
+ * NULL: the flat plane.urdf (solo8_base_env.py:47); else bilinear interpolation of the grid,
+ * clamped to its border (include/solo_engine.h SoloTerrain; BASELINE configs[4]). */
+static void ground_at(const SoloTerrain* t, double x, double y, double* h, double n[3]) {
+  if (!t) { *h = 0; n[0] = 0; n[1] = 0; n[2] = 1; return; }
+  double u = (x - t->origin[0]) / t->cell, v = (y - t->origin[1]) / t->cell;
+  int i = (int)floor(u), j = (int)floor(v);
+  i = i < 0 ? 0 : (i > t->nx - 2 ? t->nx - 2 : i);
+  j = j < 0 ? 0 : (j > t->ny - 2 ? t->ny - 2 : j);
+  double fu = u - i, fv = v - j;
+  fu = fu < 0 ? 0 : (fu > 1 ? 1 : fu);
+  fv = fv < 0 ? 0 : (fv > 1 ? 1 : fv);
+  const double* H = t->heights;
+  double h00 = H[(size_t)j * t->nx + i], h10 = H[(size_t)j * t->nx + i + 1];
+  double h01 = H[(size_t)(j + 1) * t->nx + i], h11 = H[(size_t)(j + 1) * t->nx + i + 1];
+  *h = (1 - fu) * (1 - fv) * h00 + fu * (1 - fv) * h10 + (1 - fu) * fv * h01 + fu * fv * h11;
+  double hx = ((1 - fv) * (h10 - h00) + fv * (h11 - h01)) / t->cell;
+  double hy = ((1 - fu) * (h01 - h00) + fu * (h11 - h10)) / t->cell;
+  double inv = 1.0 / sqrt(hx * hx + hy * hy + 1.0);
+  n[0] = -hx * inv; n[1] = -hy * inv; n[2] = inv;
+}
+
+static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const SoloTerrain* terrain, const Kin* k,
                        const double* st, const double ustar[NV], const double targets[ND],
                        double mu, Rows* R) {
   R->n = 0; R->mu = mu;
@@ -428,16 +450,21 @@ static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const Kin* k
     R->hi[r] = cfg->motor_torque_limit * cfg->dt;
     R->normal_row[r] = -1; R->sphere[r] = -1;
   }
-  /* sphere vs ground plane z = 0 (plane.urdf, solo8_base_env.py:47) */
-  const double n[3] = {0, 0, 1}, t1[3] = {1, 0, 0}, t2[3] = {0, 1, 0};
+  /* sphere vs the tangent plane of the ground under its centre */
   for (int s = 0; s < mdl->num_spheres; ++s) {
     int b = mdl->sphere_body[s];
-    double cw[3];
+    double cw[3], n[3], t1[3], t2[3], h;
     m3v(k->Rwb[b], mdl->sphere_center[s], cw);
     for (int a = 0; a < 3; ++a) cw[a] += k->pw[b][a];
-    double dist = cw[2] - mdl->sphere_radius[s];
+    ground_at(terrain, cw[0], cw[1], &h, n);
+    /* friction directions: world x projected into the tangent plane, and n x t1 */
+    double tn = sqrt(1.0 - n[0] * n[0]);
+    t1[0] = (1.0 - n[0] * n[0]) / tn; t1[1] = -n[0] * n[1] / tn; t1[2] = -n[0] * n[2] / tn;
+    v3cross(n, t1, t2);
+    double dist = (cw[2] - h) * n[2] - mdl->sphere_radius[s];
     if (!(dist < cfg->contact_margin)) continue;
-    double x[3] = {cw[0], cw[1], cw[2] - mdl->sphere_radius[s]};
+    double x[3] = {cw[0] - mdl->sphere_radius[s] * n[0], cw[1] - mdl->sphere_radius[s] * n[1],
+                   cw[2] - mdl->sphere_radius[s] * n[2]};
     int rn = R->n++;
     point_jacobian(mdl, k, b, x, n, R->J[rn]);
     /* non-penetration: v_n >= -dist/dt if separated (speculative), else push out with erp */
@@ -481,8 +508,9 @@ static void quat_integrate(double q[4], const double w[3], double dt) {
 
 /* One physics step of ONE robot.  st: SOLO_STATE_STRIDE doubles (in/out); targets: 8 dof
  * targets (radians); params: {friction, base-mass scale}.  dbg may be NULL. */
-int solo_oracle_step_env(const SoloConfig* cfg, const SoloModel* mdl, double* st,
-                         const double* targets, const double* params, SoloOracleDebug* dbg) {
+int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, const SoloTerrain* terrain,
+                                 double* st, const double* targets, const double* params,
+                                 SoloOracleDebug* dbg) {
   static _Thread_local Kin k;
   static _Thread_local Rows R;
   double M[NV * NV], L[NV * NV], h[NV], u[NV], udot[NV], ustar[NV];
@@ -500,7 +528,7 @@ int solo_oracle_step_env(const SoloConfig* cfg, const SoloModel* mdl, double* st
   for (int i = 0; i < NV; ++i) ustar[i] = u[i] + cfg->dt * udot[i];
   for (int a = 0; a < 3; ++a) ustar[3 + a] += cfg->dt * wxv[a];
 
-  build_rows(mdl, cfg, &k, st, ustar, targets, params[0], &R);
+  build_rows(mdl, cfg, terrain, &k, st, ustar, targets, params[0], &R);
   /* sequential impulse / projected Gauss-Seidel in velocity space */
   static _Thread_local double B[MAXROWS][NV];
   double diag[MAXROWS], lam[MAXROWS], up[NV];
@@ -550,6 +578,11 @@ int solo_oracle_step_env(const SoloConfig* cfg, const SoloModel* mdl, double* st
     }
   }
   return 0;
+}
+
+int solo_oracle_step_env(const SoloConfig* cfg, const SoloModel* mdl, double* st,
+                         const double* targets, const double* params, SoloOracleDebug* dbg) {
+  return solo_oracle_step_env_terrain(cfg, mdl, NULL, st, targets, params, dbg);
 }
 
 /* Forward dynamics two ways for known-answer test (4): returns udot from CRBA+RNEA+Cholesky
@@ -610,19 +643,25 @@ void solo_oracle_momentum(const SoloModel* mdl, const double* st, double mass_sc
 
 /* Batched stepping for the cpu_baseline leg and batch parity: st [N][32], actions [N][12]
  * in pybullet joint order (scaled by cfg->action_scale), params [N][4].  OpenMP over envs. */
-int solo_oracle_step_batch(const SoloConfig* cfg, const SoloModel* mdl, int32_t n, double* st,
-                           const double* actions, const double* params, int32_t nthreads) {
+int solo_oracle_step_batch_terrain(const SoloConfig* cfg, const SoloModel* mdl, const SoloTerrain* terrain,
+                                   int32_t n, double* st, const double* actions, const double* params,
+                                   int32_t nthreads) {
   int fail = 0;
 #pragma omp parallel for num_threads(nthreads) schedule(static) reduction(| : fail)
   for (int e = 0; e < n; ++e) {
     double tg[ND];
     for (int j = 0; j < ND; ++j)
       tg[j] = actions[(size_t)e * SOLO_NUM_JOINTS + mdl->dof_to_joint[j]] * cfg->action_scale;
-    if (solo_oracle_step_env(cfg, mdl, st + (size_t)e * SOLO_STATE_STRIDE, tg,
-                             params + (size_t)e * 4, NULL))
+    if (solo_oracle_step_env_terrain(cfg, mdl, terrain, st + (size_t)e * SOLO_STATE_STRIDE, tg,
+                                     params + (size_t)e * 4, NULL))
       fail = 1;
   }
   return fail ? -1 : 0;
+}
+
+int solo_oracle_step_batch(const SoloConfig* cfg, const SoloModel* mdl, int32_t n, double* st,
+                           const double* actions, const double* params, int32_t nthreads) {
+  return solo_oracle_step_batch_terrain(cfg, mdl, NULL, n, st, actions, params, nthreads);
 }
 
 size_t solo_oracle_debug_size(void) { return sizeof(SoloOracleDebug); }

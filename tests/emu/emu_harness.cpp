@@ -14,7 +14,8 @@ template <typename T>
 static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* prog, int n,
                double* state, const double* snapshot, const double* actions, double* targets,
                const double* params, double* obs, double* reward, uint8_t* done,
-               int32_t* term_count, double* stats, uint32_t flags, int steps = 1) {
+               int32_t* term_count, double* stats, uint32_t flags, int steps = 1,
+               const SoloTerrain* terrain = nullptr) {
   std::string err;
   if (int rc = validate_model(*mdl, &err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return rc; }
   static KParams<T> P;
@@ -36,7 +37,14 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   if (actions) act = conv(actions, (size_t)steps * n * SOLO_NUM_JOINTS);
   std::vector<T> par = conv(params, (size_t)n * 4);
   std::vector<T> ob((size_t)steps * n * (D > 0 ? D : 1)), rew((size_t)steps * n);
+  std::vector<T> terr;
+  if (terrain) {
+    terr = conv(terrain->heights, (size_t)terrain->nx * terrain->ny);
+    P.terr_nx = terrain->nx; P.terr_ny = terrain->ny; P.terr_inv_cell = (T)(1.0 / terrain->cell);
+    P.terr_ox = (T)terrain->origin[0]; P.terr_oy = (T)terrain->origin[1];
+  }
   KBuffers<T> B;
+  B.terrain = terrain ? terr.data() : nullptr;
   B.state = st.data(); B.snapshot = snap.data(); B.targets = tg.data();
   B.actions = actions ? act.data() : nullptr; B.params = par.data(); B.obs = ob.data();
   B.reward = rew.data(); B.done = done; B.term_count = term_count; B.stats = stats;
@@ -56,12 +64,12 @@ extern "C" int solo_emu_step(const SoloConfig* cfg, const SoloModel* mdl, const 
                              int dtype, int n, double* state, const double* snapshot,
                              const double* actions, double* targets, const double* params,
                              double* obs, double* reward, uint8_t* done, int32_t* term_count,
-                             double* stats, uint32_t flags) {
+                             double* stats, uint32_t flags, const SoloTerrain* terrain) {
   if (dtype == SOLO_F32)
     return run<float>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
-                      done, term_count, stats, flags);
+                      done, term_count, stats, flags, 1, terrain);
   return run<double>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
-                     done, term_count, stats, flags);
+                     done, term_count, stats, flags, 1, terrain);
 }
 
 // fused multi-step launch: actions [steps][n][12]; obs [steps][n][D], reward [steps][n], done [steps][n]
@@ -69,10 +77,10 @@ extern "C" int solo_emu_rollout(const SoloConfig* cfg, const SoloModel* mdl, con
                                 int dtype, int n, int steps, double* state, const double* snapshot,
                                 const double* actions, double* targets, const double* params,
                                 double* obs, double* reward, uint8_t* done, int32_t* term_count,
-                                double* stats, uint32_t flags) {
+                                double* stats, uint32_t flags, const SoloTerrain* terrain) {
   if (dtype == SOLO_F32)
     return run<float>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
-                      done, term_count, stats, flags, steps);
+                      done, term_count, stats, flags, steps, terrain);
   return run<double>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
-                     done, term_count, stats, flags, steps);
+                     done, term_count, stats, flags, steps, terrain);
 }

@@ -173,6 +173,7 @@ template <> struct Real<float> {
   static float clamp(float x, float lo, float hi) { return std::fmin(std::fmax(x, lo), hi); }
   static bool finite(float x) { return std::isfinite(x); }
   static float fma(float a, float b, float c) { return std::fma(a, b, c); }
+  static float floor(float x) { return std::floor(x); }
   static float big() { return 3.0e38f; }
 };
 template <> struct Real<double> {
@@ -188,6 +189,7 @@ template <> struct Real<double> {
   static double clamp(double x, double lo, double hi) { return std::fmin(std::fmax(x, lo), hi); }
   static bool finite(double x) { return std::isfinite(x); }
   static double fma(double a, double b, double c) { return std::fma(a, b, c); }
+  static double floor(double x) { return std::floor(x); }
   static double big() { return 1.0e300; }
 };
 

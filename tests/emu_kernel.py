@@ -24,11 +24,11 @@ def load(variant=''):
   lib.solo_emu_step.restype = C.c_int
   lib.solo_emu_step.argtypes = [C.POINTER(abi.SoloConfig), C.POINTER(abi.SoloModel), C.c_void_p,
                                 C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_void_p,
-                                C.c_void_p, dp, C.c_uint32]
+                                C.c_void_p, dp, C.c_uint32, C.c_void_p]
   lib.solo_emu_rollout.restype = C.c_int
   lib.solo_emu_rollout.argtypes = [C.POINTER(abi.SoloConfig), C.POINTER(abi.SoloModel), C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_void_p,
-                                   C.c_void_p, dp, C.c_uint32]
+                                   C.c_void_p, dp, C.c_uint32, C.c_void_p]
   return lib
 
 
@@ -40,8 +40,9 @@ def _dp(a):
 class EmuEngine:
   """Same call shape as gym_solo_amd.engine.Engine, numpy buffers, CPU emulation."""
 
-  def __init__(self, cfg, model, n, program=None, variant=''):
+  def __init__(self, cfg, model, n, program=None, variant='', terrain=None):
     self.lib = load(variant)
+    self.terrain = terrain
     self.cfg, self.model, self.n = cfg, model, n
     self.program = program
     self.state = np.zeros((n, abi.STATE_STRIDE))
@@ -72,7 +73,8 @@ class EmuEngine:
       C.cast(C.pointer(self.program), C.c_void_p) if self.program is not None else None,
       self.cfg.dtype, self.n, _dp(self.state), _dp(self.snapshot),
       _dp(a) if a is not None else None, _dp(self.targets), _dp(self.params), _dp(self.obs),
-      _dp(self.reward), self.done.ctypes.data, self.term_count.ctypes.data, _dp(self.stats), flags)
+      _dp(self.reward), self.done.ctypes.data, self.term_count.ctypes.data, _dp(self.stats), flags,
+      C.byref(self.terrain) if getattr(self, 'terrain', None) is not None else None)
     if rc:
       raise RuntimeError('emu step failed: %d' % rc)
 
@@ -89,7 +91,7 @@ class EmuEngine:
       C.cast(C.pointer(self.program), C.c_void_p) if self.program is not None else None,
       self.cfg.dtype, self.n, k, _dp(self.state), _dp(self.snapshot), _dp(a), _dp(self.targets),
       _dp(self.params), _dp(obs), _dp(rew), done.ctypes.data, self.term_count.ctypes.data,
-      _dp(self.stats), flags)
+      _dp(self.stats), flags, C.byref(self.terrain) if getattr(self, 'terrain', None) is not None else None)
     if rc:
       raise RuntimeError('emu rollout failed: %d' % rc)
     return obs, rew, done
@@ -130,6 +132,7 @@ class EmuTorchEngine:
     for name in ('state', 'snapshot', 'targets', 'params', 'reward', 'done', 'term_count'):
       setattr(self, name, torch.from_numpy(getattr(self._e, name)))
     self.stats_shards = torch.from_numpy(self._e.stats)
+    self.done_bool = self.done.view(torch.bool)
     self.obs = None
 
   def set_program(self, program):

@@ -18,3 +18,25 @@ def make_abi(dtype='float64', normalize_actions=False, **kw):
 
 def random_actions(rng, n, scale=2 * np.pi):
   return rng.uniform(-scale, scale, (n, abi.NUM_JOINTS))
+
+
+def incline_terrain(deg=10.0, n=64, cell=0.05):
+  """BASELINE configs[4] (i): a plane inclined about the y axis, as a 64x64 heightfield."""
+  from gym_solo_amd import abi
+  xs = (np.arange(n) - 0.5 * (n - 1)) * cell
+  h = np.tile(np.tan(np.radians(deg)) * xs, (n, 1))
+  return abi.make_terrain(h, cell)
+
+
+def stairs_terrain(rise=0.03, run=0.30, n=64, cell=0.05):
+  """BASELINE configs[4] (ii): stairs climbing along +x (0.03 m rise / 0.30 m run)."""
+  from gym_solo_amd import abi
+  xs = (np.arange(n) - 0.5 * (n - 1)) * cell
+  h = np.tile(rise * np.floor(xs / run + 0.5), (n, 1))
+  return abi.make_terrain(h, cell)
+
+
+def bumpy_terrain(seed=0, n=64, cell=0.05, amp=0.02):
+  from gym_solo_amd import abi
+  rng = np.random.default_rng(seed)
+  return abi.make_terrain(amp * rng.standard_normal((n, n)), cell)

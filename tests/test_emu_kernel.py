@@ -72,3 +72,46 @@ def test_ubsan_build_runs_clean():
   for k in range(6):
     e.step(rng.uniform(-6, 6, (2, 12)))
   assert np.isfinite(e.state).all() and np.isfinite(e.obs).all()
+
+
+@pytest.mark.parametrize('kind', ['incline', 'stairs', 'bumpy'])
+def test_heightfield_terrain_matches_oracle(kind):
+  """BASELINE configs[4]: sphere vs heightfield tangent plane (bilinear height + normal lookup per
+  collision sphere); emulated kernel vs the oracle, robots dropped onto the terrain."""
+  import helpers
+  terrain = getattr(helpers, kind + '_terrain')()
+  ca, ma = make_abi('float64', settle_steps=0)
+  ph = so.OraclePhysics(ca, ma, terrain=terrain)
+  n = 2
+  st = ph.initial_state(n)
+  st[:, abi.S_POS + 2] = 0.12  # folded legs, just above the ground: contacts within a few steps
+  st[:, abi.S_Q:abi.S_Q + 8] = [np.pi / 2, np.pi, np.pi / 2, np.pi, -np.pi / 2, -np.pi, -np.pi / 2, -np.pi]
+  st[1, abi.S_POS] = 0.4
+  st[1, abi.S_POS + 2] = 0.25
+  st[1, abi.S_QUAT:abi.S_QUAT + 4] = [0.1, -0.2, 0.3, 0.9273618495495703]
+  e = EmuEngine(ca, ma, n, terrain=terrain)
+  e.state[:] = st
+  rng = np.random.default_rng(3)
+  touched = 0
+  for k in range(150):
+    a = np.array([np.pi / 2, np.pi, 0, np.pi / 2, np.pi, 0, -np.pi / 2, -np.pi, 0, -np.pi / 2, -np.pi, 0]) + rng.uniform(-1, 1, (n, 12))
+    ph.step(st, a)
+    e.step(a, abi.STEP_PHYSICS)
+  np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=1e-9)
+  # the robots really are resting on / colliding with the terrain, not falling through it
+  assert st[:, abi.S_POS + 2].min() > -0.2 and np.abs(st[:, abi.S_LINVEL + 2]).max() < 3.0
+
+
+def test_zero_heightfield_equals_flat_plane():
+  from gym_solo_amd import abi as _abi
+  ca, ma = make_abi('float64', settle_steps=0)
+  flat = _abi.make_terrain(np.zeros((8, 8)), 0.5)
+  a, b = EmuEngine(ca, ma, 1), EmuEngine(ca, ma, 1, terrain=flat)
+  for e in (a, b):
+    e.state[0, abi.S_POS + 2] = 0.1
+  rng = np.random.default_rng(5)
+  for k in range(40):
+    act = rng.uniform(-2, 2, (1, 12))
+    a.step(act, abi.STEP_PHYSICS)
+    b.step(act, abi.STEP_PHYSICS)
+  np.testing.assert_allclose(a.state, b.state, rtol=0, atol=1e-12)

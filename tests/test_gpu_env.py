@@ -202,3 +202,80 @@ def test_client_facade_pull_path_equals_fused_step():
   assert float(q.abs().max()) == 0.0 and float(qd.abs().max()) == 0.0
   assert env_b.client.getNumJoints(env_b.robot) == 12
   assert env_b.client.getJointInfo(env_b.robot, 4)[1] == b'FR_KFE'
+
+
+@pytest.mark.parametrize('kind', ['incline', 'stairs'])
+def test_heightfield_terrain_matches_oracle(kind):
+  """BASELINE configs[4]: 10 degree incline / 0.03 m x 0.30 m stairs as a 64x64 heightfield.
+  Settle (drop from 0.5 m onto the terrain + fold) and a random rollout, f64 engine vs oracle."""
+  import torch
+  import helpers
+  from gym_solo_amd import abi
+  from gym_solo_amd.engine import Engine
+  from oracle import solo_oracle as so
+  terrain = getattr(helpers, kind + '_terrain')()
+  ca, ma = helpers.make_abi('float64')
+  n = 16
+  eng = Engine(ca, ma, n)
+  flat_snapshot = eng.snapshot.cpu().numpy().copy()
+  eng.set_terrain(terrain)
+  ph = so.OraclePhysics(ca, ma, terrain=terrain)
+  st = ph.settle(1)
+  snap = eng.snapshot.cpu().numpy()
+  np.testing.assert_allclose(snap[:, :29], np.tile(st[:, :29], (n, 1)), rtol=0, atol=1e-8)
+  assert np.abs(snap[0, :7] - flat_snapshot[0, :7]).max() > 1e-3  # the ground really changed
+  st = np.tile(st, (n, 1))
+  rng = np.random.default_rng(9)
+  for k in range(40):
+    a = rng.uniform(-2 * np.pi, 2 * np.pi, (n, 12))
+    ph.step(st, a)
+    eng.step(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+  np.testing.assert_allclose(eng.state.cpu().numpy()[:, :29], st[:, :29], rtol=0, atol=1e-8)
+  eng.set_terrain(None)
+  np.testing.assert_array_equal(eng.snapshot.cpu().numpy(), flat_snapshot)
+  eng.close()
+
+
+def test_full_size_properties_f32():
+  """BASELINE-size batch (4096 robots, f32, stairs terrain, per-env friction / mass randomisation,
+  fused 50-step launches on 2 stream slices): size-independent properties — finite states, unit
+  quaternions, nobody falls through the ground, joint rates bounded, reset restores the snapshot,
+  and a replay from the same state is bit-identical (determinism, test_solo8v2vanilla.py:141-194)."""
+  import torch
+  import helpers
+  from gym_solo_amd import abi
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  cfg = Solo8VanillaConfig()
+  cfg.dtype, cfg._dtype_pinned, cfg.steps_per_launch, cfg.rollout_streams = 'float32', True, 50, 2
+  t = helpers.stairs_terrain()
+  cfg.terrain = t
+  make_env.num_envs = 4096
+  try:
+    env = make_env(config=cfg)
+  finally:
+    make_env.num_envs = 64
+  cases.register_benchmark_workload(env, max_steps=1000)
+  env._ensure_program()
+  eng = env.engine
+  g = torch.Generator(device='cuda').manual_seed(4321)
+  eng.set_params(abi.PARAM_FRICTION, torch.rand(4096, device='cuda', generator=g) * 0.7 + 0.3)
+  eng.set_params(abi.PARAM_BASE_MASS_SCALE, torch.rand(4096, device='cuda', generator=g) * 0.4 + 0.8)
+  eng.settle()
+  acts = (torch.rand(200, 4096, 12, device='cuda', generator=g) * 2 - 1) * (2 * np.pi)
+  obs, rew, done = eng.rollout(acts, abi.STEP_ALL, record=True)
+  st = eng.state.clone()
+  assert torch.isfinite(st).all() and torch.isfinite(obs).all() and torch.isfinite(rew).all()
+  np.testing.assert_allclose(st[:, 3:7].norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+  assert float(st[:, 2].min()) > -0.25 and float(st[:, 2].max()) < 3.0
+  assert float(st[:, 21:29].abs().max()) < 500 and float((rew < -1e-6).sum()) == 0 and not bool(done.any())
+  stats = eng.stats.cpu().numpy()
+  assert stats[5] == 0 and stats[6] == 0   # nothing diverged, never more than 12 touching spheres
+  # determinism: same start state + same actions -> identical bits
+  eng.reset()
+  eng.rollout(acts[:50], abi.STEP_ALL)
+  a = eng.state.clone()
+  eng.reset()
+  np.testing.assert_array_equal(eng.state.cpu().numpy(), eng.snapshot.cpu().numpy())
+  eng.rollout(acts[:50], abi.STEP_ALL)
+  assert torch.equal(a, eng.state)
+  env._close()
