@@ -61,9 +61,18 @@ class Solo8BaseConfig:
 
   @property
   def urdf(self):
-    # The reference resolves a packaged URDF (configs.py:36-38); the batched engine takes
-    # compiled model constants instead (gym_solo_amd/model.py).
-    raise NotImplementedError('the batched engine uses gym_solo_amd.model.Solo8Model')
+    """Path of the robot URDF if one is available, else None (configs.py:36-38 resolves a file
+    packaged from the WPI-MMR/assets submodule, which is empty in the reference checkout; the
+    engine then uses the built-in constants of gym_solo_amd/model.py).  ``urdf_path`` may be
+    absolute or relative to the gym_solo_amd package."""
+    import os
+    path = getattr(self, 'urdf_path', None)
+    if not path:
+      return None
+    for cand in (path, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)):
+      if os.path.isfile(cand):
+        return cand
+    return None
 
 
 def euler_to_quat(euler) -> Tuple[float, float, float, float]:

@@ -51,6 +51,11 @@ class Solo8VanillaEnv(Solo8BaseEnv):
                      normalize_observations=normalize_observations)
 
   def build_model(self):
+    """loadURDF(self.config.urdf, ...) (solo8v2vanilla.py:151-155) when the file exists, else the
+    built-in solo8v2 constants."""
+    if self.config.urdf:
+      from gym_solo_amd.urdf import load_urdf
+      return load_urdf(self.config.urdf)
     return Solo8Model()
 
   def create_engine(self):

@@ -133,54 +133,68 @@ class Solo8Model:
     return self.base_mass + 4 * (self.upper_mass + self.lower_mass + self.foot_mass)
 
   # ---- flattened for the C-ABI -----------------------------------------------------
-  def to_abi(self) -> abi.SoloModel:
-    m = abi.SoloModel()
-    def put6(dst, I):
-      for k, (a, b) in enumerate(((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))):
-        dst[k] = float(I[a, b])
-    m.mass[0] = self.base_mass
-    for a in range(3):
-      m.com[0][a] = 0.0
-    put6(m.inertia[0], np.diag(self.base_I))
-    for leg in range(abi.NUM_LEGS):
-      ju, jl = 2 * leg, 2 * leg + 1
-      bu, bl = 1 + ju, 1 + jl
-      m.parent[ju] = 0
-      m.parent[jl] = bu
-      for a in range(3):
-        m.joint_origin[ju][a] = self.hip_origin(leg)[a]
-        m.joint_origin[jl][a] = self.knee_origin(leg)[a]
-        m.joint_axis[ju][a] = (0.0, 1.0, 0.0)[a]
-        m.joint_axis[jl][a] = (0.0, 1.0, 0.0)[a]
-      for b, li in ((bu, self.upper(leg)), (bl, self.lower_with_foot(leg))):
-        m.mass[b] = li.mass
-        for a in range(3):
-          m.com[b][a] = li.com[a]
-        put6(m.inertia[b], li.inertia)
-      m.dof_to_joint[ju] = DOF_TO_JOINT[ju]
-      m.dof_to_joint[jl] = DOF_TO_JOINT[jl]
-    # spheres, 4 per leg l (model order = contact solve order): 4l knee (lower-leg origin),
-    # 4l+1 foot, 4l+2 / 4l+3 the two base-box corners (bottom, top) next to that leg's hip
+  def base(self) -> LinkInertial:
+    return LinkInertial(self.base_mass, np.zeros(3), np.diag(self.base_I))
+
+  def spheres(self):
+    """Collision spheres as (body, centre in body frame, radius), 4 per leg l in contact-solve
+    order: 4l knee (lower-leg origin), 4l+1 foot (ankle origin), 4l+2 / 4l+3 the two base-box
+    corners (bottom, top) next to that leg's hip.  body: 0 = base, 1+2l = upper, 2+2l = lower."""
     hx, hy, hz = self.base_sphere_half_extents
+    out = []
     for leg in range(abi.NUM_LEGS):
       sx, sy = self.leg_signs(leg)
-      k, f = 4 * leg, 4 * leg + 1
-      m.sphere_body[k] = 2 + 2 * leg
+      out.append((2 + 2 * leg, np.zeros(3), self.knee_radius))
+      out.append((2 + 2 * leg, self.ankle_origin(leg), self.foot_radius))
+      for sz in (-1, 1):
+        out.append((0, np.array([sx * hx, sy * hy, sz * hz]), self.base_sphere_radius))
+    return out
+
+  # ---- flattened for the C-ABI -----------------------------------------------------
+  def to_abi(self) -> abi.SoloModel:
+    return model_to_abi(self)
+
+
+def model_to_abi(model) -> abi.SoloModel:
+  """Flatten any object with the Solo8 accessor interface (base(), upper(leg), lower_with_foot(leg),
+  hip_origin(leg), knee_origin(leg), spheres()) — Solo8Model or urdf.UrdfSolo8Model — into the
+  C-ABI struct."""
+  m = abi.SoloModel()
+  def put6(dst, I):
+    for k, (a, b) in enumerate(((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))):
+      dst[k] = float(I[a, b])
+  base = model.base()
+  m.mass[0] = base.mass
+  for a in range(3):
+    m.com[0][a] = float(base.com[a])
+  put6(m.inertia[0], base.inertia)
+  for leg in range(abi.NUM_LEGS):
+    ju, jl = 2 * leg, 2 * leg + 1
+    bu, bl = 1 + ju, 1 + jl
+    m.parent[ju] = 0
+    m.parent[jl] = bu
+    for a in range(3):
+      m.joint_origin[ju][a] = model.hip_origin(leg)[a]
+      m.joint_origin[jl][a] = model.knee_origin(leg)[a]
+      m.joint_axis[ju][a] = (0.0, 1.0, 0.0)[a]
+      m.joint_axis[jl][a] = (0.0, 1.0, 0.0)[a]
+    for b, li in ((bu, model.upper(leg)), (bl, model.lower_with_foot(leg))):
+      m.mass[b] = li.mass
       for a in range(3):
-        m.sphere_center[k][a] = 0.0
-      m.sphere_radius[k] = self.knee_radius
-      m.sphere_body[f] = 2 + 2 * leg
-      for a in range(3):
-        m.sphere_center[f][a] = self.ankle_origin(leg)[a]
-      m.sphere_radius[f] = self.foot_radius
-      for q, sz in enumerate((-1, 1)):
-        b = 4 * leg + 2 + q
-        m.sphere_body[b] = 0
-        for a, v in enumerate((sx * hx, sy * hy, sz * hz)):
-          m.sphere_center[b][a] = v
-        m.sphere_radius[b] = self.base_sphere_radius
-    m.num_spheres = 16
-    return m
+        m.com[b][a] = li.com[a]
+      put6(m.inertia[b], li.inertia)
+    m.dof_to_joint[ju] = DOF_TO_JOINT[ju]
+    m.dof_to_joint[jl] = DOF_TO_JOINT[jl]
+  sph = model.spheres()
+  if len(sph) != abi.MAX_SPHERES:
+    raise ValueError('the engine expects {} collision spheres'.format(abi.MAX_SPHERES))
+  for s, (body, center, radius) in enumerate(sph):
+    m.sphere_body[s] = int(body)
+    for a in range(3):
+      m.sphere_center[s][a] = float(center[a])
+    m.sphere_radius[s] = float(radius)
+  m.num_spheres = len(sph)
+  return m
 
 
 def _principal_rotation(I: np.ndarray) -> np.ndarray:

@@ -75,3 +75,37 @@ def test_gui_and_realtime_flags():
   with mock.patch('time.sleep', return_value=None) as sl:
     env.step(env.action_space.sample())
     assert sl.called  # gym_solo/envs/test_solo8v2vanilla.py:37-48
+
+
+def test_make_and_vector_adapter(monkeypatch):
+  """gym_solo/__init__.py:3-11 ids + a VectorEnv-style adapter over the in-kernel auto-reset."""
+  import torch
+  import gym_solo_amd
+  from gym_solo_amd.envs import solo8v2vanilla
+  from gym_solo_amd.vector import Solo8VectorEnv
+  from gym_solo_amd.core import obs as solo_obs, termination as terms
+  from gym_solo_amd.testing import SimpleReward
+  with pytest.raises(ValueError):
+    gym_solo_amd.make('solo8vanilla-realtime-v0')
+  with pytest.raises(ValueError):
+    gym_solo_amd.make('nope-v0')
+  monkeypatch.setitem(gym_solo_amd._REGISTRY, 'solo8vanilla-v0', 'test_env_host:EmuSolo8VanillaEnv')
+  cfg = solo8v2vanilla.Solo8VanillaConfig()
+  cfg.dtype, cfg.num_envs, cfg.auto_reset = 'float64', 2, True
+  env = gym_solo_amd.make('solo8vanilla-v0', config=cfg)
+  env.obs_factory.register_observation(solo_obs.TorsoIMU(env.robot))
+  env.reward_factory.register_reward(1, SimpleReward())
+  env.termination_factory.register_termination(terms.TimeBasedTermination(2))
+  venv = Solo8VectorEnv(env)
+  assert venv.num_envs == 2 and venv.observation_space.shape == (2, 9) and venv.action_space.shape == (2, 12)
+  obs0, info = venv.reset(seed=3)
+  assert obs0.shape == (2, 9) and info == {}
+  flags = []
+  for k in range(6):
+    o, r, terminated, truncated, info = venv.step(torch.zeros(2, 12, dtype=torch.float64))
+    flags.append((bool(terminated.any()), bool(truncated.all())))
+  assert flags == [(False, False), (False, False), (False, True)] * 2  # time limit -> truncation
+  cfg2 = solo8v2vanilla.Solo8VanillaConfig()
+  cfg2.dtype, cfg2.num_envs = 'float64', 2
+  with pytest.raises(ValueError):
+    Solo8VectorEnv(make_env(config=cfg2))

@@ -1,0 +1,47 @@
+"""URDF loader: write the built-in constants as URDF, load them back, and check
+the C-ABI model and the reference's getJointInfo fixture are reproduced from the FILE."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gym_solo_amd import abi
+from gym_solo_amd.model import Solo8Model, pybullet_joint_info
+from gym_solo_amd.urdf import load_urdf, parse_urdf, to_urdf
+
+
+def test_round_trip_reproduces_abi_model(tmp_path):
+  path = tmp_path / 'solo.urdf'
+  path.write_text(to_urdf(Solo8Model()))
+  loaded = load_urdf(str(path))
+  a, b = Solo8Model().to_abi(), loaded.to_abi()
+  assert bytes(C.string_at(C.addressof(a), C.sizeof(a))) == bytes(C.string_at(C.addressof(b), C.sizeof(b)))
+  assert loaded.total_mass == pytest.approx(Solo8Model().total_mass, rel=1e-15)
+
+
+def test_fixture_reproduced_from_urdf():
+  fixture = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'joint_info_fixture.json')))
+  info = pybullet_joint_info(parse_urdf(to_urdf()))
+  for f, o in zip(fixture['joint_info'], info):
+    assert o[1].decode() == f[1] and o[2] == f[2] and o[16] == f[16]
+    np.testing.assert_allclose(o[13], f[13], atol=2e-5)
+    np.testing.assert_allclose(o[14], f[14], atol=2e-6)
+    np.testing.assert_allclose(o[15], f[15], atol=2e-5)
+
+
+def test_modified_urdf_changes_the_model_and_bad_urdfs_are_rejected():
+  text = to_urdf()
+  heavier = parse_urdf(text.replace('<mass value="1.16115091"/>', '<mass value="2.0"/>'))
+  assert heavier.to_abi().mass[0] == 2.0
+  rotated = text.replace('<origin xyz="1.377e-05 0.01935853 -0.078707" rpy="0 0 0"/>',
+                         '<origin xyz="1.377e-05 0.01935853 -0.078707" rpy="0.3 0 0"/>', 1)
+  m = parse_urdf(rotated).to_abi()
+  assert abs(m.inertia[1][5] - Solo8Model().to_abi().inertia[1][5]) > 1e-5  # Iyz of the FL upper leg
+  with pytest.raises(ValueError):
+    parse_urdf(text.replace('<axis xyz="0 1 0"/>', '<axis xyz="1 0 0"/>', 1))
+  with pytest.raises(ValueError):
+    parse_urdf(text.replace('name="HR_ANKLE" type="fixed"', 'name="HR_ANKLE" type="revolute"'))
+  with pytest.raises(ValueError):
+    parse_urdf(text.replace('FL_KFE', 'FL_KNEE'))
