@@ -136,7 +136,8 @@ def main():
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
   torch.cuda.set_device(local_rank)
-  distributed = world > 1
+  # under torch.distributed.run the collective path is exercised even with one rank
+  distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or os.environ.get('SOLO_BENCH_FORCE_DIST') == '1'
   if distributed:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -170,7 +171,7 @@ def main():
   eng.rollout(acts, abi.STEP_ALL, out=out)
   # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI
   stats = all_reduce_stats(eng.stats - stats_before)
-  barrier()
+  barrier()  # (all_reduce_stats is a no-op without an initialised process group)
   elapsed = time.perf_counter() - t0
   t = torch.tensor([elapsed], dtype=torch.float64, device='cuda:%d' % local_rank)
   if distributed:

@@ -81,3 +81,51 @@ def test_single_step_f32(torch):
   assert err[:, :15].max() < 5e-6
   assert err[:, 15:29].max() < 5e-3
   eng.close()
+
+
+def _sway_actions(k, n):
+  """Smooth stand-up and sway (contact-rich, not chaotic)."""
+  t = k * 1e-3
+  a = np.zeros((n, 12))
+  amp = 0.25 * min(1.0, t / 0.3)
+  for leg in range(4):
+    s = 1.0 if leg < 2 else -1.0
+    a[:, 3 * leg] = s * (0.6 + amp * np.sin(2 * np.pi * 1.5 * t + leg))
+    a[:, 3 * leg + 1] = -s * (1.2 + amp * np.sin(2 * np.pi * 1.5 * t + leg))
+  return a
+
+
+@pytest.mark.parametrize('regime', ['rest', 'stand-sway'])
+def test_thousand_step_divergence_within_1e4(torch, regime):
+  """BASELINE target: <= 1e-4 relative joint-state divergence over 1000 steps.  It is checked
+  against the f64 CPU oracle (PyBullet is unavailable) in the two non-chaotic regimes: `rest`
+  (zero targets from the folded reset pose: the robot unfolds and stands at z = 0.337, the
+  reference's standing height) and a smooth contact-rich stand-and-sway.  The f32 engine stays
+  within 1e-4 on q and qd (base pose within 1e-3 of a metre), the f64 engine within 1e-9.
+  (Random U(-2pi, 2pi) flailing is chaotic: there round-off grows ~e^(50 t) in ANY arithmetic —
+  measured in tools/gpu_divergence.py, quoted in DESIGN.md.)"""
+  from gym_solo_amd.engine import Engine
+  from oracle import solo_oracle as so
+  n = 8
+  ca32, ma = make_abi('float32')
+  ca64, _ = make_abi('float64')
+  e32, e64 = Engine(ca32, ma, n), Engine(ca64, ma, n)
+  ph = so.OraclePhysics(ca64, ma)
+  st = e64.state.cpu().numpy().copy()
+  for k in range(1000):
+    a = np.zeros((n, 12)) if regime == 'rest' else _sway_actions(k, n)
+    ph.step(st, a)
+    e64.step(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+    e32.step(torch.as_tensor(a, device='cuda', dtype=torch.float32), abi.STEP_PHYSICS)
+  s64, s32 = e64.state.cpu().numpy(), e32.state.cpu().numpy().astype(np.float64)
+
+  def rel(x, sl):
+    return (np.abs(x[:, sl] - st[:, sl]).max(axis=1) / np.maximum(np.abs(st[:, sl]).max(axis=1), 1.0)).max()
+  q, qd, base = slice(7, 15), slice(21, 29), slice(0, 7)
+  assert rel(s64, q) < 1e-9 and rel(s64, qd) < 1e-9 and rel(s64, base) < 1e-9
+  assert rel(s32, q) < 1e-4 and rel(s32, qd) < 1e-4 and rel(s32, base) < 1e-3
+  assert 0.25 < np.median(st[:, 2]) < 0.36   # standing, not lying
+  if regime == 'rest':
+    assert abs(np.median(st[:, 2]) - 0.33698) < 2e-3  # examples/solo8_vanilla/interactive_pos_control.py:23
+  e32.close()
+  e64.close()
