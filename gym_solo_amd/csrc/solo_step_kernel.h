@@ -120,12 +120,22 @@ __device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
 //     v    = t + An[r] * sl[r]       (v_fma_f32)
 // `lane_r` is the lane that owns the row (compile-time for motors, an SGPR for contacts); SLOT is
 // the compile-time register slot of the row in An / sl.
+// The update is CONDITIONAL on the impulse really changing (scalar compare + branch): an unchanged
+// row is then an exact no-op - as in the delta form "u += B * 0" - instead of re-rounding v, so
+// saturated motor rows stop perturbing the candidates, the sweep reaches an exact fixed point in
+// finite precision, and `changed` lets the caller leave the iteration loop when a whole sweep
+// changed nothing (bit-identical to running the remaining sweeps).
 template <typename T, int SLOT>
-__device__ __forceinline__ void pgs_row(T& v, T lo, T hi, int lane_r, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
+__device__ __forceinline__ void pgs_row(T& v, T lo, T hi, int lane_r, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int& changed) {
   const T a = An[SLOT];
-  const T t = Real<T>::fma(-a, sl[SLOT], v);
-  sl[SLOT] = wave_readlane(Real<T>::clamp(v, lo, hi), lane_r);
-  v = Real<T>::fma(a, sl[SLOT], t);
+  const T old = sl[SLOT];
+  const T t = Real<T>::fma(-a, old, v);  // off the critical path; dropped if the row is unchanged
+  const T now = wave_readlane(Real<T>::clamp(v, lo, hi), lane_r);
+  if (wave_uniform_bits_differ(now, old)) {
+    v = Real<T>::fma(a, now, t);
+    sl[SLOT] = now;
+    changed = 1;
+  }
 }
 // -(ghat_me.ghat_r + [same leg] hhat_me.hhat_r) / A_me,me   (0 on the diagonal): the entry of
 // this lane's scaled Delassus row for the row owned by lane_r.  `me` = own whitened row (regs),
@@ -179,9 +189,9 @@ struct ForMotors {
     An[D] = wave_pin(delassus_entry<T>(rowvec, motor_lane(D), gh, hh, nid, lane));
     ForMotors<T, D + 1>::build(An, rowvec, gh, hh, nid, lane);
   }
-  static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
-    pgs_row<T, D>(v, -imp, imp, motor_lane(D), sl, An);
-    ForMotors<T, D + 1>::solve(v, imp, sl, An);
+  static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int& changed) {
+    pgs_row<T, D>(v, -imp, imp, motor_lane(D), sl, An, changed);
+    ForMotors<T, D + 1>::solve(v, imp, sl, An, changed);
   }
   static __device__ __forceinline__ T gather(T lam, const T (&sl)[kNumRowSlots], int lane) {
     return ForMotors<T, D + 1>::gather((lane == motor_lane(D)) ? sl[D] : lam, sl, lane);
@@ -190,20 +200,20 @@ struct ForMotors {
 template <typename T>
 struct ForMotors<T, SOLO_NUM_DOF> {
   static __device__ __forceinline__ void build(T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, T, int) {}
-  static __device__ __forceinline__ void solve(T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
+  static __device__ __forceinline__ void solve(T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots], int&) {}
   static __device__ __forceinline__ T gather(T lam, const T (&)[kNumRowSlots], int) { return lam; }
 };
 template <typename T, int C>
 struct ForContacts {
   static constexpr int S0 = SOLO_NUM_DOF + 3 * C;
   // normal row, then the two friction rows limited by mu * (fresh normal impulse)
-  static __device__ __forceinline__ void solve(int nc, const int (&cl)[kMaxContacts], T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots]) {
+  static __device__ __forceinline__ void solve(int nc, const int (&cl)[kMaxContacts], T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int& changed) {
     if (C >= nc) return;
-    pgs_row<T, S0>(v, T(0), Real<T>::big(), cl[C], sl, An);
+    pgs_row<T, S0>(v, T(0), Real<T>::big(), cl[C], sl, An, changed);
     const T lim = mu * sl[S0];
-    pgs_row<T, S0 + 1>(v, -lim, lim, cl[C] + 1, sl, An);
-    pgs_row<T, S0 + 2>(v, -lim, lim, cl[C] + 2, sl, An);
-    ForContacts<T, C + 1>::solve(nc, cl, v, mu, sl, An);
+    pgs_row<T, S0 + 1>(v, -lim, lim, cl[C] + 1, sl, An, changed);
+    pgs_row<T, S0 + 2>(v, -lim, lim, cl[C] + 2, sl, An, changed);
+    ForContacts<T, C + 1>::solve(nc, cl, v, mu, sl, An, changed);
   }
   static __device__ __forceinline__ T gather(int nc, const int (&cl)[kMaxContacts], T lam, const T (&sl)[kNumRowSlots], int lane) {
     if (C >= nc) return lam;
@@ -215,7 +225,7 @@ struct ForContacts {
 };
 template <typename T>
 struct ForContacts<T, kMaxContacts> {
-  static __device__ __forceinline__ void solve(int, const int (&)[kMaxContacts], T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots]) {}
+  static __device__ __forceinline__ void solve(int, const int (&)[kMaxContacts], T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots], int&) {}
   static __device__ __forceinline__ T gather(int, const int (&)[kMaxContacts], T lam, const T (&)[kNumRowSlots], int) { return lam; }
 };
 // touching spheres in solve order -> lanes of their normal rows: the set bits of the ballot,
@@ -564,8 +574,10 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   const int iters = wave_uniform(P->iterations);  // scalar trip count: keeps the loop (and sl[]) on the SALU side
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
-    ForMotors<T, 0>::solve(v, imp, sl, An);
-    ForContacts<T, 0>::solve(nc, cl, v, mu, sl, An);
+    int changed = 0;
+    ForMotors<T, 0>::solve(v, imp, sl, An, changed);
+    ForContacts<T, 0>::solve(nc, cl, v, mu, sl, An, changed);
+    if (!changed) break;  // exact fixed point: the remaining sweeps would be no-ops
   }
   SOLO_STAMP(B, 9);
   T lam = ForMotors<T, 0>::gather(T(0), sl, lane);

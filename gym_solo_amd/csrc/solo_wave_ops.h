@@ -27,6 +27,14 @@ __device__ __forceinline__ int wave_opaque_lane(int lane) {
 // pins a per-lane value: it is materialised at this point of the program (no instruction)
 __device__ __forceinline__ float wave_pin(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double wave_pin(double x) { asm volatile("" : "+v"(x)); return x; }
+// both arguments are wave-uniform (SGPRs): integer compare of the bit patterns on the SALU
+__device__ __forceinline__ bool wave_uniform_bits_differ(float a, float b) {
+  return __builtin_amdgcn_readfirstlane(__float_as_int(a)) != __builtin_amdgcn_readfirstlane(__float_as_int(b));
+}
+__device__ __forceinline__ bool wave_uniform_bits_differ(double a, double b) {
+  const long long x = __double_as_longlong(a) ^ __double_as_longlong(b);
+  return (__builtin_amdgcn_readfirstlane((int)(x & 0xffffffffll)) | __builtin_amdgcn_readfirstlane((int)(x >> 32))) != 0;
+}
 // declares an int wave-uniform (v_readfirstlane -> SGPR)
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // compiler scheduling fence (no instruction): instructions are not moved across it

@@ -125,6 +125,8 @@ template <typename P> inline P* wave_opaque(P* p) { return p; }
 inline int wave_opaque_lane(int lane) { return lane; }
 template <typename T> inline T wave_pin(T x) { return x; }
 inline int wave_uniform(int x) { return x; }
+inline bool wave_uniform_bits_differ(float a, float b) { return std::memcmp(&a, &b, 4) != 0; }
+inline bool wave_uniform_bits_differ(double a, double b) { return std::memcmp(&a, &b, 8) != 0; }
 
 inline float wave_readlane(float x, int lane) {
   uint32_t b; std::memcpy(&b, &x, 4);
