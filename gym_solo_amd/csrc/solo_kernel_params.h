@@ -61,7 +61,9 @@ struct ObsElemK {
 
 template <typename T>
 struct RewardInstrK {
-  int32_t op, pad;
+  int32_t op;
+  int32_t src;  // three-address form of the postfix program: src0 | src1 << 8 = indices of the
+                // instructions whose results this one consumes (SCALE: src0; ADD / MUL: both)
   T a, b, c;
 };
 
@@ -193,12 +195,23 @@ inline int pack_program(const SoloProgram& p, KParams<T>* k, std::string* err) {
   if (p.num_terms < 0 || p.num_terms > SOLO_MAX_TERMS) return fail("num_terms out of range");
   // the reward program must be a well-formed postfix expression leaving one value
   int depth = 0;
+  int stack[SOLO_MAX_REWARD_OPS];  // instruction index that produced each stack entry
+  int srcs[SOLO_MAX_REWARD_OPS];
   for (int i = 0; i < p.num_reward_ops; ++i) {
     const int op = p.reward[i].op;
+    srcs[i] = 0;
     if (op < SOLO_R_CONST || op > SOLO_R_MUL) return fail("bad reward opcode");
-    if (op <= SOLO_R_SMALL_CONTROL) ++depth;
-    else if (op == SOLO_R_SCALE) { if (depth < 1) return fail("reward stack underflow"); }
-    else { if (depth < 2) return fail("reward stack underflow"); --depth; }
+    if (op <= SOLO_R_SMALL_CONTROL) stack[depth++] = i;
+    else if (op == SOLO_R_SCALE) {
+      if (depth < 1) return fail("reward stack underflow");
+      srcs[i] = stack[depth - 1];
+      stack[depth - 1] = i;
+    } else {
+      if (depth < 2) return fail("reward stack underflow");
+      srcs[i] = stack[depth - 2] | (stack[depth - 1] << 8);
+      --depth;
+      stack[depth - 1] = i;
+    }
     if (depth > 8) return fail("reward stack deeper than 8");
     if (op >= SOLO_R_FLAT_TORSO && op <= SOLO_R_SMALL_CONTROL) {
       // rewards.py:405-417: lower <= upper, margin >= 0
@@ -230,6 +243,7 @@ inline int pack_program(const SoloProgram& p, KParams<T>* k, std::string* err) {
   }
   for (int i = 0; i < p.num_reward_ops; ++i) {
     k->reward[i].op = p.reward[i].op;
+    k->reward[i].src = srcs[i];
     k->reward[i].a = (T)p.reward[i].a;
     k->reward[i].b = (T)p.reward[i].b;
     k->reward[i].c = (T)p.reward[i].c;

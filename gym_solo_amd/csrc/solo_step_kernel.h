@@ -525,7 +525,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   T diag = hh[0] * hh[0] + hh[1] * hh[1];
 #pragma unroll
   for (int i = 0; i < 6; ++i) diag += gh[i] * gh[i];
-  T inv_d = T(1) / diag;
+  T inv_d = R::rcp(diag);
   if (!live) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) gh[i] = T(0);
@@ -578,6 +578,9 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     ForMotors<T, 0>::solve(v, imp, sl, An, changed);
     ForContacts<T, 0>::solve(nc, cl, v, mu, sl, An, changed);
     if (!changed) break;  // exact fixed point: the remaining sweeps would be no-ops
+#ifdef SOLO_STAMPS
+    if (lane == 0) B.stamps[(size_t)(block_id() + B.env_base) * 16 + 15] = (unsigned long long)(it + 1) | ((unsigned long long)nc << 32);
+#endif
   }
   SOLO_STAMP(B, 9);
   T lam = ForMotors<T, 0>::gather(T(0), sl, lane);
@@ -629,7 +632,7 @@ __device__ __forceinline__ void physics_finish(const KParams<T>* __restrict__ P,
   const T th = R::sqrt(dot(wn, wn)) * dt;
   T sh, ch;
   R::sincos(T(0.5) * th, &sh, &ch);
-  const T sc = (th > T(1e-12)) ? sh / th * dt : T(0.5) * dt;
+  const T sc = (th > T(1e-12)) ? sh * R::rcp(th) * dt : T(0.5) * dt;
   const T dx = wn.x * sc, dy = wn.y * sc, dz = wn.z * sc, dw = ch;
   T nx = dw * qx + dx * qw + dy * qz - dz * qy;
   T ny = dw * qy - dx * qz + dy * qw + dz * qx;
@@ -669,7 +672,11 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][20];
   __shared__ T s_src[48];
-  __shared__ T s_stack[8];
+  // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
+  // read them from LDS instead of paying a global-load latency each
+  __shared__ LegConst<T> s_legc[4];
+  __shared__ RowConst<T> s_rowc[64];
+  __shared__ ObsElemK<T> s_obsc[SOLO_MAX_OBS];
   __shared__ RewardInstrK<T> s_rprog[SOLO_MAX_REWARD_OPS];
 
   const int lane0 = lane_id();
@@ -682,7 +689,25 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   double* stats = B.stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH;
 
   const KParams<T>* __restrict__ const P0 = Pin;
-  if ((B.flags & SOLO_STEP_REWARD) && lane0 < SOLO_MAX_REWARD_OPS) s_rprog[lane0] = P0->reward[lane0];
+  {
+    constexpr int kLegWords = (int)(sizeof(LegConst<T>) * 4 / sizeof(T));
+    const T* src = reinterpret_cast<const T*>(P0->leg);
+    T* dst = reinterpret_cast<T*>(s_legc);
+    for (int i = lane0; i < kLegWords; i += 64) dst[i] = src[i];
+    s_rowc[lane0] = P0->row[lane0];
+    if (B.flags & SOLO_STEP_OBS) s_obsc[lane0] = P0->obs[lane0];
+  }
+  // reward program: lane i owns instruction i (leaves are evaluated lane-parallel)
+  const int n_rops = (B.flags & SOLO_STEP_REWARD) ? wave_uniform(P0->num_reward_ops) : 0;
+  if (lane0 < SOLO_MAX_REWARD_OPS) {
+    RewardInstrK<T> r0;
+    r0.op = -1; r0.src = 0; r0.a = r0.b = r0.c = T(0);
+    if (lane0 < n_rops) r0 = P0->reward[lane0];
+    s_rprog[lane0] = r0;
+  }
+  // next step's action of this lane's joint, fetched one step ahead
+  T act_next = T(0);
+  if (B.actions != nullptr && lane0 < SOLO_NUM_JOINTS) act_next = B.actions[(size_t)env * SOLO_NUM_JOINTS + lane0];
   if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = B.state[rec + lane0];
   const T mu = B.params[(size_t)env * 4 + 0];
   const T mass_scale = B.params[(size_t)env * 4 + 1];
@@ -701,13 +726,15 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     const KParams<T>* __restrict__ P = wave_opaque(P0);  // NB: values loaded through it that steer
     // control flow must be re-declared uniform (wave_uniform), or loops turn divergent
     const int lane = wave_opaque_lane(lane0);  // same reason: per-lane address arithmetic stays in the step
-    const LegConst<T>& L = P->leg[lane >> 4];
-    const RowConst<T>& rc = P->row[lane];
+    const LegConst<T>& L = s_legc[lane >> 4];
+    const RowConst<T>& rc = s_rowc[lane];
     if (lane < SOLO_NUM_JOINTS) {
       T t;
       if (B.actions != nullptr) {
         // action de-normalisation (solo8v2vanilla.py:84-85) + setJointMotorControlArray (:87-90)
-        t = B.actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * P->action_scale;
+        t = act_next * P->action_scale;
+        if (step + 1 < B.steps)
+          act_next = B.actions[(size_t)(step + 1) * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane];
         if (step == B.steps - 1) B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = t;
       } else {
         t = B.targets[(size_t)env * SOLO_NUM_JOINTS + lane];
@@ -752,7 +779,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
       }
       wave_sync();
       if (lane < P->num_obs) {
-        const ObsElemK<T>& e = P->obs[lane];
+        const ObsElemK<T>& e = s_obsc[lane];
         T v = s_src[e.src] * e.scale;
         if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
         if (e.flags & 2) v = (T(2) * (v - e.nlo)) / e.range - T(1);
@@ -761,43 +788,42 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     }
 
     SOLO_STAMP(B, 11);
-    // ---- reward: postfix program, evaluated redundantly by every lane (wave-uniform) ---------
+    // ---- reward: lane i evaluates leaf instruction i (all leaves at once: one tolerance() for
+    //      the wave), then the SCALE / ADD / MUL instructions are folded in program order with
+    //      v_readlane fetches of their operands (three-address form prepared on the host) ---------
     T reward = T(0);
-    if (B.flags & SOLO_STEP_REWARD) {
-      int sp = 0;
-      for (int i = 0; i < P->num_reward_ops; ++i) {
-        const RewardInstrK<T> in = s_rprog[i];
-        const T gs = P->gauss_scale;
-        switch (in.op) {
-          case SOLO_R_CONST: s_stack[sp++] = in.a; break;
-          case SOLO_R_UPRIGHT: {
-            const T fu = T(-1.5707963267948966);
-            s_stack[sp++] = fu * pitch / (fu * fu);
-          } break;
-          case SOLO_R_FLAT_TORSO:
-            s_stack[sp++] = tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -in.a, in.a, in.b, gs);
-            break;
-          case SOLO_R_TORSO_HEIGHT:
-            s_stack[sp++] = tolerance<T>(s_state[SOLO_S_POS + 2], in.a - in.b, in.a + in.b, in.c, gs);
-            break;
-          case SOLO_R_HORIZ_SPEED: {
-            const T vx = s_state[SOLO_S_LINVEL], vy = s_state[SOLO_S_LINVEL + 1];
-            s_stack[sp++] = tolerance<T>(R::sqrt(vx * vx + vy * vy), in.a - in.b, in.a + in.b, in.c, gs);
-          } break;
-          case SOLO_R_SMALL_CONTROL: {
-            T sum = T(0);
+    if (n_rops > 0) {
+      const RewardInstrK<T> rin = s_rprog[lane & (SOLO_MAX_REWARD_OPS - 1)];
+      const T gs = P->gauss_scale;
+      const T vx = s_state[SOLO_S_LINVEL], vy = s_state[SOLO_S_LINVEL + 1];
+      T sum = T(0);
 #pragma unroll
-            for (int j = 0; j < SOLO_NUM_DOF; ++j) sum += R::abs(s_state[SOLO_S_QD + j]);
-            // mean over all 12 pybullet joints incl. the 4 fixed ones (rewards.py:297-300)
-            s_stack[sp++] = tolerance<T>(sum / T(SOLO_NUM_JOINTS), T(0), T(0), in.a, gs);
-          } break;
-          case SOLO_R_SCALE: s_stack[sp - 1] = in.a * s_stack[sp - 1]; break;
-          case SOLO_R_ADD: s_stack[sp - 2] = s_stack[sp - 2] + s_stack[sp - 1]; --sp; break;
-          case SOLO_R_MUL: s_stack[sp - 2] = s_stack[sp - 2] * s_stack[sp - 1]; --sp; break;
-          default: break;
+      for (int j = 0; j < SOLO_NUM_DOF; ++j) sum += R::abs(s_state[SOLO_S_QD + j]);
+      // argument and bounds of this lane's tolerance() (rewards.py:256-269,290-301,326-338,362-373)
+      T x = T(0), lo = T(0), hi = T(0), mg = T(1);
+      if (rin.op == SOLO_R_FLAT_TORSO) { x = R::sqrt(roll * roll + pitch * pitch); lo = -rin.a; hi = rin.a; mg = rin.b; }
+      else if (rin.op == SOLO_R_TORSO_HEIGHT) { x = s_state[SOLO_S_POS + 2]; lo = rin.a - rin.b; hi = rin.a + rin.b; mg = rin.c; }
+      else if (rin.op == SOLO_R_HORIZ_SPEED) { x = R::sqrt(vx * vx + vy * vy); lo = rin.a - rin.b; hi = rin.a + rin.b; mg = rin.c; }
+      else if (rin.op == SOLO_R_SMALL_CONTROL) { x = sum / T(SOLO_NUM_JOINTS); mg = rin.a; }  // mean over all 12 joints (rewards.py:297-300)
+      T val = tolerance<T>(x, lo, hi, mg, gs);
+      const T fu = T(-1.5707963267948966);
+      if (rin.op == SOLO_R_UPRIGHT) val = fu * pitch / (fu * fu);
+      if (rin.op == SOLO_R_CONST) val = rin.a;
+      for (int i = 0; i < n_rops; ++i) {
+        const int op = wave_readlane_int(rin.op, i);
+        if (op >= SOLO_R_SCALE) {
+          const int src = wave_readlane_int(rin.src, i);
+          const T x0 = wave_readlane(val, src & 255);
+          T res;
+          if (op == SOLO_R_SCALE) res = wave_readlane(rin.a, i) * x0;
+          else {
+            const T x1 = wave_readlane(val, (src >> 8) & 255);
+            res = (op == SOLO_R_ADD) ? (x0 + x1) : (x0 * x1);
+          }
+          val = (lane == i) ? res : val;
         }
       }
-      reward = s_stack[0];
+      reward = wave_readlane(val, n_rops - 1);
       if (lane == 0) B.reward[(size_t)step * B.reward_stride + env] = reward;
     }
 

@@ -27,6 +27,7 @@ __device__ __forceinline__ int wave_opaque_lane(int lane) {
 // pins a per-lane value: it is materialised at this point of the program (no instruction)
 __device__ __forceinline__ float wave_pin(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double wave_pin(double x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int wave_readlane_int(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
 // both arguments are wave-uniform (SGPRs): integer compare of the bit patterns on the SALU
 __device__ __forceinline__ bool wave_uniform_bits_differ(float a, float b) {
   return __builtin_amdgcn_readfirstlane(__float_as_int(a)) != __builtin_amdgcn_readfirstlane(__float_as_int(b));
@@ -96,10 +97,32 @@ template <typename T> __device__ __forceinline__ T wave_sum_group16(T x) {
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 
 template <typename T> struct Real;
+// f32: hardware v_sqrt / v_rsq / v_rcp (<= 1 ulp each) instead of the IEEE-correct library
+// sequences (~10-25 instructions apiece), and a Cody-Waite + minimax sincos (~25 instructions,
+// ~1 ulp for |x| < 1e4 rad; joint angles stay within +-20 rad) instead of libm's ~120-instruction
+// sincosf with its Payne-Hanek path.  The f64 instantiation keeps the precise library versions:
+// it is the parity path.
 template <> struct Real<float> {
-  static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
-  static __device__ __forceinline__ float rsqrt(float x) { return 1.0f / sqrtf(x); }
-  static __device__ __forceinline__ void sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+  static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ void sincos(float x, float* s, float* c) {
+    const float k = __builtin_rintf(x * 0.63661977236758134f);          // nearest multiple of pi/2
+    float r = __builtin_fmaf(k, -1.57079601287841796875f, x);           // pi/2 in three pieces
+    r = __builtin_fmaf(k, -3.1391647326017846e-07f, r);
+    r = __builtin_fmaf(k, -5.3903029534742385e-15f, r);
+    const float r2 = r * r;
+    float sp = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = __builtin_fmaf(r2, sp, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(r2 * r, sp, r);                     // sin(r), |r| <= pi/4
+    float cp = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(r2, cp, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(r2 * r2, cp, __builtin_fmaf(r2, -0.5f, 1.0f));  // cos(r)
+    const int q = (int)k;
+    const float a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    *s = (q & 2) ? -a : a;
+    *c = ((q + 1) & 2) ? -b : b;
+  }
   static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
   static __device__ __forceinline__ float asin(float x) { return asinf(x); }
   static __device__ __forceinline__ float exp(float x) { return expf(x); }
@@ -115,6 +138,7 @@ template <> struct Real<float> {
 template <> struct Real<double> {
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
   static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
   static __device__ __forceinline__ double asin(double x) { return ::asin(x); }

@@ -125,6 +125,7 @@ template <typename P> inline P* wave_opaque(P* p) { return p; }
 inline int wave_opaque_lane(int lane) { return lane; }
 template <typename T> inline T wave_pin(T x) { return x; }
 inline int wave_uniform(int x) { return x; }
+inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
 inline bool wave_uniform_bits_differ(float a, float b) { return std::memcmp(&a, &b, 4) != 0; }
 inline bool wave_uniform_bits_differ(double a, double b) { return std::memcmp(&a, &b, 8) != 0; }
 
@@ -165,6 +166,7 @@ template <typename T> struct Real;
 template <> struct Real<float> {
   static float sqrt(float x) { return std::sqrt(x); }
   static float rsqrt(float x) { return 1.0f / std::sqrt(x); }
+  static float rcp(float x) { return 1.0f / x; }
   static void sincos(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
   static float atan2(float y, float x) { return std::atan2(y, x); }
   static float asin(float x) { return std::asin(x); }
@@ -181,6 +183,7 @@ template <> struct Real<float> {
 template <> struct Real<double> {
   static double sqrt(double x) { return std::sqrt(x); }
   static double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+  static double rcp(double x) { return 1.0 / x; }
   static void sincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
   static double atan2(double y, double x) { return std::atan2(y, x); }
   static double asin(double x) { return std::asin(x); }

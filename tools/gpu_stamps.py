@@ -25,4 +25,9 @@ for n in (256, 4096):
   print(f'N={n}: median wave lifetime {tot} ticks, whole-grid span {span} ticks')
   for k, nm in enumerate(names):
     print(f'   {nm:14s} {med[k]:9.0f}  {100*med[k]/tot:5.1f}%')
+  its = (buf[:, 15] & 0xffffffff).astype(np.int64); ncs = (buf[:, 15] >> 32).astype(np.int64)
+  print('   sweeps executed: mean %.1f  hist(0,5,10,20,30,40,49,50)=%s' % (its.mean(), np.histogram(its, bins=[0,5,10,20,30,40,49,50,51])[0].tolist()))
+  for c in range(0, 8):
+    m = ncs == c
+    if m.any(): print('   nc=%d: %4d robots, mean sweeps %.1f, at cap %.0f%%, mean wave life %.0f' % (c, m.sum(), its[m].mean(), 100*(its[m]>=49).mean(), (buf[m,14].astype(np.int64)-buf[m,0].astype(np.int64)).mean()))
   env._close()
