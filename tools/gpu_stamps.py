@@ -25,6 +25,9 @@ for n in (256, 4096):
   print(f'N={n}: median wave lifetime {tot} ticks, whole-grid span {span} ticks')
   for k, nm in enumerate(names):
     print(f'   {nm:14s} {med[k]:9.0f}  {100*med[k]/tot:5.1f}%')
+  t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 14].astype(np.int64)
+  life = t1 - t0
+  print('   wave life percentiles 50/90/99/max: %s ; start skew (last start - first start) %d ; first start -> last end %d ticks' % (np.percentile(life, [50, 90, 99, 100]).astype(int).tolist(), t0.max() - t0.min(), t1.max() - t0.min()))
   its = (buf[:, 15] & 0xffffffff).astype(np.int64); ncs = (buf[:, 15] >> 32).astype(np.int64)
   print('   sweeps executed: mean %.1f  hist(0,5,10,20,30,40,49,50)=%s' % (its.mean(), np.histogram(its, bins=[0,5,10,20,30,40,49,50,51])[0].tolist()))
   for c in range(0, 8):
