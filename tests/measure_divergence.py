@@ -1,4 +1,5 @@
-"""GPU probe: divergence of the f32 engine (and of the f64 engine) from the f64 CPU oracle over 1000
+"""(measurement script, not collected by pytest; under tests/ because it uses the oracle)
+GPU probe: divergence of the f32 engine (and of the f64 engine) from the f64 CPU oracle over 1000
 steps in three regimes (not a test; numbers quoted in DESIGN.md)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

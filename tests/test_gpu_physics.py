@@ -103,7 +103,7 @@ def test_thousand_step_divergence_within_1e4(torch, regime):
   reference's standing height) and a smooth contact-rich stand-and-sway.  The f32 engine stays
   within 1e-4 on q and qd (base pose within 1e-3 of a metre), the f64 engine within 1e-9.
   (Random U(-2pi, 2pi) flailing is chaotic: there round-off grows ~e^(50 t) in ANY arithmetic —
-  measured in tools/gpu_divergence.py, quoted in DESIGN.md.)"""
+  measured in tests/measure_divergence.py, quoted in DESIGN.md.)"""
   from gym_solo_amd.engine import Engine
   from oracle import solo_oracle as so
   n = 8
