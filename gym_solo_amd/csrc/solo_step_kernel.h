@@ -42,6 +42,11 @@
 #define SOLO_STAMP(B, i) do {} while (0)
 #endif
 
+// test hook (CPU emulator builds only): called once per Gauss-Seidel sweep
+#ifndef SOLO_PGS_SWEEP_HOOK
+#define SOLO_PGS_SWEEP_HOOK(it, nc, sl, changed, v) do {} while (0)
+#endif
+
 namespace solo {
 
 template <typename T> struct V3 { T x, y, z; };
@@ -184,10 +189,16 @@ struct PickLane<kMaxContacts> {
 template <typename T, int D>
 struct ForMotors {
   static __device__ __forceinline__ void build(T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
-    // pinned: the entry is computed HERE, next to its two LDS row reads (otherwise the arithmetic
-    // sinks to the solver loop while all 16 row reads (64 VGPRs) stay up front and spill)
-    An[D] = wave_pin(delassus_entry<T>(rowvec, motor_lane(D), gh, hh, nid, lane));
-    ForMotors<T, D + 1>::build(An, rowvec, gh, hh, nid, lane);
+    // pinned, four at a time: the entries are computed HERE, next to their LDS row reads
+    // (otherwise the arithmetic sinks to the solver loop while all 16 row reads (64 VGPRs) stay
+    // up front and spill); a group's 8 reads are in flight together
+    static_assert(D % 4 == 0 && SOLO_NUM_DOF % 4 == 0, "motor entries are built in groups of four");
+    An[D] = delassus_entry<T>(rowvec, motor_lane(D), gh, hh, nid, lane);
+    An[D + 1] = delassus_entry<T>(rowvec, motor_lane(D + 1), gh, hh, nid, lane);
+    An[D + 2] = delassus_entry<T>(rowvec, motor_lane(D + 2), gh, hh, nid, lane);
+    An[D + 3] = delassus_entry<T>(rowvec, motor_lane(D + 3), gh, hh, nid, lane);
+    wave_pin_group(An[D], An[D + 1], An[D + 2], An[D + 3]);
+    ForMotors<T, D + 4>::build(An, rowvec, gh, hh, nid, lane);
   }
   static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int& changed) {
     pgs_row<T, D>(v, -imp, imp, motor_lane(D), sl, An, changed);
@@ -318,16 +329,18 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   const V3<T> wU = {om.x, om.y + qd1, om.z}, wL = {om.x, om.y + qd1 + qd2, om.z};
   const V3<T> aU = {-qd1 * om.z, T(0), qd1 * om.x};                       // om x (qd1 y)
   const V3<T> aL = {aU.x - qd2 * wU.z, T(0), aU.z + qd2 * wU.x};          // + wU x (qd2 y)
-  const V3<T> a_o1 = cross(om, cross(om, o1));
+  // centripetal terms as w x (w x r) = w (w.r) - |w|^2 r
+  const T om2 = dot(om, om), wU2 = dot(wU, wU), wL2 = dot(wL, wL);
+  const V3<T> a_o1 = dot(om, o1) * om - om2 * o1;
   const V3<T> d12 = o2 - o1;
-  const V3<T> a_cU = a_o1 + cross(aU, rU1) + cross(wU, cross(wU, rU1));
-  const V3<T> a_o2 = a_o1 + cross(aU, d12) + cross(wU, cross(wU, d12));
-  const V3<T> a_cL = a_o2 + cross(aL, rL2) + cross(wL, cross(wL, rL2));
+  const V3<T> a_cU = a_o1 + cross(aU, rU1) + (dot(wU, rU1) * wU - wU2 * rU1);
+  const V3<T> a_o2 = a_o1 + cross(aU, d12) + (dot(wU, d12) * wU - wU2 * d12);
+  const V3<T> a_cL = a_o2 + cross(aL, rL2) + (dot(wL, rL2) * wL - wL2 * rL2);
   const V3<T> v_cU = vb + cross(om, cU) + qd1 * tU1;
   const V3<T> v_cL = vb + cross(om, cL) + qd1 * tL1 + qd2 * tL2;
   const T kl = P->lin_damp, ka = P->ang_damp;
   const T dU = kl * (T(1) + R::sqrt(dot(v_cU, v_cU))), dL = kl * (T(1) + R::sqrt(dot(v_cL, v_cL)));
-  const T eU = ka * (T(1) + R::sqrt(dot(wU, wU))), eL = ka * (T(1) + R::sqrt(dot(wL, wL)));
+  const T eU = ka * (T(1) + R::sqrt(wU2)), eL = ka * (T(1) + R::sqrt(wL2));
   const V3<T> FU = mU * (a_cU - gb + dU * v_cU);
   const V3<T> FL = mL * (a_cL - gb + dL * v_cL);
   const V3<T> IwU = symmul(IU, wU), IwL = symmul(IL, wL);
@@ -360,11 +373,34 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   S[5][0] = mc.y;  S[5][1] = -mc.x; S[5][2] = T(0);
   S[3][3] = mleg; S[4][3] = T(0); S[4][4] = mleg; S[5][3] = T(0); S[5][4] = T(0); S[5][5] = mleg;
   T rhs[6] = {-Nleg.x, -Nleg.y, -Nleg.z, -Fleg.x, -Fleg.y, -Fleg.z};
+  // Sum of the 27 per-leg terms over the four legs, through LDS: one lane per leg posts its
+  // terms, lane e adds the four copies of term e, everyone reads the totals back as broadcasts
+  // (~30 instructions; 27 in-register cross-row sums cost six each).  The row-vector array is
+  // not live yet and serves as the scratch: part[4][28], tot[28].
+  {
+    T* part = &s_rowvec[0][0];
+    T* tot = part + 4 * 28;
+    if (k == 0) {
+      T* mine = part + leg * 28;
+      int o = 0;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < 6; ++i) {
 #pragma unroll
-    for (int j = 0; j <= i; ++j) S[i][j] = sum_over_legs(S[i][j] - W1[i] * W1[j] - W2[i] * W2[j]);
-    rhs[i] = sum_over_legs(rhs[i] + W1[i] * e1 + W2[i] * e2);
+        for (int j = 0; j <= i; ++j) mine[o++] = S[i][j] - W1[i] * W1[j] - W2[i] * W2[j];
+        mine[21 + i] = rhs[i] + W1[i] * e1 + W2[i] * e2;
+      }
+    }
+    wave_sync();
+    if (lane < 27) tot[lane] = (part[lane] + part[28 + lane]) + (part[56 + lane] + part[84 + lane]);
+    wave_sync();
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) S[i][j] = tot[o++];
+      rhs[i] = tot[21 + i];
+    }
+    // (the sync after parking the factors below orders these reads before the row phase's writes)
   }
   // the base body itself (mass / inertia scaled per env for domain randomisation)
   {
@@ -375,7 +411,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     S[0][0] += I0[0]; S[1][0] += I0[3]; S[1][1] += I0[1]; S[2][0] += I0[4]; S[2][1] += I0[5]; S[2][2] += I0[2];
     S[3][3] += m0; S[4][4] += m0; S[5][5] += m0;
     const V3<T> Iw = symmul(I0, om);
-    const V3<T> N0 = cross(om, Iw) + (ka * (T(1) + R::sqrt(dot(om, om)))) * Iw;
+    const V3<T> N0 = cross(om, Iw) + (ka * (T(1) + R::sqrt(om2))) * Iw;
     const V3<T> F0 = m0 * ((kl * (T(1) + R::sqrt(dot(vb, vb)))) * vb - gb);
     rhs[0] -= N0.x; rhs[1] -= N0.y; rhs[2] -= N0.z;
     rhs[3] -= F0.x; rhs[4] -= F0.y; rhs[5] -= F0.z;
@@ -557,9 +593,10 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
 #pragma unroll 1
   for (int c = 0; c < nc; ++c) {
     const int lr = PickLane<0>::run(c, cl);
-    const T e0 = wave_pin(delassus_entry<T>(s_rowvec, lr, gh, hh, nid, lane));
-    const T e1 = wave_pin(delassus_entry<T>(s_rowvec, lr + 1, gh, hh, nid, lane));
-    const T e2 = wave_pin(delassus_entry<T>(s_rowvec, lr + 2, gh, hh, nid, lane));
+    T e0 = delassus_entry<T>(s_rowvec, lr, gh, hh, nid, lane);
+    T e1 = delassus_entry<T>(s_rowvec, lr + 1, gh, hh, nid, lane);
+    T e2 = delassus_entry<T>(s_rowvec, lr + 2, gh, hh, nid, lane);
+    wave_pin_group(e0, e1, e2);
     StoreContactEntries<T, 0>::run(c, An, e0, e1, e2);
   }
   // (motor entries last, right before the solver that consumes them: keeps their rows' LDS
@@ -577,6 +614,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     int changed = 0;
     ForMotors<T, 0>::solve(v, imp, sl, An, changed);
     ForContacts<T, 0>::solve(nc, cl, v, mu, sl, An, changed);
+    SOLO_PGS_SWEEP_HOOK(it, nc, sl, changed, v);
     if (!changed) break;  // exact fixed point: the remaining sweeps would be no-ops
 #ifdef SOLO_STAMPS
     if (lane == 0) B.stamps[(size_t)(block_id() + B.env_base) * 16 + 15] = (unsigned long long)(it + 1) | ((unsigned long long)nc << 32);
@@ -598,7 +636,7 @@ __device__ __forceinline__ void physics_finish(const KParams<T>* __restrict__ P,
   const T dt = P->dt;
   T z[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) z[i] = sum_over_legs(sum_over_group16(s_rowvec[lane][i] * lam));
+  for (int i = 0; i < 6; ++i) z[i] = wave_sum_all(s_rowvec[lane][i] * lam);
   const T yl1 = sum_over_group16(s_rowvec[lane][6] * lam), yl2 = sum_over_group16(s_rowvec[lane][7] * lam);
   // C^T x = z (back substitution with the parked Cholesky factor)
 #pragma unroll
@@ -714,6 +752,15 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   int cnt[SOLO_MAX_TERMS];
 #pragma unroll
   for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = B.term_count[(size_t)env * SOLO_MAX_TERMS + t];
+  // termination program: a handful of wave-uniform ints, read once per launch (scalar registers)
+  const int n_terms = (B.flags & SOLO_STEP_DONE) ? wave_uniform(P0->num_terms) : 0;
+  const int auto_reset = wave_uniform(P0->auto_reset);
+  int term_kind[SOLO_MAX_TERMS], term_param[SOLO_MAX_TERMS];
+#pragma unroll
+  for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
+    term_kind[t] = wave_uniform(P0->term_kind[t]);
+    term_param[t] = wave_uniform(P0->term_param[t]);
+  }
 
   // B.steps consecutive env steps of THIS robot in one launch: the state record stays in LDS,
   // only actions come in and obs / reward / done go out per step.  Robots are independent, so
@@ -833,12 +880,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
       bool done = false;
 #pragma unroll
       for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
-        if (t < P->num_terms && !done) {
-          if (P->term_kind[t] == SOLO_T_TIME) {
+        if (t < n_terms && !done) {
+          if (term_kind[t] == SOLO_T_TIME) {
             cnt[t] += 1;
-            done = cnt[t] > P->term_param[t];
-          } else if (P->term_kind[t] == SOLO_T_CONST) {
-            done = P->term_param[t] != 0;
+            done = cnt[t] > term_param[t];
+          } else if (term_kind[t] == SOLO_T_CONST) {
+            done = term_param[t] != 0;
           }
         }
       }
@@ -847,7 +894,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
         if (lane == 0) { s_state[SOLO_S_RETURN] += reward; s_state[SOLO_S_EPLEN] += T(1); }
         wave_sync();
       }
-      const bool restart = (done || diverged) && P->auto_reset != 0;
+      const bool restart = (done || diverged) && auto_reset != 0;
       if (restart) {
         if (lane == 0 && done) {
           const double ret = (double)s_state[SOLO_S_RETURN];

@@ -27,6 +27,12 @@ __device__ __forceinline__ int wave_opaque_lane(int lane) {
 // pins a per-lane value: it is materialised at this point of the program (no instruction)
 __device__ __forceinline__ float wave_pin(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double wave_pin(double x) { asm volatile("" : "+v"(x)); return x; }
+// pins a group at ONE point: the loads feeding all of them may be in flight together (f32), or
+// one after the other where registers are short (f64: every value is a register pair)
+__device__ __forceinline__ void wave_pin_group(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+__device__ __forceinline__ void wave_pin_group(float& a, float& b, float& c, float& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void wave_pin_group(double& a, double& b, double& c) { a = wave_pin(a); b = wave_pin(b); c = wave_pin(c); }
+__device__ __forceinline__ void wave_pin_group(double& a, double& b, double& c, double& d) { a = wave_pin(a); b = wave_pin(b); c = wave_pin(c); d = wave_pin(d); }
 __device__ __forceinline__ int wave_readlane_int(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
 // both arguments are wave-uniform (SGPRs): integer compare of the bit patterns on the SALU
 __device__ __forceinline__ bool wave_uniform_bits_differ(float a, float b) {
@@ -94,6 +100,18 @@ template <typename T> __device__ __forceinline__ T wave_sum_group16(T x) {
   x += dpp_mov<0x121>(x);
   return x;
 }
+// sum over all 64 lanes as a wave-uniform value: row all-reduce, then the GFX9 DPP row broadcasts
+// (row_bcast:15 into rows 1,3; row_bcast:31 into rows 2,3) leave the total in lane 63, which
+// v_readlane moves to a scalar register.  Association: (r3 + r2) + (r1 + r0) over the row sums.
+__device__ __forceinline__ float wave_sum_all(float x) {
+  x = wave_sum_group16(x);
+  // written as DPP adds on the destination itself: rows outside row_mask keep their value (the
+  // compiler cannot fold a masked mov_dpp + add for floats); s_nop covers the VALU-write -> DPP-read hazard
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(x));
+  return wave_readlane(x, 63);
+}
+__device__ __forceinline__ double wave_sum_all(double x) { return wave_sum_legs(wave_sum_group16(x)); }
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 
 template <typename T> struct Real;
@@ -123,8 +141,27 @@ template <> struct Real<float> {
     *s = (q & 2) ? -a : a;
     *c = ((q + 1) & 2) ? -b : b;
   }
-  static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
-  static __device__ __forceinline__ float asin(float x) { return asinf(x); }
+  // atan2 by octant reduction + odd minimax polynomial on [0, 1] (max error 1.5e-7 rad), ~22
+  // instructions instead of libm's ~60; asin(x) = atan2(x, sqrt(1 - x^2)).  These feed the Euler
+  // angles of the observation / reward programs (obs.py:271, rewards.py:233).
+  static __device__ __forceinline__ float atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = (mx == 0.0f) ? 0.0f : mn * __builtin_amdgcn_rcpf(mx);
+    const float s2 = a * a;
+    float p = __builtin_fmaf(s2, -0.0040545654f, 0.021862952f);
+    p = __builtin_fmaf(s2, p, -0.05591232f);
+    p = __builtin_fmaf(s2, p, 0.09642197f);
+    p = __builtin_fmaf(s2, p, -0.13908629f);
+    p = __builtin_fmaf(s2, p, 0.19946566f);
+    p = __builtin_fmaf(s2, p, -0.3332986f);
+    p = __builtin_fmaf(s2, p, 0.99999934f);
+    float r = a * p;
+    r = (ay > ax) ? 1.57079637f - r : r;
+    r = (x < 0.0f) ? 3.14159274f - r : r;
+    return __builtin_copysignf(r, y);
+  }
+  static __device__ __forceinline__ float asin(float x) { return atan2(x, __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(-x, x, 1.0f)))); }
   static __device__ __forceinline__ float exp(float x) { return expf(x); }
   static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
   static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }

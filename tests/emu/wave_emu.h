@@ -124,6 +124,8 @@ inline void wave_sched_fence() {}
 template <typename P> inline P* wave_opaque(P* p) { return p; }
 inline int wave_opaque_lane(int lane) { return lane; }
 template <typename T> inline T wave_pin(T x) { return x; }
+template <typename T> inline void wave_pin_group(T&, T&, T&) {}
+template <typename T> inline void wave_pin_group(T&, T&, T&, T&) {}
 inline int wave_uniform(int x) { return x; }
 inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
 inline bool wave_uniform_bits_differ(float a, float b) { return std::memcmp(&a, &b, 4) != 0; }
@@ -152,6 +154,7 @@ template <typename T> inline T wave_sum_group16(T x) {
   x += emu_shfl_xor(x, 1);
   return x;
 }
+template <typename T> inline T wave_sum_all(T x) { return wave_sum_legs(wave_sum_group16(x)); }
 inline unsigned long long wave_ballot(bool p) {
   WaveEmu& e = WaveEmu::get();
   e.post(p ? 1 : 0);
