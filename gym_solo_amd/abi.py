@@ -90,7 +90,7 @@ class SoloConfig(C.Structure):
     ('auto_reset', C.c_int32),
     ('steps_per_launch', C.c_int32),
     ('rollout_streams', C.c_int32),
-    ('reserved', C.c_int32),
+    ('solver_ulp_tolerance', C.c_int32),
   ]
 
 

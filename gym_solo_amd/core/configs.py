@@ -47,6 +47,7 @@ class Solo8BaseConfig:
   device: int = 0
   dtype: str = 'float32'          # arithmetic type of the engine: 'float32' | 'float64'
   solver_iterations: int = 50     # Bullet default [recalled]
+  solver_ulp_tolerance: int = 2   # impulse changes of <= this many ulps count as converged (0 = bit-exact)
   motor_kp: float = 0.1           # pybullet POSITION_CONTROL default positionGain [recalled]
   motor_kd: float = 1.0           # pybullet POSITION_CONTROL default velocityGain [recalled]
   contact_erp: float = 0.2
@@ -110,6 +111,9 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
   c.contact_erp = float(config.contact_erp)
   c.contact_margin = float(config.contact_margin)
   c.solver_iterations = int(config.solver_iterations)
+  c.solver_ulp_tolerance = int(getattr(config, 'solver_ulp_tolerance', 2))
+  if c.solver_ulp_tolerance < 0:
+    raise ValueError('solver_ulp_tolerance must be >= 0')
   c.settle_steps = int(config.settle_steps)
   q = euler_to_quat(config.robot_start_orientation_euler)
   for a in range(4):

@@ -75,6 +75,7 @@ struct KParams {
   T action_scale;
   T gauss_scale;  // sqrt(-2 ln 0.1): rewards.py:427 with the default margin_value
   int32_t iterations, auto_reset;
+  int32_t ulp_tol, pad1;  // SoloConfig::solver_ulp_tolerance
   // heightfield ground (SoloTerrain): grid size, 1/cell, origin; heights live in KBuffers::terrain
   int32_t terr_nx, terr_ny;
   T terr_inv_cell, terr_ox, terr_oy;
@@ -152,6 +153,7 @@ inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) 
   k->gauss_scale = (T)std::sqrt(-2.0 * std::log(0.1));
   k->iterations = c.solver_iterations;
   k->auto_reset = c.auto_reset;
+  k->ulp_tol = c.solver_ulp_tolerance;
   k->base_mass = (T)m.mass[0];
   for (int a = 0; a < 6; ++a) k->base_I[a] = (T)m.inertia[0][a];
   for (int leg = 0; leg < 4; ++leg) {

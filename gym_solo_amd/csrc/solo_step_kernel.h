@@ -129,14 +129,17 @@ __device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
 // row is then an exact no-op - as in the delta form "u += B * 0" - instead of re-rounding v, so
 // saturated motor rows stop perturbing the candidates, the sweep reaches an exact fixed point in
 // finite precision, and `changed` lets the caller leave the iteration loop when a whole sweep
-// changed nothing (bit-identical to running the remaining sweeps).
+// changed nothing (with ulps = 0 bit-identical to running the remaining sweeps).  `ulps`
+// (SoloConfig::solver_ulp_tolerance) widens "unchanged" to "within that many units in the last
+// place": last-bit limit cycles (measured: period 2, one contact's three rows flipping by one
+// ulp) otherwise keep ~3% of the robots sweeping to the iteration cap.
 template <typename T, int SLOT>
-__device__ __forceinline__ void pgs_row(T& v, T lo, T hi, int lane_r, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int& changed) {
+__device__ __forceinline__ void pgs_row(T& v, T lo, T hi, int lane_r, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int ulps, int& changed) {
   const T a = An[SLOT];
   const T old = sl[SLOT];
   const T t = Real<T>::fma(-a, old, v);  // off the critical path; dropped if the row is unchanged
   const T now = wave_readlane(Real<T>::clamp(v, lo, hi), lane_r);
-  if (wave_uniform_bits_differ(now, old)) {
+  if (wave_uniform_ulps_exceed(now, old, ulps)) {
     v = Real<T>::fma(a, now, t);
     sl[SLOT] = now;
     changed = 1;
@@ -200,9 +203,9 @@ struct ForMotors {
     wave_pin_group(An[D], An[D + 1], An[D + 2], An[D + 3]);
     ForMotors<T, D + 4>::build(An, rowvec, gh, hh, nid, lane);
   }
-  static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int& changed) {
-    pgs_row<T, D>(v, -imp, imp, motor_lane(D), sl, An, changed);
-    ForMotors<T, D + 1>::solve(v, imp, sl, An, changed);
+  static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int ulps, int& changed) {
+    pgs_row<T, D>(v, -imp, imp, motor_lane(D), sl, An, ulps, changed);
+    ForMotors<T, D + 1>::solve(v, imp, sl, An, ulps, changed);
   }
   static __device__ __forceinline__ T gather(T lam, const T (&sl)[kNumRowSlots], int lane) {
     return ForMotors<T, D + 1>::gather((lane == motor_lane(D)) ? sl[D] : lam, sl, lane);
@@ -211,20 +214,20 @@ struct ForMotors {
 template <typename T>
 struct ForMotors<T, SOLO_NUM_DOF> {
   static __device__ __forceinline__ void build(T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, T, int) {}
-  static __device__ __forceinline__ void solve(T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots], int&) {}
+  static __device__ __forceinline__ void solve(T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots], int, int&) {}
   static __device__ __forceinline__ T gather(T lam, const T (&)[kNumRowSlots], int) { return lam; }
 };
 template <typename T, int C>
 struct ForContacts {
   static constexpr int S0 = SOLO_NUM_DOF + 3 * C;
   // normal row, then the two friction rows limited by mu * (fresh normal impulse)
-  static __device__ __forceinline__ void solve(int nc, const int (&cl)[kMaxContacts], T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int& changed) {
+  static __device__ __forceinline__ void solve(int nc, const int (&cl)[kMaxContacts], T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int ulps, int& changed) {
     if (C >= nc) return;
-    pgs_row<T, S0>(v, T(0), Real<T>::big(), cl[C], sl, An, changed);
+    pgs_row<T, S0>(v, T(0), Real<T>::big(), cl[C], sl, An, ulps, changed);
     const T lim = mu * sl[S0];
-    pgs_row<T, S0 + 1>(v, -lim, lim, cl[C] + 1, sl, An, changed);
-    pgs_row<T, S0 + 2>(v, -lim, lim, cl[C] + 2, sl, An, changed);
-    ForContacts<T, C + 1>::solve(nc, cl, v, mu, sl, An, changed);
+    pgs_row<T, S0 + 1>(v, -lim, lim, cl[C] + 1, sl, An, ulps, changed);
+    pgs_row<T, S0 + 2>(v, -lim, lim, cl[C] + 2, sl, An, ulps, changed);
+    ForContacts<T, C + 1>::solve(nc, cl, v, mu, sl, An, ulps, changed);
   }
   static __device__ __forceinline__ T gather(int nc, const int (&cl)[kMaxContacts], T lam, const T (&sl)[kNumRowSlots], int lane) {
     if (C >= nc) return lam;
@@ -236,7 +239,7 @@ struct ForContacts {
 };
 template <typename T>
 struct ForContacts<T, kMaxContacts> {
-  static __device__ __forceinline__ void solve(int, const int (&)[kMaxContacts], T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots], int&) {}
+  static __device__ __forceinline__ void solve(int, const int (&)[kMaxContacts], T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots], int, int&) {}
   static __device__ __forceinline__ T gather(int, const int (&)[kMaxContacts], T lam, const T (&)[kNumRowSlots], int) { return lam; }
 };
 // touching spheres in solve order -> lanes of their normal rows: the set bits of the ballot,
@@ -576,6 +579,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   const unsigned long long touching = wave_ballot(live && type == ROW_NORMAL);
   wave_sync();
 
+  SOLO_STAMP(B, 7);
   // ---- scaled Delassus row of this lane, then projected Gauss-Seidel --------------------------
   int nc = 0;
   int cl[kMaxContacts];
@@ -608,12 +612,13 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   T v = w * nid;       // lam = 0
   SOLO_STAMP(B, 8);
   const T imp = P->motor_impulse;
+  const int ulps = wave_uniform(P->ulp_tol);
   const int iters = wave_uniform(P->iterations);  // scalar trip count: keeps the loop (and sl[]) on the SALU side
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     int changed = 0;
-    ForMotors<T, 0>::solve(v, imp, sl, An, changed);
-    ForContacts<T, 0>::solve(nc, cl, v, mu, sl, An, changed);
+    ForMotors<T, 0>::solve(v, imp, sl, An, ulps, changed);
+    ForContacts<T, 0>::solve(nc, cl, v, mu, sl, An, ulps, changed);
     SOLO_PGS_SWEEP_HOOK(it, nc, sl, changed, v);
     if (!changed) break;  // exact fixed point: the remaining sweeps would be no-ops
 #ifdef SOLO_STAMPS

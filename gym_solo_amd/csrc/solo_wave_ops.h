@@ -42,6 +42,20 @@ __device__ __forceinline__ bool wave_uniform_bits_differ(double a, double b) {
   const long long x = __double_as_longlong(a) ^ __double_as_longlong(b);
   return (__builtin_amdgcn_readfirstlane((int)(x & 0xffffffffll)) | __builtin_amdgcn_readfirstlane((int)(x >> 32))) != 0;
 }
+// both arguments wave-uniform: do they differ by MORE than k units in the last place?  Integer
+// arithmetic on the bit patterns (the SALU has no float compare); values of opposite sign count as
+// different.  k = 0 is wave_uniform_bits_differ.
+__device__ __forceinline__ bool wave_uniform_ulps_exceed(float a, float b, int k) {
+  const unsigned d = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(a)) - (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(b)) + (unsigned)k;
+  return d > 2u * (unsigned)k;
+}
+__device__ __forceinline__ bool wave_uniform_ulps_exceed(double a, double b, int k) {
+  const long long x = __double_as_longlong(a), y = __double_as_longlong(b);
+  const unsigned long long d = (unsigned long long)x - (unsigned long long)y + (unsigned long long)k;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(d & 0xffffffffull));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32));
+  return hi != 0u || lo > 2u * (unsigned)k;
+}
 // declares an int wave-uniform (v_readfirstlane -> SGPR)
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // compiler scheduling fence (no instruction): instructions are not moved across it

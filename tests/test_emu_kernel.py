@@ -115,3 +115,35 @@ def test_zero_heightfield_equals_flat_plane():
     a.step(act, abi.STEP_PHYSICS)
     b.step(act, abi.STEP_PHYSICS)
   np.testing.assert_allclose(a.state, b.state, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('dtype,tol', [('float64', 1e-12), ('float32', 2e-5)])
+def test_ulp_tolerance_only_moves_last_bits(dtype, tol):
+  """SoloConfig.solver_ulp_tolerance: 0 ends the Gauss-Seidel iteration only at a bit-exact
+  fixed point; the default 2 also ends last-bit limit cycles.  One step from identical states
+  differs by rounding noise only (positions/angles to `tol`; velocities carry the 1/dt-scaled
+  motor rows, hence x1e3)."""
+  ca0, ma = make_abi(dtype, solver_ulp_tolerance=0)
+  ca2, _ = make_abi(dtype, solver_ulp_tolerance=2)
+  assert ca0.solver_ulp_tolerance == 0 and ca2.solver_ulp_tolerance == 2
+  n = 6
+  a = EmuEngine(ca0, ma, n)
+  rng = np.random.default_rng(5)
+  for k in range(60):  # flail into contact-rich, decorrelated poses (exact mode)
+    a.step(random_actions(rng, n), abi.STEP_PHYSICS)
+  b = EmuEngine(ca2, ma, n)
+  worst_q = worst_v = 0.0
+  for k in range(10):
+    b.state[:] = a.state
+    act = random_actions(rng, n)
+    a.step(act, abi.STEP_PHYSICS)
+    b.step(act, abi.STEP_PHYSICS)
+    d = np.abs(a.state - b.state)
+    worst_q = max(worst_q, d[:, :15].max())
+    worst_v = max(worst_v, d[:, 15:29].max())
+  assert worst_q < tol and worst_v < 1e3 * tol, (worst_q, worst_v)
+
+
+def test_negative_ulp_tolerance_rejected():
+  with pytest.raises(ValueError):
+    make_abi('float32', solver_ulp_tolerance=-1)

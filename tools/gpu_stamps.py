@@ -8,7 +8,7 @@ import numpy as np, torch
 from gym_solo_amd import abi
 from bench import build_env
 names = ['loads+sync', 'kinematics', 'crba', 'rne bias', 'schur+sum', 'chol+solve', 'rows', 'A build', 'PGS', 'gather+finish', 'euler+obs', 'reward', 'done', 'store']
-for n in (256, 4096):
+for n in [int(a) for a in sys.argv[1:]] or (1024, 4096):
   env = build_env(n, 0, 'float32')
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(1234)
@@ -33,4 +33,21 @@ for n in (256, 4096):
   for c in range(0, 8):
     m = ncs == c
     if m.any(): print('   nc=%d: %4d robots, mean sweeps %.1f, at cap %.0f%%, mean wave life %.0f' % (c, m.sum(), its[m].mean(), 100*(its[m]>=49).mean(), (buf[m,14].astype(np.int64)-buf[m,0].astype(np.int64)).mean()))
+  env._close()
+
+# ---- fused launches (the bench configuration): how unequal are the robots' 100-step totals? ----
+for n, spl in ((1024, 100), (4096, 100)):
+  env = build_env(n, 0, 'float32', steps_per_launch=spl, rollout_streams=1)
+  eng = env.engine
+  g = torch.Generator(device='cuda').manual_seed(99)
+  acts = (torch.rand(500, n, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
+  eng.rollout(acts, abi.STEP_ALL)                      # into the flailing steady state
+  eng.rollout(acts[:spl], abi.STEP_ALL)                # ONE fused launch: its stamps are read back
+  buf = np.zeros((n, 16), dtype=np.uint64)
+  eng.lib.solo_engine_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
+  t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 14].astype(np.int64)
+  per_step = (t1 - t0) / spl
+  print('fused N=%d S=%d: per-robot mean step (ticks) percentiles 1/50/90/99/max: %s ; launch makespan/steps = %.0f ; mean %.0f' % (
+    n, spl, np.percentile(per_step, [1, 50, 90, 99, 100]).astype(int).tolist(), (t1.max() - t0.min()) / spl, per_step.mean()))
   env._close()
