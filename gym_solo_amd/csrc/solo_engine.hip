@@ -98,8 +98,8 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMemset(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t)));
     HIP_TRY(hipMemset(stats, 0, kStatsBytes));
 #ifdef SOLO_STAMPS
-    HIP_TRY(hipMalloc((void**)&stamps, (size_t)n * 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(stamps, 0, (size_t)n * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&stamps, (size_t)n * 32 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(stamps, 0, (size_t)n * 32 * sizeof(unsigned long long)));
 #endif
     std::vector<T> hp((size_t)n * 4, T(0));
     std::vector<T> ha((size_t)n * SOLO_NUM_JOINTS);
@@ -369,13 +369,13 @@ struct SoloEngine { EngineBase* impl; };
 extern "C" {
 
 #ifdef SOLO_STAMPS
-// DIAGNOSTIC build only: copies the [N][16] s_memtime stamps of the last launch to the host.
+// DIAGNOSTIC build only: copies the [N][32] s_memtime stamps of the last launch to the host.
 int solo_engine_debug_stamps(SoloEngine* eng, unsigned long long* host, int is_f32) {
   if (!eng || !eng->impl) return SOLO_ERR_INVALID_ARG;
   hipDeviceSynchronize();
-  if (is_f32) { auto* e = static_cast<Engine<float>*>(eng->impl); return hipMemcpy(host, e->stamps, (size_t)e->n * 128, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SOLO_ERR_HIP; }
+  if (is_f32) { auto* e = static_cast<Engine<float>*>(eng->impl); return hipMemcpy(host, e->stamps, (size_t)e->n * 256, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SOLO_ERR_HIP; }
   auto* e = static_cast<Engine<double>*>(eng->impl);
-  return hipMemcpy(host, e->stamps, (size_t)e->n * 128, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SOLO_ERR_HIP;
+  return hipMemcpy(host, e->stamps, (size_t)e->n * 256, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SOLO_ERR_HIP;
 }
 #endif
 

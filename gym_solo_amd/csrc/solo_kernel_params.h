@@ -109,7 +109,10 @@ struct KBuffers {
   // element strides between consecutive steps of a multi-step launch (0: reuse the buffer)
   long long action_stride, obs_stride, reward_stride, done_stride;
 #ifdef SOLO_STAMPS
-  unsigned long long* stamps;  // [N][16] s_memtime stamps, DIAGNOSTIC builds only (make stamps)
+  unsigned long long* stamps;  // [N][32] s_memtime stamps, DIAGNOSTIC builds only (make stamps):
+                               // [0..15] absolute stamps of the launch's last step, [16+i] = ticks
+                               // spent before stamp i summed over the launch's steps
+  unsigned long long* acc;     // the launch's accumulators in LDS (set by the kernel)
 #endif
 };
 

@@ -36,7 +36,12 @@
 #ifdef SOLO_STAMPS
 #define SOLO_STAMP(B, i)                                                                          \
   do {                                                                                            \
-    if (solo::lane_id() == 0) (B).stamps[(size_t)(solo::block_id() + (B).env_base) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (solo::lane_id() == 0) {                                                                   \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                 \
+      (B).stamps[(size_t)(solo::block_id() + (B).env_base) * 32 + (i)] = t_;                      \
+      (B).acc[(i)] += t_ - (B).acc[16];                                                           \
+      (B).acc[16] = t_;                                                                           \
+    }                                                                                             \
   } while (0)
 #else
 #define SOLO_STAMP(B, i) do {} while (0)
@@ -44,7 +49,7 @@
 
 // test hook (CPU emulator builds only): called once per Gauss-Seidel sweep
 #ifndef SOLO_PGS_SWEEP_HOOK
-#define SOLO_PGS_SWEEP_HOOK(it, nc, sl, changed, v) do {} while (0)
+#define SOLO_PGS_SWEEP_HOOK(it, pend, lam, v) do {} while (0)
 #endif
 
 namespace solo {
@@ -111,41 +116,6 @@ __device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
   return within ? T(1) : v;
 }
 
-// ---- projected Gauss-Seidel on the Delassus matrix ------------------------------------------
-// Lane s iterates on its UNCLAMPED candidate  v_s = lam_s - w_s / A_ss  (w = constraint-space
-// velocity error).  v_s is invariant under row s's own update, so with the scaled row
-// An[s][r] = -A_sr / A_ss (r != s), An[s][s] = 0 a row update is, for ALL lanes at once,
-//     v += An[.][r] * (lam_r_new - lam_r_old).
-// The impulse of row r is wave-uniform, so it lives in an SGPR (sl[r]) - no per-lane select,
-// and the change is applied as two fused multiply-adds with one SGPR operand each (gfx950 VALU
-// instructions take a single scalar operand; there is no scalar float subtract):
-//     t    = v - An[r] * sl[r]       (v_fma_f32, off the critical path)
-//     cand = clamp(v)                (v_med3_f32, every lane, only lane r matters)
-//     sl[r] = readlane(cand, r)      (v_readlane_b32)
-//     v    = t + An[r] * sl[r]       (v_fma_f32)
-// `lane_r` is the lane that owns the row (compile-time for motors, an SGPR for contacts); SLOT is
-// the compile-time register slot of the row in An / sl.
-// The update is CONDITIONAL on the impulse really changing (scalar compare + branch): an unchanged
-// row is then an exact no-op - as in the delta form "u += B * 0" - instead of re-rounding v, so
-// saturated motor rows stop perturbing the candidates, the sweep reaches an exact fixed point in
-// finite precision, and `changed` lets the caller leave the iteration loop when a whole sweep
-// changed nothing (with ulps = 0 bit-identical to running the remaining sweeps).  `ulps`
-// (SoloConfig::solver_ulp_tolerance) widens "unchanged" to "within that many units in the last
-// place": last-bit limit cycles (measured: period 2, one contact's three rows flipping by one
-// ulp) otherwise keep ~3% of the robots sweeping to the iteration cap.
-template <typename T, int SLOT>
-__device__ __forceinline__ void pgs_row(T& v, T lo, T hi, int lane_r, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int ulps, int& changed) {
-  const T a = An[SLOT];
-  const T old = sl[SLOT];
-  const T t = Real<T>::fma(-a, old, v);  // off the critical path; dropped if the row is unchanged
-  const T now = wave_readlane(Real<T>::clamp(v, lo, hi), lane_r);
-  if (wave_uniform_ulps_exceed(now, old, ulps)) {
-    v = Real<T>::fma(a, now, t);
-    sl[SLOT] = now;
-    changed = 1;
-  }
-}
-// -(ghat_me.ghat_r + [same leg] hhat_me.hhat_r) / A_me,me   (0 on the diagonal): the entry of
 // this lane's scaled Delassus row for the row owned by lane_r.  `me` = own whitened row (regs),
 // the other row is a wave-uniform LDS broadcast.
 template <typename T>
@@ -156,108 +126,6 @@ __device__ __forceinline__ T delassus_entry(const T (*rowvec)[8], int lane_r, co
   const T full = ((lane >> 4) == (lane_r >> 4)) ? (a + b) : a;
   return (lane == lane_r) ? T(0) : full * neg_inv_d;
 }
-// writes the three entries of touching sphere c into its compile-time register slots; c is
-// wave-uniform, so this is a scalar jump, not divergence
-template <typename T, int C>
-struct StoreContactEntries {
-  static __device__ __forceinline__ void run(int c, T (&An)[kNumRowSlots], T e0, T e1, T e2) {
-    if (c == C) {
-      An[SOLO_NUM_DOF + 3 * C] = e0;
-      An[SOLO_NUM_DOF + 3 * C + 1] = e1;
-      An[SOLO_NUM_DOF + 3 * C + 2] = e2;
-    } else {
-      StoreContactEntries<T, C + 1>::run(c, An, e0, e1, e2);
-    }
-  }
-};
-template <typename T>
-struct StoreContactEntries<T, kMaxContacts> {
-  static __device__ __forceinline__ void run(int, T (&)[kNumRowSlots], T, T, T) {}
-};
-template <int C>
-struct PickLane {
-  static __device__ __forceinline__ int run(int c, const int (&cl)[kMaxContacts]) {
-    return c == C ? cl[C] : PickLane<C + 1>::run(c, cl);
-  }
-};
-template <>
-struct PickLane<kMaxContacts> {
-  static __device__ __forceinline__ int run(int, const int (&)[kMaxContacts]) { return 0; }
-};
-
-// Register slots: 0..7 = motor rows (dof order), 8+3c+q = row q of the c-th TOUCHING sphere (in
-// model sphere order).  Only touching spheres get slots, so the solver loop never visits - or
-// branches around - a sphere that is in the air (a skipped branch costs ~20 cycles of a
-// latency-bound wave).  cl[c] = lane of the normal row of the c-th touching sphere.
-template <typename T, int D>
-struct ForMotors {
-  static __device__ __forceinline__ void build(T (&An)[kNumRowSlots], const T (*rowvec)[8], const T* gh, const T* hh, T nid, int lane) {
-    // pinned, four at a time: the entries are computed HERE, next to their LDS row reads
-    // (otherwise the arithmetic sinks to the solver loop while all 16 row reads (64 VGPRs) stay
-    // up front and spill); a group's 8 reads are in flight together
-    static_assert(D % 4 == 0 && SOLO_NUM_DOF % 4 == 0, "motor entries are built in groups of four");
-    An[D] = delassus_entry<T>(rowvec, motor_lane(D), gh, hh, nid, lane);
-    An[D + 1] = delassus_entry<T>(rowvec, motor_lane(D + 1), gh, hh, nid, lane);
-    An[D + 2] = delassus_entry<T>(rowvec, motor_lane(D + 2), gh, hh, nid, lane);
-    An[D + 3] = delassus_entry<T>(rowvec, motor_lane(D + 3), gh, hh, nid, lane);
-    wave_pin_group(An[D], An[D + 1], An[D + 2], An[D + 3]);
-    ForMotors<T, D + 4>::build(An, rowvec, gh, hh, nid, lane);
-  }
-  static __device__ __forceinline__ void solve(T& v, T imp, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int ulps, int& changed) {
-    pgs_row<T, D>(v, -imp, imp, motor_lane(D), sl, An, ulps, changed);
-    ForMotors<T, D + 1>::solve(v, imp, sl, An, ulps, changed);
-  }
-  static __device__ __forceinline__ T gather(T lam, const T (&sl)[kNumRowSlots], int lane) {
-    return ForMotors<T, D + 1>::gather((lane == motor_lane(D)) ? sl[D] : lam, sl, lane);
-  }
-};
-template <typename T>
-struct ForMotors<T, SOLO_NUM_DOF> {
-  static __device__ __forceinline__ void build(T (&)[kNumRowSlots], const T (*)[8], const T*, const T*, T, int) {}
-  static __device__ __forceinline__ void solve(T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots], int, int&) {}
-  static __device__ __forceinline__ T gather(T lam, const T (&)[kNumRowSlots], int) { return lam; }
-};
-template <typename T, int C>
-struct ForContacts {
-  static constexpr int S0 = SOLO_NUM_DOF + 3 * C;
-  // normal row, then the two friction rows limited by mu * (fresh normal impulse)
-  static __device__ __forceinline__ void solve(int nc, const int (&cl)[kMaxContacts], T& v, T mu, T (&sl)[kNumRowSlots], const T (&An)[kNumRowSlots], int ulps, int& changed) {
-    if (C >= nc) return;
-    pgs_row<T, S0>(v, T(0), Real<T>::big(), cl[C], sl, An, ulps, changed);
-    const T lim = mu * sl[S0];
-    pgs_row<T, S0 + 1>(v, -lim, lim, cl[C] + 1, sl, An, ulps, changed);
-    pgs_row<T, S0 + 2>(v, -lim, lim, cl[C] + 2, sl, An, ulps, changed);
-    ForContacts<T, C + 1>::solve(nc, cl, v, mu, sl, An, ulps, changed);
-  }
-  static __device__ __forceinline__ T gather(int nc, const int (&cl)[kMaxContacts], T lam, const T (&sl)[kNumRowSlots], int lane) {
-    if (C >= nc) return lam;
-    lam = (lane == cl[C]) ? sl[S0] : lam;
-    lam = (lane == cl[C] + 1) ? sl[S0 + 1] : lam;
-    lam = (lane == cl[C] + 2) ? sl[S0 + 2] : lam;
-    return ForContacts<T, C + 1>::gather(nc, cl, lam, sl, lane);
-  }
-};
-template <typename T>
-struct ForContacts<T, kMaxContacts> {
-  static __device__ __forceinline__ void solve(int, const int (&)[kMaxContacts], T&, T, T (&)[kNumRowSlots], const T (&)[kNumRowSlots], int, int&) {}
-  static __device__ __forceinline__ T gather(int, const int (&)[kMaxContacts], T lam, const T (&)[kNumRowSlots], int) { return lam; }
-};
-// touching spheres in solve order -> lanes of their normal rows: the set bits of the ballot,
-// lowest first (wave-uniform scalar code: s_ff1 / s_bitset per touching sphere)
-template <int C>
-struct CompactSpheres {
-  static __device__ __forceinline__ void run(unsigned long long m, int& nc, int (&cl)[kMaxContacts]) {
-    if (m == 0ull) return;
-    cl[C] = __builtin_ctzll(m);
-    nc = C + 1;
-    CompactSpheres<C + 1>::run(m & (m - 1ull), nc, cl);
-  }
-};
-template <>
-struct CompactSpheres<kMaxContacts> {
-  static __device__ __forceinline__ void run(unsigned long long, int&, int (&)[kMaxContacts]) {}
-};
-
 // ------------------------------------------------------------------------------------------
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
 // constraint impulse; physics_finish writes s_state (new).
@@ -580,55 +448,70 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   wave_sync();
 
   SOLO_STAMP(B, 7);
-  // ---- scaled Delassus row of this lane, then projected Gauss-Seidel --------------------------
-  int nc = 0;
-  int cl[kMaxContacts];
-#pragma unroll
-  for (int i = 0; i < kMaxContacts; ++i) cl[i] = 0;
-  CompactSpheres<0>::run(touching, nc, cl);
-  if (__builtin_popcountll(touching) > kMaxContacts && lane == 0)
-    stats_add(&B.stats[(size_t)((block_id() + B.env_base) % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH + 6], 1.0);
-  T An[kNumRowSlots];
-#pragma unroll
-  for (int i = 0; i < kNumRowSlots; ++i) An[i] = T(0);
+  // ---- projected Gauss-Seidel, sparse in the rows that still move ---------------------------
+  // Per-lane solver state: candidate v, impulse lam, bounds lo/hi (friction bounds follow their
+  // contact's normal impulse).  `pend` is the set of rows whose clamped candidate differs from
+  // their impulse by more than `ulps` units in the last place - evaluated for all 64 lanes at
+  // once (v_med3 + integer compare + the compare's own lane mask).  A sweep walks the pending rows
+  // in solver order (motor rows, then contacts by sphere) with a scalar find-first-set; only
+  // those rows cost anything, and after each change the mask is re-evaluated, so the decisions
+  // are the ones a dense sweep over every row would take.
   const T nid = -inv_d;
-  // one runtime loop over the touching spheres (a single copy of the LDS reads + dot products);
-  // the results land in compile-time register slots through a scalar switch
-#pragma unroll 1
-  for (int c = 0; c < nc; ++c) {
-    const int lr = PickLane<0>::run(c, cl);
-    T e0 = delassus_entry<T>(s_rowvec, lr, gh, hh, nid, lane);
-    T e1 = delassus_entry<T>(s_rowvec, lr + 1, gh, hh, nid, lane);
-    T e2 = delassus_entry<T>(s_rowvec, lr + 2, gh, hh, nid, lane);
-    wave_pin_group(e0, e1, e2);
-    StoreContactEntries<T, 0>::run(c, An, e0, e1, e2);
-  }
-  // (motor entries last, right before the solver that consumes them: keeps their rows' LDS
-  // reads from being issued before - and spilled across - the loop above)
-  ForMotors<T, 0>::build(An, s_rowvec, gh, hh, nid, lane);
-  T sl[kNumRowSlots];  // impulses: wave-uniform -> scalar registers
-#pragma unroll
-  for (int i = 0; i < kNumRowSlots; ++i) sl[i] = T(0);
-  T v = w * nid;       // lam = 0
-  SOLO_STAMP(B, 8);
   const T imp = P->motor_impulse;
+  T lo = T(0), hi = T(0);
+  if (is_motor) { lo = -imp; hi = imp; }
+  else if (live && type == ROW_NORMAL) hi = R::big();
+  T lamv = T(0);
+  T v = live ? w * nid : T(0);  // lam = 0 (idle lanes: +0, so that they never look pending)
+  SOLO_STAMP(B, 8);
   const int ulps = wave_uniform(P->ulp_tol);
-  const int iters = wave_uniform(P->iterations);  // scalar trip count: keeps the loop (and sl[]) on the SALU side
-#pragma unroll 1
-  for (int it = 0; it < iters; ++it) {
-    int changed = 0;
-    ForMotors<T, 0>::solve(v, imp, sl, An, ulps, changed);
-    ForContacts<T, 0>::solve(nc, cl, v, mu, sl, An, ulps, changed);
-    SOLO_PGS_SWEEP_HOOK(it, nc, sl, changed, v);
-    if (!changed) break;  // exact fixed point: the remaining sweeps would be no-ops
+  const int iters = wave_uniform(P->iterations);  // scalar trip count
+  constexpr unsigned long long kMotorLanes = 0x0003000300030003ull;
+  T cand = R::clamp(v, lo, hi);
+  unsigned long long pend = wave_ballot(ulps_exceed(cand, lamv, ulps));
 #ifdef SOLO_STAMPS
-    if (lane == 0) B.stamps[(size_t)(block_id() + B.env_base) * 16 + 15] = (unsigned long long)(it + 1) | ((unsigned long long)nc << 32);
+  int n_changed = 0;
 #endif
+  int it = 0;
+#pragma unroll 1
+  for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+      unsigned long long window = phase == 0 ? kMotorLanes : ~kMotorLanes;
+#pragma unroll 1
+      while ((pend & window) != 0ull) {
+        const int r = __builtin_ctzll(pend & window);  // wave-uniform: the row to update
+        window &= ~((2ull << r) - 1ull);               // the cursor moves past it
+        // column r of the scaled Delassus matrix, from the whitened row vectors in LDS
+        const T col = delassus_entry<T>(s_rowvec, r, gh, hh, nid, lane);
+        const T delta = wave_readlane(cand - lamv, r);
+        v = R::fma(col, delta, v);
+        lamv = (lane == r) ? cand : lamv;
+        if (phase == 1 && (r & 15) % 3 == 2) {
+          // a normal row moved: its two friction rows are limited by mu * (fresh normal impulse)
+          const T lim = mu * wave_readlane(cand, r);
+          const bool mine = (unsigned)(lane - r - 1) < 2u;
+          lo = mine ? T(0) - lim : lo;  // (0 - 0 = +0: a zero bound must not be -0)
+          hi = mine ? lim : hi;
+        }
+        cand = R::clamp(v, lo, hi);
+        pend = wave_ballot(ulps_exceed(cand, lamv, ulps));
+#ifdef SOLO_STAMPS
+        ++n_changed;
+#endif
+      }
+    }
+    SOLO_PGS_SWEEP_HOOK(it, pend, lamv, v);
   }
+#ifdef SOLO_STAMPS
+  if (lane == 0) {
+    B.stamps[(size_t)(block_id() + B.env_base) * 32 + 15] = (unsigned long long)it | ((unsigned long long)__builtin_popcountll(touching) << 32);
+    B.acc[15] += (unsigned long long)it;
+    B.acc[0] += (unsigned long long)n_changed;
+  }
+#endif
   SOLO_STAMP(B, 9);
-  T lam = ForMotors<T, 0>::gather(T(0), sl, lane);
-  lam = ForContacts<T, 0>::gather(nc, cl, lam, sl, lane);
-  return lam;
+  return lamv;
 }
 
 // post-solve half: apply the impulses (du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam -
@@ -726,6 +609,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   const int env = block_id() + B.env_base;
   if (env >= B.num_envs) return;
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
+#ifdef SOLO_STAMPS
+  __shared__ unsigned long long s_acc[17];
+  if (lane0 < 17) s_acc[lane0] = lane0 == 16 ? __builtin_amdgcn_s_memtime() : 0ull;
+  B.acc = s_acc;
+  wave_sync();
+#endif
   SOLO_STAMP(B, 0);
   // episodic statistics are sharded over SOLO_STATS_SHARDS rows: all robots of a batch finish
   // their episodes in the same step, and same-address atomics serialise at ~12 ns each
@@ -925,6 +814,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   }
   if (lane1 < SOLO_STATE_STRIDE) B.state[rec + lane1] = s_state[lane1];
   SOLO_STAMP(B, 14);
+#ifdef SOLO_STAMPS
+  wave_sync();
+  if (lane1 < 16) B.stamps[(size_t)env * 32 + 16 + lane1] = s_acc[lane1];
+#endif
 }
 
 // setJointMotorControlArray without a step (solo8v2vanilla.py:87-90)

@@ -56,6 +56,14 @@ __device__ __forceinline__ bool wave_uniform_ulps_exceed(double a, double b, int
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32));
   return hi != 0u || lo > 2u * (unsigned)k;
 }
+// per-lane: do a and b differ by more than k units in the last place?  (values of opposite sign,
+// including +0 / -0, count as different)
+__device__ __forceinline__ bool ulps_exceed(float a, float b, int k) {
+  return (unsigned)(__float_as_uint(a) - __float_as_uint(b) + (unsigned)k) > 2u * (unsigned)k;
+}
+__device__ __forceinline__ bool ulps_exceed(double a, double b, int k) {
+  return (unsigned long long)(__double_as_longlong(a) - __double_as_longlong(b) + (long long)k) > 2ull * (unsigned long long)k;
+}
 // declares an int wave-uniform (v_readfirstlane -> SGPR)
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // compiler scheduling fence (no instruction): instructions are not moved across it

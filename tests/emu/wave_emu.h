@@ -130,6 +130,14 @@ inline int wave_uniform(int x) { return x; }
 inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
 inline bool wave_uniform_bits_differ(float a, float b) { return std::memcmp(&a, &b, 4) != 0; }
 inline bool wave_uniform_bits_differ(double a, double b) { return std::memcmp(&a, &b, 8) != 0; }
+inline bool ulps_exceed(float a, float b, int k) {
+  uint32_t x, y; std::memcpy(&x, &a, 4); std::memcpy(&y, &b, 4);
+  return (uint32_t)(x - y + (uint32_t)k) > 2u * (uint32_t)k;
+}
+inline bool ulps_exceed(double a, double b, int k) {
+  uint64_t x, y; std::memcpy(&x, &a, 8); std::memcpy(&y, &b, 8);
+  return (uint64_t)(x - y + (uint64_t)k) > 2ull * (uint64_t)k;
+}
 inline bool wave_uniform_ulps_exceed(float a, float b, int k) {
   uint32_t x, y; std::memcpy(&x, &a, 4); std::memcpy(&y, &b, 4);
   return (uint32_t)(x - y + (uint32_t)k) > 2u * (uint32_t)k;

@@ -2,7 +2,7 @@
 (libsolo_hip_stamps.so; never quote this build's run time, only its shares)."""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ['SOLO_HIP_LIB'] = os.path.join(ROOT, 'gym_solo_amd', 'csrc', 'libsolo_hip_stamps.so')
+os.environ.setdefault('SOLO_HIP_LIB', os.path.join(ROOT, 'gym_solo_amd', 'csrc', 'libsolo_hip_stamps.so'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from gym_solo_amd import abi
@@ -15,7 +15,7 @@ for n in [int(a) for a in sys.argv[1:]] or (1024, 4096):
   acts = (torch.rand(64, n, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
   eng.rollout(acts, abi.STEP_ALL)
   eng.step(acts[0], abi.STEP_ALL)
-  buf = np.zeros((n, 16), dtype=np.uint64)
+  buf = np.zeros((n, 32), dtype=np.uint64)
   eng.lib.solo_engine_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
   assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
   d = np.diff(buf[:, :15].astype(np.int64), axis=1)
@@ -43,11 +43,20 @@ for n, spl in ((1024, 100), (4096, 100)):
   acts = (torch.rand(500, n, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
   eng.rollout(acts, abi.STEP_ALL)                      # into the flailing steady state
   eng.rollout(acts[:spl], abi.STEP_ALL)                # ONE fused launch: its stamps are read back
-  buf = np.zeros((n, 16), dtype=np.uint64)
+  buf = np.zeros((n, 32), dtype=np.uint64)
   eng.lib.solo_engine_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
   assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
   t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 14].astype(np.int64)
   per_step = (t1 - t0) / spl
+  acc = buf[:, 16:32].astype(np.int64)   # acc[:, i] = ticks before stamp i, summed over the launch; acc[:, 15] = sweeps
+  order = np.argsort(per_step)
+  groups = (('fastest 10%', order[:n // 10]), ('middle 10%', order[n * 45 // 100:n * 55 // 100]), ('slowest 1%', order[-max(1, n // 100):]))
+  print('   per-step ticks by phase (launch totals / steps), robots grouped by their launch total:')
+  print('   %-14s' % 'phase' + ''.join('%14s' % g[0] for g in groups))
+  for k, nm in enumerate(names):
+    print('   %-14s' % nm + ''.join('%14.0f' % (acc[idx, k + 1].mean() / spl) for _, idx in groups))
+  print('   %-14s' % 'changed rows' + ''.join('%14.2f' % (acc[idx, 0].mean() / spl) for _, idx in groups))
+  print('   %-14s' % 'sweeps/step' + ''.join('%14.2f' % (acc[idx, 15].mean() / spl) for _, idx in groups))
   print('fused N=%d S=%d: per-robot mean step (ticks) percentiles 1/50/90/99/max: %s ; launch makespan/steps = %.0f ; mean %.0f' % (
     n, spl, np.percentile(per_step, [1, 50, 90, 99, 100]).astype(int).tolist(), (t1.max() - t0.min()) / spl, per_step.mean()))
   env._close()
