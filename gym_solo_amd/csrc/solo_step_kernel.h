@@ -116,16 +116,6 @@ __device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
   return within ? T(1) : v;
 }
 
-// this lane's scaled Delassus row for the row owned by lane_r.  `me` = own whitened row (regs),
-// the other row is a wave-uniform LDS broadcast.
-template <typename T>
-__device__ __forceinline__ T delassus_entry(const T (*rowvec)[8], int lane_r, const T* gh, const T* hh, T neg_inv_d, int lane) {
-  const T* rv = rowvec[lane_r];
-  const T a = gh[0] * rv[0] + gh[1] * rv[1] + gh[2] * rv[2] + gh[3] * rv[3] + gh[4] * rv[4] + gh[5] * rv[5];
-  const T b = hh[0] * rv[6] + hh[1] * rv[7];
-  const T full = ((lane >> 4) == (lane_r >> 4)) ? (a + b) : a;
-  return (lane == lane_r) ? T(0) : full * neg_inv_d;
-}
 // ------------------------------------------------------------------------------------------
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
 // constraint impulse; physics_finish writes s_state (new).
@@ -466,7 +456,9 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   SOLO_STAMP(B, 8);
   const int ulps = wave_uniform(P->ulp_tol);
   const int iters = wave_uniform(P->iterations);  // scalar trip count
-  constexpr unsigned long long kMotorLanes = 0x0003000300030003ull;
+  constexpr unsigned long long kMotorLanes = 0x0003000300030003ull;   // k = 0, 1 of each leg
+  constexpr unsigned long long kNormalLanes = 0x0924092409240924ull;  // k = 2, 5, 8, 11
+  const int my_leg = lane >> 4;
   T cand = R::clamp(v, lo, hi);
   unsigned long long pend = wave_ballot(ulps_exceed(cand, lamv, ulps));
 #ifdef SOLO_STAMPS
@@ -482,12 +474,21 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
       while ((pend & window) != 0ull) {
         const int r = __builtin_ctzll(pend & window);  // wave-uniform: the row to update
         window &= ~((2ull << r) - 1ull);               // the cursor moves past it
-        // column r of the scaled Delassus matrix, from the whitened row vectors in LDS
-        const T col = delassus_entry<T>(s_rowvec, r, gh, hh, nid, lane);
+        // column r of the scaled Delassus matrix, from the whitened row vectors in LDS:
+        // -(ghat_s . ghat_r + [same leg] hhat_s . hhat_r) / A_ss, and 0 for the row itself
+        T rv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rv[i] = s_rowvec[r][i];  // one wave-uniform 32-B broadcast
+        const T a1 = gh[0] * rv[0] + gh[1] * rv[1] + gh[2] * rv[2];
+        const T a2 = gh[3] * rv[3] + gh[4] * rv[4] + gh[5] * rv[5];
+        const T hb = hh[0] * rv[6] + hh[1] * rv[7];
+        const T b = (my_leg == (r >> 4)) ? hb : T(0);
+        const T scale = (lane == r) ? T(0) : nid;
+        const T col = ((a1 + a2) + b) * scale;
         const T delta = wave_readlane(cand - lamv, r);
         v = R::fma(col, delta, v);
         lamv = (lane == r) ? cand : lamv;
-        if (phase == 1 && (r & 15) % 3 == 2) {
+        if ((kNormalLanes >> r) & 1ull) {
           // a normal row moved: its two friction rows are limited by mu * (fresh normal impulse)
           const T lim = mu * wave_readlane(cand, r);
           const bool mine = (unsigned)(lane - r - 1) < 2u;
