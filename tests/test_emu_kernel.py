@@ -147,3 +147,24 @@ def test_ulp_tolerance_only_moves_last_bits(dtype, tol):
 def test_negative_ulp_tolerance_rejected():
   with pytest.raises(ValueError):
     make_abi('float32', solver_ulp_tolerance=-1)
+
+
+def test_flailing_batch_matches_oracle_every_step():
+  """A wider batch of flailing robots on the incline, checked after EVERY step: slowly converging
+  row pairs (a saturating motor against a base-corner contact) make the sparse Gauss-Seidel
+  revisit the same few rows sweep after sweep, which is where a stale row-vector buffer in the
+  double-buffered fetch showed up (one robot, one step, 8e-4) before it was fixed."""
+  import helpers
+  terrain = helpers.incline_terrain()
+  ca, ma = make_abi('float64')
+  n = 16
+  ph = so.OraclePhysics(ca, ma, terrain=terrain)
+  st = np.tile(ph.settle(1), (n, 1))
+  e = EmuEngine(ca, ma, n, terrain=terrain)
+  e.state[:] = st
+  rng = np.random.default_rng(9)
+  for k in range(40):
+    a = random_actions(rng, n)
+    ph.step(st, a)
+    e.step(a, abi.STEP_PHYSICS)
+    np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=1e-9, err_msg='step %d' % k)
