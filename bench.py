@@ -30,8 +30,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 BYTES_PER_ENV_STEP = {'float32': 385, 'float64': 765}  # SURVEY.md §8d algorithmic bytes
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md chip table
-FLOP_PER_ENV_STEP_EST = 3.0e5                           # SURVEY.md §8d estimate (secondary bound)
-FP32_VECTOR_PEAK_TFLOPS = 157.3
+NUM_SIMDS = 1024                                        # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+VALU_ISSUE_CYCLES = 4                                   # one wave64 VALU instruction occupies its SIMD 4 cycles
 
 
 def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1):
@@ -96,14 +96,29 @@ def cpu_baseline(num_envs, seconds_target=12.0):
                     '%d threads) + numpy obs/reward, %.1f s' % (num_envs, steps, cores, el)}
 
 
-def pmc_traffic(dtype):
-  """HBM bytes per launch from a committed rocprofv3 --pmc run (profiles/), or None."""
+def pmc_profile(dtype, key):
+  """A per-launch / per-env-step figure from the committed rocprofv3 --pmc run (profiles/), or None."""
   path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
   try:
     with open(path) as f:
-      return json.load(f).get(dtype, {}).get('hbm_bytes_per_launch')
+      return json.load(f).get(dtype, {}).get(key)
   except Exception:  # noqa: BLE001
     return None
+
+
+def secondary_bound(dtype, env_steps_per_launch, chains, kern_ms, clock_hz):
+  """The bound that actually binds (the path is VALU-issue / latency bound, not
+  HBM bound): share of the chip's VALU issue slots the launches keep busy, from the VALU
+  instruction count per env-step measured with rocprofv3 --pmc SQ_INSTS_VALU (profiles/)."""
+  valu = pmc_profile(dtype, 'valu_insts_per_env_step')
+  if not valu or not clock_hz:
+    return 'VALU-issue / latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype'
+  simd_cycles = NUM_SIMDS * kern_ms * 1e-3 * clock_hz
+  util = chains * valu * env_steps_per_launch * VALU_ISSUE_CYCLES / simd_cycles
+  return ('VALU-issue / latency bound by construction (SURVEY.md §8d), not HBM bound: %.0f VALU instructions per '
+          'env-step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/pmc_traffic.json) x %d cycles x %d env-steps x %d '
+          'concurrent launch chains = %.2f of the %d SIMDs\' issue cycles over the measured launch duration at %.2f GHz'
+          % (valu, VALU_ISSUE_CYCLES, env_steps_per_launch, chains, util, NUM_SIMDS, clock_hz / 1e9))
 
 
 def main():
@@ -209,15 +224,13 @@ def main():
                              'TimeBasedTermination(1000)+auto-reset, dt=1e-3, 50 PGS iterations' % n,
                  'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': streams, 'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                   'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_traffic(args.dtype),
+                   'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_profile(args.dtype, 'hbm_bytes_per_launch'),
                    'kernel': eng.kernel_name, 'kernel_ms': kern_ms,
                    'algorithmic_bytes_per_launch': bytes_per_launch, 'env_steps_per_launch': env_steps_per_launch,
                    'concurrent_launch_chains': n // robots_per_launch,
                    'achieved_all_chains': achieved * (n // robots_per_launch),
-                   'note': 'latency/VALU-bound by construction (SURVEY.md §8d); secondary bound: est. '
-                           '%.0e flop/env-step -> %.3f of the %.1f TFLOP/s f32 vector peak'
-                           % (FLOP_PER_ENV_STEP_EST, FLOP_PER_ENV_STEP_EST * env_steps_per_launch / (kern_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                              FP32_VECTOR_PEAK_TFLOPS)},
+                   'note': secondary_bound(args.dtype, env_steps_per_launch, n // robots_per_launch, kern_ms,
+                                           torch.cuda.get_device_properties(local_rank).clock_rate * 1e3)},
       'episodes': summarize(st),
       'env_api_env_steps_per_s_rank0': api_rate,
     }
