@@ -32,6 +32,8 @@ BYTES_PER_ENV_STEP = {'float32': 385, 'float64': 765}  # SURVEY.md §8d algorith
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md chip table
 NUM_SIMDS = 1024                                        # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 VALU_ISSUE_CYCLES = 4                                   # one wave64 VALU instruction occupies its SIMD 4 cycles
+SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICROARCH.md chip table (matches the
+                                                        # in-kernel s_memtime rate measured with tools/gpu_stamps.py)
 
 
 def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1):
@@ -230,7 +232,7 @@ def main():
                    'concurrent_launch_chains': n // robots_per_launch,
                    'achieved_all_chains': achieved * (n // robots_per_launch),
                    'note': secondary_bound(args.dtype, env_steps_per_launch, n // robots_per_launch, kern_ms,
-                                           torch.cuda.get_device_properties(local_rank).clock_rate * 1e3)},
+                                           SHADER_CLOCK_HZ)},
       'episodes': summarize(st),
       'env_api_env_steps_per_s_rank0': api_rate,
     }

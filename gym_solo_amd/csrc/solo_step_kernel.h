@@ -122,7 +122,7 @@ __device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, const KBuffers<T>& B, const LegConst<T>& L,
-                                           const RowConst<T>& rc, const T* s_state, const T* s_tgt, T (*s_rowvec)[8],
+                                           const RowConst<T>& rc, const T* s_state, const T* s_tgt, T (*s_rowvec)[8], T (*s_hext)[8],
                                            T* s_keep, T (*s_leg)[20], T mu, T mass_scale, int lane) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
@@ -434,33 +434,40 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   for (int i = 0; i < 6; ++i) s_rowvec[lane][i] = gh[i];
   s_rowvec[lane][6] = hh[0];
   s_rowvec[lane][7] = hh[1];
+  // the joint-space part again, in the slot of this row's leg of a [64][4 legs x 2] array whose
+  // other slots stay zero: a lane reads the slot of ITS leg, so "same leg" needs no test
+  s_hext[lane][2 * leg] = hh[0];
+  s_hext[lane][2 * leg + 1] = hh[1];
   const unsigned long long touching = wave_ballot(live && type == ROW_NORMAL);
   wave_sync();
 
   SOLO_STAMP(B, 7);
   // ---- projected Gauss-Seidel, sparse in the rows that still move ---------------------------
   // Per-lane solver state: candidate v, impulse lam, bounds lo/hi (friction bounds follow their
-  // contact's normal impulse).  `pend` is the set of rows whose clamped candidate differs from
-  // their impulse by more than `ulps` units in the last place - evaluated for all 64 lanes at
-  // once (v_med3 + integer compare + the compare's own lane mask).  A sweep walks the pending rows
-  // in solver order (motor rows, then contacts by sphere) with a scalar find-first-set; only
-  // those rows cost anything, and after each change the mask is re-evaluated, so the decisions
-  // are the ones a dense sweep over every row would take.
+  // contact's normal impulse), dl = clamp(v) - lam.  `pend` is the set of rows with |dl| above the
+  // tolerance (solver_ulp_tolerance half-ulps of |lam|, relative) - evaluated for all 64 lanes at
+  // once (v_med3, subtract, compare; the compare's lane mask IS the set).  A sweep walks the
+  // pending rows in solver order (motor rows, then contacts by sphere) with a scalar
+  // find-first-set; only those rows cost anything, and after each change the set is re-evaluated,
+  // so the decisions are the ones a dense sweep over every row would take.
   const T nid = -inv_d;
   const T imp = P->motor_impulse;
   T lo = T(0), hi = T(0);
   if (is_motor) { lo = -imp; hi = imp; }
   else if (live && type == ROW_NORMAL) hi = R::big();
   T lamv = T(0);
-  T v = live ? w * nid : T(0);  // lam = 0 (idle lanes: +0, so that they never look pending)
+  T v = live ? w * nid : T(0);  // lam = 0
   SOLO_STAMP(B, 8);
-  const int ulps = wave_uniform(P->ulp_tol);
+  const T tol_rel = T(wave_uniform(P->ulp_tol)) * R::half_ulp();
   const int iters = wave_uniform(P->iterations);  // scalar trip count
   constexpr unsigned long long kMotorLanes = 0x0003000300030003ull;   // k = 0, 1 of each leg
   constexpr unsigned long long kNormalLanes = 0x0924092409240924ull;  // k = 2, 5, 8, 11
-  const int my_leg = lane >> 4;
+  RowDot<T> own;
+  own.set(gh, hh);
+  const T* my_hext = &s_hext[0][2 * leg];  // + 8 r: row r's joint-space part if r is on this lane's leg, else 0
   T cand = R::clamp(v, lo, hi);
-  unsigned long long pend = wave_ballot(ulps_exceed(cand, lamv, ulps));
+  T dl = cand - lamv;
+  unsigned long long pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
 #ifdef SOLO_STAMPS
   int n_changed = 0;
 #endif
@@ -476,27 +483,21 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
         window &= ~((2ull << r) - 1ull);               // the cursor moves past it
         // column r of the scaled Delassus matrix, from the whitened row vectors in LDS:
         // -(ghat_s . ghat_r + [same leg] hhat_s . hhat_r) / A_ss, and 0 for the row itself
-        T rv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rv[i] = s_rowvec[r][i];  // one wave-uniform 32-B broadcast
-        const T a1 = gh[0] * rv[0] + gh[1] * rv[1] + gh[2] * rv[2];
-        const T a2 = gh[3] * rv[3] + gh[4] * rv[4] + gh[5] * rv[5];
-        const T hb = hh[0] * rv[6] + hh[1] * rv[7];
-        const T b = (my_leg == (r >> 4)) ? hb : T(0);
-        const T scale = (lane == r) ? T(0) : nid;
-        const T col = ((a1 + a2) + b) * scale;
-        const T delta = wave_readlane(cand - lamv, r);
-        v = R::fma(col, delta, v);
+        const T dotp = own.dot(s_rowvec[r], my_hext + 8 * r);
+        const T delta = wave_readlane(dl, r);
+        const T sd = (lane == r) ? T(0) : nid * delta;
+        v = R::fma(dotp, sd, v);
         lamv = (lane == r) ? cand : lamv;
         if ((kNormalLanes >> r) & 1ull) {
           // a normal row moved: its two friction rows are limited by mu * (fresh normal impulse)
           const T lim = mu * wave_readlane(cand, r);
           const bool mine = (unsigned)(lane - r - 1) < 2u;
-          lo = mine ? T(0) - lim : lo;  // (0 - 0 = +0: a zero bound must not be -0)
+          lo = mine ? T(0) - lim : lo;  // (0 - 0 = +0)
           hi = mine ? lim : hi;
         }
         cand = R::clamp(v, lo, hi);
-        pend = wave_ballot(ulps_exceed(cand, lamv, ulps));
+        dl = cand - lamv;
+        pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
 #ifdef SOLO_STAMPS
         ++n_changed;
 #endif
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_state[SOLO_STATE_STRIDE];
   __shared__ T s_tgt[16];
   __shared__ T s_rowvec[64][8];
+  __shared__ T s_hext[64][8];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][20];
   __shared__ T s_src[48];
@@ -622,6 +624,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   double* stats = B.stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH;
 
   const KParams<T>* __restrict__ const P0 = Pin;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s_hext[lane0][i] = T(0);
   {
     constexpr int kLegWords = (int)(sizeof(LegConst<T>) * 4 / sizeof(T));
     const T* src = reinterpret_cast<const T*>(P0->leg);
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     SOLO_STAMP(B, 1);
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
-      const T lam = physics_solve<T>(P, B, L, rc, s_state, s_tgt, s_rowvec, s_keep, s_leg, mu, mass_scale, lane);
+      const T lam = physics_solve<T>(P, B, L, rc, s_state, s_tgt, s_rowvec, s_hext, s_keep, s_leg, mu, mass_scale, lane);
       physics_finish<T>(P, s_state, s_rowvec, s_keep, s_leg, lam, lane);
       // a robot whose state went non-finite is restored from its snapshot and counted
       const bool bad = lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31]);

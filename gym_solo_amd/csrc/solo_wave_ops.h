@@ -34,36 +34,6 @@ __device__ __forceinline__ void wave_pin_group(float& a, float& b, float& c, flo
 __device__ __forceinline__ void wave_pin_group(double& a, double& b, double& c) { a = wave_pin(a); b = wave_pin(b); c = wave_pin(c); }
 __device__ __forceinline__ void wave_pin_group(double& a, double& b, double& c, double& d) { a = wave_pin(a); b = wave_pin(b); c = wave_pin(c); d = wave_pin(d); }
 __device__ __forceinline__ int wave_readlane_int(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
-// both arguments are wave-uniform (SGPRs): integer compare of the bit patterns on the SALU
-__device__ __forceinline__ bool wave_uniform_bits_differ(float a, float b) {
-  return __builtin_amdgcn_readfirstlane(__float_as_int(a)) != __builtin_amdgcn_readfirstlane(__float_as_int(b));
-}
-__device__ __forceinline__ bool wave_uniform_bits_differ(double a, double b) {
-  const long long x = __double_as_longlong(a) ^ __double_as_longlong(b);
-  return (__builtin_amdgcn_readfirstlane((int)(x & 0xffffffffll)) | __builtin_amdgcn_readfirstlane((int)(x >> 32))) != 0;
-}
-// both arguments wave-uniform: do they differ by MORE than k units in the last place?  Integer
-// arithmetic on the bit patterns (the SALU has no float compare); values of opposite sign count as
-// different.  k = 0 is wave_uniform_bits_differ.
-__device__ __forceinline__ bool wave_uniform_ulps_exceed(float a, float b, int k) {
-  const unsigned d = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(a)) - (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(b)) + (unsigned)k;
-  return d > 2u * (unsigned)k;
-}
-__device__ __forceinline__ bool wave_uniform_ulps_exceed(double a, double b, int k) {
-  const long long x = __double_as_longlong(a), y = __double_as_longlong(b);
-  const unsigned long long d = (unsigned long long)x - (unsigned long long)y + (unsigned long long)k;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(d & 0xffffffffull));
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32));
-  return hi != 0u || lo > 2u * (unsigned)k;
-}
-// per-lane: do a and b differ by more than k units in the last place?  (values of opposite sign,
-// including +0 / -0, count as different)
-__device__ __forceinline__ bool ulps_exceed(float a, float b, int k) {
-  return (unsigned)(__float_as_uint(a) - __float_as_uint(b) + (unsigned)k) > 2u * (unsigned)k;
-}
-__device__ __forceinline__ bool ulps_exceed(double a, double b, int k) {
-  return (unsigned long long)(__double_as_longlong(a) - __double_as_longlong(b) + (long long)k) > 2ull * (unsigned long long)k;
-}
 // declares an int wave-uniform (v_readfirstlane -> SGPR)
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // compiler scheduling fence (no instruction): instructions are not moved across it
@@ -136,6 +106,38 @@ __device__ __forceinline__ float wave_sum_all(float x) {
 __device__ __forceinline__ double wave_sum_all(double x) { return wave_sum_legs(wave_sum_group16(x)); }
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 
+// ghat_s . ghat_r + hhat_s . x for the Delassus columns: the lane's own whitened row stays in
+// registers, the other row comes from LDS.  f32: four v_pk_fma_f32 (two terms each) + one add.
+typedef float solo_f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct RowDot {
+  T g[6], h[2];
+  __device__ __forceinline__ void set(const T* gh, const T* hh) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = gh[i];
+    h[0] = hh[0]; h[1] = hh[1];
+  }
+  __device__ __forceinline__ T dot(const T* rg, const T* rh) const {
+    const T a1 = g[0] * rg[0] + g[1] * rg[1] + g[2] * rg[2];
+    const T a2 = g[3] * rg[3] + g[4] * rg[4] + g[5] * rg[5];
+    return (a1 + a2) + (h[0] * rh[0] + h[1] * rh[1]);
+  }
+};
+template <> struct RowDot<float> {
+  solo_f32x2 g01, g23, g45, h01;
+  __device__ __forceinline__ void set(const float* gh, const float* hh) {
+    g01 = solo_f32x2{gh[0], gh[1]}; g23 = solo_f32x2{gh[2], gh[3]}; g45 = solo_f32x2{gh[4], gh[5]};
+    h01 = solo_f32x2{hh[0], hh[1]};
+  }
+  __device__ __forceinline__ float dot(const float* rg, const float* rh) const {
+    const solo_f32x2* r = reinterpret_cast<const solo_f32x2*>(rg);
+    solo_f32x2 acc = g01 * r[0];
+    acc = g23 * r[1] + acc;
+    acc = g45 * r[2] + acc;
+    acc = h01 * *reinterpret_cast<const solo_f32x2*>(rh) + acc;
+    return acc.x + acc.y;
+  }
+};
+
 template <typename T> struct Real;
 // f32: hardware v_sqrt / v_rsq / v_rcp (<= 1 ulp each) instead of the IEEE-correct library
 // sequences (~10-25 instructions apiece), and a Cody-Waite + minimax sincos (~25 instructions,
@@ -193,6 +195,7 @@ template <> struct Real<float> {
   static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
   static __device__ __forceinline__ float floor(float x) { return floorf(x); }
   static __device__ __forceinline__ float big() { return 3.0e38f; }
+  static __device__ __forceinline__ float half_ulp() { return 5.9604645e-8f; }  // 2^-24
 };
 template <> struct Real<double> {
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
@@ -210,6 +213,7 @@ template <> struct Real<double> {
   static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
   static __device__ __forceinline__ double floor(double x) { return ::floor(x); }
   static __device__ __forceinline__ double big() { return 1.0e300; }
+  static __device__ __forceinline__ double half_ulp() { return 1.1102230246251565e-16; }  // 2^-53
 };
 
 __device__ __forceinline__ void stats_add(double* p, double v) { atomicAdd(p, v); }

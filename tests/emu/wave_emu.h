@@ -128,24 +128,15 @@ template <typename T> inline void wave_pin_group(T&, T&, T&) {}
 template <typename T> inline void wave_pin_group(T&, T&, T&, T&) {}
 inline int wave_uniform(int x) { return x; }
 inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
-inline bool wave_uniform_bits_differ(float a, float b) { return std::memcmp(&a, &b, 4) != 0; }
-inline bool wave_uniform_bits_differ(double a, double b) { return std::memcmp(&a, &b, 8) != 0; }
-inline bool ulps_exceed(float a, float b, int k) {
-  uint32_t x, y; std::memcpy(&x, &a, 4); std::memcpy(&y, &b, 4);
-  return (uint32_t)(x - y + (uint32_t)k) > 2u * (uint32_t)k;
-}
-inline bool ulps_exceed(double a, double b, int k) {
-  uint64_t x, y; std::memcpy(&x, &a, 8); std::memcpy(&y, &b, 8);
-  return (uint64_t)(x - y + (uint64_t)k) > 2ull * (uint64_t)k;
-}
-inline bool wave_uniform_ulps_exceed(float a, float b, int k) {
-  uint32_t x, y; std::memcpy(&x, &a, 4); std::memcpy(&y, &b, 4);
-  return (uint32_t)(x - y + (uint32_t)k) > 2u * (uint32_t)k;
-}
-inline bool wave_uniform_ulps_exceed(double a, double b, int k) {
-  uint64_t x, y; std::memcpy(&x, &a, 8); std::memcpy(&y, &b, 8);
-  return (uint64_t)(x - y + (uint64_t)k) > 2ull * (uint64_t)k;
-}
+template <typename T> struct RowDot {
+  T g[6], h[2];
+  void set(const T* gh, const T* hh) { for (int i = 0; i < 6; ++i) g[i] = gh[i]; h[0] = hh[0]; h[1] = hh[1]; }
+  T dot(const T* rg, const T* rh) const {
+    const T a1 = g[0] * rg[0] + g[1] * rg[1] + g[2] * rg[2];
+    const T a2 = g[3] * rg[3] + g[4] * rg[4] + g[5] * rg[5];
+    return (a1 + a2) + (h[0] * rh[0] + h[1] * rh[1]);
+  }
+};
 
 inline float wave_readlane(float x, int lane) {
   uint32_t b; std::memcpy(&b, &x, 4);
@@ -198,6 +189,7 @@ template <> struct Real<float> {
   static float fma(float a, float b, float c) { return std::fma(a, b, c); }
   static float floor(float x) { return std::floor(x); }
   static float big() { return 3.0e38f; }
+  static float half_ulp() { return 5.9604645e-8f; }
 };
 template <> struct Real<double> {
   static double sqrt(double x) { return std::sqrt(x); }
@@ -215,6 +207,7 @@ template <> struct Real<double> {
   static double fma(double a, double b, double c) { return std::fma(a, b, c); }
   static double floor(double x) { return std::floor(x); }
   static double big() { return 1.0e300; }
+  static double half_ulp() { return 1.1102230246251565e-16; }
 };
 
 inline void stats_add(double* p, double v) { *p += v; }

@@ -60,3 +60,24 @@ for n, spl in ((1024, 100), (4096, 100)):
   print('fused N=%d S=%d: per-robot mean step (ticks) percentiles 1/50/90/99/max: %s ; launch makespan/steps = %.0f ; mean %.0f' % (
     n, spl, np.percentile(per_step, [1, 50, 90, 99, 100]).astype(int).tolist(), (t1.max() - t0.min()) / spl, per_step.mean()))
   env._close()
+
+# ---- is a robot's cost persistent from one fused launch to the next? (would cost-sorted slices pay?)
+n, spl = 4096, 100
+env = build_env(n, 0, 'float32', steps_per_launch=spl, rollout_streams=1)
+eng = env.engine
+g = torch.Generator(device='cuda').manual_seed(7)
+acts = (torch.rand(400, n, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
+eng.rollout(acts, abi.STEP_ALL)
+tot = []
+for j in range(4):
+  eng.rollout(acts[j * spl:(j + 1) * spl], abi.STEP_ALL)
+  buf = np.zeros((n, 32), dtype=np.uint64)
+  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
+  tot.append((buf[:, 14].astype(np.int64) - buf[:, 0].astype(np.int64)) / spl)
+tot = np.array(tot)
+print('launch-to-launch correlation of per-robot cost (100-step launches): %s' % np.round([np.corrcoef(tot[j], tot[j + 1])[0, 1] for j in range(3)], 3).tolist())
+for j in range(3):
+  order = np.argsort(tot[j])  # sort by the PREVIOUS launch's cost, look at this launch's maxima per quartile
+  q = [tot[j + 1][order[i * n // 4:(i + 1) * n // 4]].max() for i in range(4)]
+  print('   quartiles by previous cost -> max cost now: %s ; overall max %d mean %d' % (np.array(q).astype(int).tolist(), tot[j + 1].max(), tot[j + 1].mean()))
+env._close()
