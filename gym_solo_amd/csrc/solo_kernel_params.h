@@ -24,12 +24,6 @@ namespace solo {
 enum RowType : int32_t { ROW_IDLE = 0, ROW_MOTOR = 1, ROW_NORMAL = 2, ROW_TAN1 = 3, ROW_TAN2 = 4 };
 enum BodyKind : int32_t { BODY_BASE = 0, BODY_UPPER = 1, BODY_LOWER = 2 };
 
-// Register slots of the solver: 8 motor rows + 3 rows for each of at most kMaxContacts touching
-// spheres.  12 is the geometric maximum for this model on a plane: of the 8 base-box corner
-// spheres at most one face (4) can be within the contact margin of a plane, plus 4 knees and 4
-// feet.  A 13th touching sphere (impossible on flat ground) is dropped and counted in stats[6].
-constexpr int kMaxContacts = 12;
-constexpr int kNumRowSlots = SOLO_NUM_DOF + 3 * kMaxContacts;  // 44 (Delassus row length)
 __host__ __device__ constexpr int motor_lane(int dof) { return 16 * (dof >> 1) + (dof & 1); }
 __host__ __device__ constexpr int sphere_lane(int s) { return 16 * (s >> 2) + 2 + 3 * (s & 3); }
 

@@ -10,23 +10,24 @@
 //  * grid = N workgroups of 64 threads; the robot's 128-B state record is ONE coalesced load.
 //  * lane = 16*leg + k.  The four 16-lane groups run the leg-local part of the articulated
 //    dynamics (kinematics, composite inertias, Newton-Euler bias) in parallel; the base-level
-//    sums over the legs are wavefront shuffles (xor 16 / xor 32).
+//    sums over the legs go through LDS (27 terms at once) or DPP row broadcasts.
 //  * The floating base couples the legs only through a 6x6 block, so the joint-space inverse
 //    inertia is applied in factored form: Cholesky of the four 2x2 leg blocks P_l and of the
 //    6x6 base Schur complement S = M_bb - sum_l M_bl P_l^-1 M_lb (the base's articulated-body
 //    inertia).  Every constraint row r (8 motor rows + 3 per touching sphere) is owned by ONE
 //    LANE, which whitens its Jacobian against those factors (ghat_r in R^6, hhat_r in R^2), so
 //    that the Delassus matrix is  A_sr = ghat_s.ghat_r + [same leg] hhat_s.hhat_r.
-//  * Lane s keeps row s of A in registers (56 VGPRs in f32).  Projected Gauss-Seidel then costs
-//    per row: one fma + clamp + v_readlane broadcast of the impulse change + one fma in every
-//    lane; rows of spheres that do not touch are skipped with wave-uniform branches (no
-//    divergence: the whole wave belongs to one robot).
+//  * The matrix is never stored.  Projected Gauss-Seidel keeps, per lane, the row's candidate,
+//    impulse and bounds; the rows that still move are found for all lanes at once (clamp,
+//    subtract, compare: the compare's lane mask is the set) and only those are visited, in solver
+//    order, each one rebuilding its Delassus column from the whitened row vectors in LDS (see
+//    physics_solve).  All branching is wave-uniform: the whole wave belongs to one robot.
 //  * obs / reward / done are evaluated from the new state by the same wave (lane k = obs
 //    element k -> one coalesced store), reward as a small postfix program.
 // No MFMA: there is no dense contraction here (14 dofs, <= 56 rows per robot).
 //
 // The including translation unit must provide solo::lane_id/block_id/wave_sync/wave_readlane/
-// wave_sum_legs/wave_sum_group16/wave_ballot/Real<T>/stats_add (solo_wave_ops.h on the GPU).
+// wave_sum_group16/wave_sum_all/wave_ballot/RowDot<T>/Real<T>/stats_add (solo_wave_ops.h on the GPU).
 #pragma once
 
 #include "solo_kernel_params.h"
@@ -83,7 +84,6 @@ template <typename T> __device__ __forceinline__ void rot_inertia_y(T c, T s, co
   o[4] = cs * (I[2] - I[0]) + (cc - ss) * I[4];
   o[5] = c * I[5] - s * I[3];
 }
-template <typename T> __device__ __forceinline__ T sum_over_legs(T x) { return wave_sum_legs(x); }
 template <typename T> __device__ __forceinline__ T sum_over_group16(T x) { return wave_sum_group16(x); }
 
 // Euler angles of pybullet.getEulerFromQuaternion ([recalled] pybullet.c; call sites

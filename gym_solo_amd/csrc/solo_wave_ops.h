@@ -24,20 +24,9 @@ __device__ __forceinline__ int wave_opaque_lane(int lane) {
   asm volatile("" : "+v"(lane));
   return lane;
 }
-// pins a per-lane value: it is materialised at this point of the program (no instruction)
-__device__ __forceinline__ float wave_pin(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ double wave_pin(double x) { asm volatile("" : "+v"(x)); return x; }
-// pins a group at ONE point: the loads feeding all of them may be in flight together (f32), or
-// one after the other where registers are short (f64: every value is a register pair)
-__device__ __forceinline__ void wave_pin_group(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
-__device__ __forceinline__ void wave_pin_group(float& a, float& b, float& c, float& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
-__device__ __forceinline__ void wave_pin_group(double& a, double& b, double& c) { a = wave_pin(a); b = wave_pin(b); c = wave_pin(c); }
-__device__ __forceinline__ void wave_pin_group(double& a, double& b, double& c, double& d) { a = wave_pin(a); b = wave_pin(b); c = wave_pin(c); d = wave_pin(d); }
 __device__ __forceinline__ int wave_readlane_int(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
 // declares an int wave-uniform (v_readfirstlane -> SGPR)
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
-// compiler scheduling fence (no instruction): instructions are not moved across it
-__device__ __forceinline__ void wave_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ float wave_readlane(float x, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
@@ -51,11 +40,6 @@ __device__ __forceinline__ double wave_readlane(double x, int lane) {
 // ---- cross-lane sums without LDS traffic ---------------------------------------------------
 // v_permlane16_swap / v_permlane32_swap (new on gfx950) exchange odd<->even 16-lane rows and
 // the two 32-lane halves inside the VALU; DPP row rotations fold into the v_add itself.
-__device__ __forceinline__ unsigned swap_rows16_add_helper(unsigned u, unsigned* other) {
-  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  *other = r[1];
-  return r[0];
-}
 // x[lane] + x[lane^16] + x[lane^32] + x[lane^48]: sum over the four 16-lane leg groups
 __device__ __forceinline__ float wave_sum_legs(float x) {
   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);

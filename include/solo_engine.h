@@ -216,8 +216,7 @@ typedef struct SoloStateView {
   void* term_count;     /* int32 [N][SOLO_MAX_TERMS]                      */
   void* params;         /* real  [N][4]: lateral friction, base-mass scale, 2 spare */
   void* stats;          /* double[SOLO_STATS_SHARDS][8], sum over the shard axis: sum return, sum return^2,
-                           episodes, sum length, (unused), diverged robots restored, steps with >12 touching
-                           spheres (extras dropped; impossible on a plane), spare */
+                           episodes, sum length, (unused), diverged robots restored, 2 spare */
 } SoloStateView;
 
 typedef struct SoloEngine SoloEngine;

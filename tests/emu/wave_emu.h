@@ -120,12 +120,8 @@ class WaveEmu {
 inline int lane_id() { return WaveEmu::get().lane(); }
 inline int block_id() { return blockIdx.x; }
 inline void wave_sync() { WaveEmu::get().yield(); }
-inline void wave_sched_fence() {}
 template <typename P> inline P* wave_opaque(P* p) { return p; }
 inline int wave_opaque_lane(int lane) { return lane; }
-template <typename T> inline T wave_pin(T x) { return x; }
-template <typename T> inline void wave_pin_group(T&, T&, T&) {}
-template <typename T> inline void wave_pin_group(T&, T&, T&, T&) {}
 inline int wave_uniform(int x) { return x; }
 inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
 template <typename T> struct RowDot {

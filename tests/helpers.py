@@ -40,3 +40,13 @@ def bumpy_terrain(seed=0, n=64, cell=0.05, amp=0.02):
   from gym_solo_amd import abi
   rng = np.random.default_rng(seed)
   return abi.make_terrain(amp * rng.standard_normal((n, n)), cell)
+
+
+def trench_terrain(half=0.04, slope=4.0, n=96, cell=0.01):
+  """A trench along x narrower than the base box: its walls touch the TOP corner spheres of the
+  base while the floor side touches the bottom ones, so more than 12 of the 16 collision spheres
+  can be in contact at once (impossible on a plane)."""
+  from gym_solo_amd import abi
+  ys = (np.arange(n) - 0.5 * (n - 1)) * cell
+  h = np.clip((np.abs(ys) - half) * slope, 0.0, 0.5)
+  return abi.make_terrain(np.tile(h[:, None], (1, n)), cell)

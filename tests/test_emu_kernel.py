@@ -168,3 +168,27 @@ def test_flailing_batch_matches_oracle_every_step():
     ph.step(st, a)
     e.step(a, abi.STEP_PHYSICS)
     np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=1e-9, err_msg='step %d' % k)
+
+
+def test_all_sixteen_spheres_in_contact():
+  """More than 12 touching spheres (impossible on a plane, possible on a heightfield): a robot
+  wedged into a trench narrower than its base has all 16 collision spheres in contact (56
+  constraint rows).  The solver has no contact cap; kernel vs oracle over the violent first steps."""
+  import helpers
+  terrain = helpers.trench_terrain()
+  ca, ma = make_abi('float64', settle_steps=0)
+  ph = so.OraclePhysics(ca, ma, terrain=terrain)
+  st = ph.initial_state(1)
+  st[:, abi.S_POS + 2] = 0.08
+  st[:, abi.S_Q:abi.S_Q + 8] = [np.pi / 2, np.pi, np.pi / 2, np.pi, -np.pi / 2, -np.pi, -np.pi / 2, -np.pi]
+  a = np.array([[np.pi / 2, np.pi, 0, np.pi / 2, np.pi, 0, -np.pi / 2, -np.pi, 0, -np.pi / 2, -np.pi, 0]])
+  e = EmuEngine(ca, ma, 1, terrain=terrain)
+  e.state[:] = st
+  contacts = []
+  for k in range(4):
+    dbg = ph.step_debug(st[0].copy(), a[0][[0, 1, 3, 4, 6, 7, 9, 10]])
+    contacts.append((dbg.num_rows - 8) // 3)
+    ph.step(st, a)
+    e.step(a, abi.STEP_PHYSICS)
+    np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=1e-9, atol=1e-9, err_msg='step %d' % k)
+  assert max(contacts) == 16
