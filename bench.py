@@ -131,7 +131,7 @@ def main():
   ap.add_argument('--envs-per-gpu', type=int, default=4096)
   ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--steps-per-launch', type=int, default=100,
+  ap.add_argument('--steps-per-launch', type=int, default=250,
                   help='env steps of every robot fused into one kernel launch by the open-loop rollout '
                        '(1 = one launch per step, the closed-loop granularity)')
   ap.add_argument('--rollout-streams', type=int, default=2,

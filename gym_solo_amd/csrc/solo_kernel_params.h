@@ -48,7 +48,7 @@ struct RowConst {
 template <typename T>
 struct ObsElemK {
   int32_t src, flags;
-  T scale, lo, hi, nlo, range;  // normalise: 2*(a - nlo)/range - 1, range = nhi - nlo (obs.py:152)
+  T scale, lo, hi, nscale, noff;  // normalise: 2*(a - nlo)/(nhi - nlo) - 1 (obs.py:152) as a * nscale + noff
 };
 
 template <typename T>
@@ -57,6 +57,7 @@ struct RewardInstrK {
   int32_t src;  // three-address form of the postfix program: src0 | src1 << 8 = indices of the
                 // instructions whose results this one consumes (SCALE: src0; ADD / MUL: both)
   T a, b, c;
+  T d;  // tolerance leaves: gaussian scale / margin (rewards.py:427), 0 when the margin is 0
 };
 
 template <typename T>
@@ -235,8 +236,9 @@ inline int pack_program(const SoloProgram& p, KParams<T>* k, std::string* err) {
     o.scale = (T)p.obs[i].scale;
     o.lo = (T)p.obs[i].lo;
     o.hi = (T)p.obs[i].hi;
-    o.nlo = (T)p.obs[i].nlo;
-    o.range = (T)(p.obs[i].nhi - p.obs[i].nlo);
+    const double range = (double)p.obs[i].nhi - (double)p.obs[i].nlo;
+    o.nscale = (T)(range != 0.0 ? 2.0 / range : 0.0);
+    o.noff = (T)(range != 0.0 ? -2.0 * (double)p.obs[i].nlo / range - 1.0 : 0.0);
   }
   for (int i = 0; i < p.num_reward_ops; ++i) {
     k->reward[i].op = p.reward[i].op;
@@ -244,6 +246,11 @@ inline int pack_program(const SoloProgram& p, KParams<T>* k, std::string* err) {
     k->reward[i].a = (T)p.reward[i].a;
     k->reward[i].b = (T)p.reward[i].b;
     k->reward[i].c = (T)p.reward[i].c;
+    double margin = 0.0;
+    if (p.reward[i].op == SOLO_R_FLAT_TORSO) margin = p.reward[i].b;
+    else if (p.reward[i].op == SOLO_R_TORSO_HEIGHT || p.reward[i].op == SOLO_R_HORIZ_SPEED) margin = p.reward[i].c;
+    else if (p.reward[i].op == SOLO_R_SMALL_CONTROL) margin = p.reward[i].a;
+    k->reward[i].d = (T)(margin != 0.0 ? std::sqrt(-2.0 * std::log(0.1)) / margin : 0.0);
   }
   for (int i = 0; i < SOLO_MAX_TERMS; ++i) {
     k->term_kind[i] = p.term_kind[i];

@@ -105,13 +105,13 @@ __device__ __forceinline__ void euler_from_quat(T x, T y, T z, T w, T* roll, T* 
   }
 }
 
-// gaussian tolerance, gym_solo/core/rewards.py:384-431 with margin_value = 0.1
+// gaussian tolerance, gym_solo/core/rewards.py:384-431 with margin_value = 0.1;
+// scale_over_margin = sqrt(-2 ln 0.1) / margin is prepared on the host (0 when margin = 0)
 template <typename T>
-__device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale) {
+__device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale_over_margin) {
   const bool within = (lo <= x) && (x <= hi);
   if (margin == T(0)) return within ? T(1) : T(0);
-  const T sig = ((x < lo) ? (lo - x) : (x - hi)) / margin;
-  const T t = sig * scale;
+  const T t = ((x < lo) ? (lo - x) : (x - hi)) * scale_over_margin;
   const T v = Real<T>::exp(T(-0.5) * (t * t));
   return within ? T(1) : v;
 }
@@ -507,7 +507,9 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   }
 #ifdef SOLO_STAMPS
   if (lane == 0) {
-    B.stamps[(size_t)(block_id() + B.env_base) * 32 + 15] = (unsigned long long)it | ((unsigned long long)__builtin_popcountll(touching) << 32);
+    // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28
+    const unsigned long long hw = (unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xfffff), xcc = (unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf);
+    B.stamps[(size_t)(block_id() + B.env_base) * 32 + 15] = (unsigned long long)(it & 0xffff) | ((unsigned long long)__builtin_popcountll(touching) << 16) | (xcc << 24) | (hw << 28);
     B.acc[15] += (unsigned long long)it;
     B.acc[0] += (unsigned long long)n_changed;
   }
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   const int n_rops = (B.flags & SOLO_STEP_REWARD) ? wave_uniform(P0->num_reward_ops) : 0;
   if (lane0 < SOLO_MAX_REWARD_OPS) {
     RewardInstrK<T> r0;
-    r0.op = -1; r0.src = 0; r0.a = r0.b = r0.c = T(0);
+    r0.op = -1; r0.src = 0; r0.a = r0.b = r0.c = r0.d = T(0);
     if (lane0 < n_rops) r0 = P0->reward[lane0];
     s_rprog[lane0] = r0;
   }
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
         const ObsElemK<T>& e = s_obsc[lane];
         T v = s_src[e.src] * e.scale;
         if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
-        if (e.flags & 2) v = (T(2) * (v - e.nlo)) / e.range - T(1);
+        if (e.flags & 2) v = R::fma(v, e.nscale, e.noff);
         B.obs[(size_t)step * B.obs_stride + (size_t)env * P->num_obs + lane] = v;
       }
     }
@@ -740,7 +742,6 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     T reward = T(0);
     if (n_rops > 0) {
       const RewardInstrK<T> rin = s_rprog[lane & (SOLO_MAX_REWARD_OPS - 1)];
-      const T gs = P->gauss_scale;
       const T vx = s_state[SOLO_S_LINVEL], vy = s_state[SOLO_S_LINVEL + 1];
       T sum = T(0);
 #pragma unroll
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
       else if (rin.op == SOLO_R_TORSO_HEIGHT) { x = s_state[SOLO_S_POS + 2]; lo = rin.a - rin.b; hi = rin.a + rin.b; mg = rin.c; }
       else if (rin.op == SOLO_R_HORIZ_SPEED) { x = R::sqrt(vx * vx + vy * vy); lo = rin.a - rin.b; hi = rin.a + rin.b; mg = rin.c; }
       else if (rin.op == SOLO_R_SMALL_CONTROL) { x = sum / T(SOLO_NUM_JOINTS); mg = rin.a; }  // mean over all 12 joints (rewards.py:297-300)
-      T val = tolerance<T>(x, lo, hi, mg, gs);
+      T val = tolerance<T>(x, lo, hi, mg, rin.d);
       const T fu = T(-1.5707963267948966);
       if (rin.op == SOLO_R_UPRIGHT) val = fu * pitch / (fu * fu);
       if (rin.op == SOLO_R_CONST) val = rin.a;

@@ -28,7 +28,7 @@ for n in [int(a) for a in sys.argv[1:]] or (1024, 4096):
   t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 14].astype(np.int64)
   life = t1 - t0
   print('   wave life percentiles 50/90/99/max: %s ; start skew (last start - first start) %d ; first start -> last end %d ticks' % (np.percentile(life, [50, 90, 99, 100]).astype(int).tolist(), t0.max() - t0.min(), t1.max() - t0.min()))
-  its = (buf[:, 15] & 0xffffffff).astype(np.int64); ncs = (buf[:, 15] >> 32).astype(np.int64)
+  its = (buf[:, 15] & 0xffff).astype(np.int64); ncs = ((buf[:, 15] >> 16) & 0xff).astype(np.int64)
   print('   sweeps executed: mean %.1f  hist(0,5,10,20,30,40,49,50)=%s' % (its.mean(), np.histogram(its, bins=[0,5,10,20,30,40,49,50,51])[0].tolist()))
   for c in range(0, 8):
     m = ncs == c
@@ -74,8 +74,22 @@ for j in range(4):
   buf = np.zeros((n, 32), dtype=np.uint64)
   assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
   tot.append((buf[:, 14].astype(np.int64) - buf[:, 0].astype(np.int64)) / spl)
+  hw = (buf[:, 15] >> 28).astype(np.int64); xcc = ((buf[:, 15] >> 24) & 0xf).astype(np.int64)
+  simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+  placements = globals().setdefault('placements', [])
+  placements.append(((((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd))
 tot = np.array(tot)
+# placement: which SIMD ran each robot's wave (XCC, SE, SH, CU, SIMD from HW_ID), is it the same every launch?
+place = []
 print('launch-to-launch correlation of per-robot cost (100-step launches): %s' % np.round([np.corrcoef(tot[j], tot[j + 1])[0, 1] for j in range(3)], 3).tolist())
+pl = np.array(placements)
+print('distinct SIMD ids seen: %d ; waves per SIMD min/max: %s ; same placement as previous launch: %s' % (
+  len(np.unique(pl[0])), np.bincount(np.unique(pl[0], return_inverse=True)[1]).min().__repr__() + '/' + np.bincount(np.unique(pl[0], return_inverse=True)[1]).max().__repr__(),
+  [float((pl[j] == pl[j + 1]).mean()) for j in range(3)]))
+u, inv = np.unique(pl[1], return_inverse=True)
+simd_sum = np.bincount(inv, weights=tot[1]); cnt = np.bincount(inv)
+print('per-SIMD sum of its robots cost: mean %.0f max %.0f (x%.2f) ; per-robot cost: mean %.0f max %.0f ; block ids sharing SIMD of block 0: %s' % (
+  simd_sum.mean(), simd_sum.max(), simd_sum.max() / simd_sum.mean(), tot[1].mean(), tot[1].max(), np.where(pl[1] == pl[1][0])[0].tolist()))
 for j in range(3):
   order = np.argsort(tot[j])  # sort by the PREVIOUS launch's cost, look at this launch's maxima per quartile
   q = [tot[j + 1][order[i * n // 4:(i + 1) * n // 4]].max() for i in range(4)]

@@ -9,8 +9,8 @@ from gym_solo_amd.workloads import register_benchmark_workload
 n = 4096
 g = torch.Generator(device='cuda').manual_seed(1234)
 acts = (torch.rand(1000, n, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
-for streams in (1, 2, 4):
-  for spl in (1, 5, 25, 100, 500):
+for streams in (1, 2, 3, 4, 8):
+  for spl in (1, 25, 100, 250, 1000):
     cfg = Solo8VanillaConfig()
     cfg.num_envs, cfg.dtype, cfg.auto_reset, cfg.steps_per_launch, cfg.rollout_streams = n, 'float32', True, spl, streams
     env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
