@@ -163,7 +163,8 @@ def main():
 
   n, k, w = args.envs_per_gpu, args.steps, args.warmup
   tdtype = torch.float32 if args.dtype == 'float32' else torch.float64
-  spl, streams = max(1, args.steps_per_launch), max(1, args.rollout_streams)
+  # (a run shorter than one fused launch fuses what it has: K steps per launch)
+  spl, streams = max(1, min(args.steps_per_launch, k)), max(1, args.rollout_streams)
   env = build_env(n, local_rank, args.dtype, steps_per_launch=spl, rollout_streams=streams)
   eng = env.engine
   gen = torch.Generator(device='cuda:%d' % local_rank).manual_seed(rank_seed(1234, rank))
