@@ -229,6 +229,7 @@ struct Engine final : EngineBase {
 
   int rollout(const void* a, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out, hipStream_t s) override {
     if (int rc = check_flags(flags)) return rc;
+    if (k == 0) return SOLO_OK;  // an empty rollout is a no-op
     if (!a || k < 0) { err = "rollout needs actions [K][N][12]"; return SOLO_ERR_INVALID_ARG; }
     return rollout_impl((const T*)a, k, flags, obs_out, reward_out, done_out, s, nullptr, nullptr);
   }

@@ -696,8 +696,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     if (B.flags & SOLO_STEP_PHYSICS) {
       const T lam = physics_solve<T>(P, B, L, rc, s_state, s_tgt, s_rowvec, s_hext, s_keep, s_leg, mu, mass_scale, lane);
       physics_finish<T>(P, s_state, s_rowvec, s_keep, s_leg, lam, lane);
-      // a robot whose state went non-finite is restored from its snapshot and counted
-      const bool bad = lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31]);
+      // a robot whose state went non-finite - or that was handed a non-finite target, which the
+      // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted
+      const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) ||
+                       (lane < SOLO_NUM_JOINTS && !R::finite(s_tgt[lane & 15]));
       diverged = wave_ballot(bad) != 0ull;
       if (diverged) {
         if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];

@@ -1,0 +1,116 @@
+"""Edge cases of the C-ABI on the GPU: single robot, ragged batch / rollout lengths against the
+fused-launch and stream-slice sizes, empty rollout, masked reset, a robot driven non-finite, bad
+arguments (the reference's own tests cover the 1-robot case only; these are the batched shapes)."""
+import numpy as np
+import pytest
+
+from gym_solo_amd import abi
+from helpers import make_abi, random_actions
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def torch():
+  import torch
+  if not torch.cuda.is_available():
+    pytest.skip('needs an MI355X')
+  return torch
+
+
+def _engine(n, dtype='float64', **kw):
+  from gym_solo_amd.engine import Engine
+  ca, ma = make_abi(dtype, **kw)
+  return Engine(ca, ma, n), ca, ma
+
+
+def test_single_robot_matches_oracle(torch):
+  from oracle import solo_oracle as so
+  eng, ca, ma = _engine(1)
+  ph = so.OraclePhysics(ca, ma)
+  st = eng.state.cpu().numpy().copy()
+  rng = np.random.default_rng(0)
+  for k in range(30):
+    a = random_actions(rng, 1)
+    ph.step(st, a)
+    eng.step(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+  np.testing.assert_allclose(eng.state.cpu().numpy()[:, :29], st[:, :29], rtol=0, atol=1e-9)
+  eng.close()
+
+
+@pytest.mark.parametrize('n,spl,streams,k', [(777, 7, 2, 23), (5, 4, 3, 9), (1, 3, 2, 4), (130, 1, 4, 3)])
+def test_ragged_sizes_fused_equals_single_steps(torch, n, spl, streams, k):
+  """Batch not divisible by the stream slices, rollout length not divisible by steps_per_launch,
+  more slices than make sense for the batch: same trajectories as K single steps, bit for bit."""
+  a, _, _ = _engine(n, 'float32', steps_per_launch=spl, rollout_streams=streams, settle_steps=50)
+  b, _, _ = _engine(n, 'float32', steps_per_launch=1, rollout_streams=1, settle_steps=50)
+  rng = np.random.default_rng(n)
+  acts = torch.as_tensor(rng.uniform(-6, 6, (k, n, 12)), device='cuda', dtype=torch.float32)
+  a.rollout(acts, abi.STEP_PHYSICS)
+  for i in range(k):
+    b.step(acts[i], abi.STEP_PHYSICS)
+  torch.cuda.synchronize()
+  assert torch.equal(a.state, b.state)
+  assert torch.equal(a.targets, b.targets)
+  a.close(); b.close()
+
+
+def test_empty_rollout_is_a_noop(torch):
+  eng, _, _ = _engine(8, 'float32', settle_steps=20)
+  before = eng.state.clone()
+  eng.rollout(torch.empty(0, 8, 12, device='cuda', dtype=torch.float32), abi.STEP_PHYSICS)
+  torch.cuda.synchronize()
+  assert torch.equal(eng.state, before)
+  eng.close()
+
+
+def test_masked_reset_restores_only_the_masked_robots(torch):
+  eng, _, _ = _engine(16, 'float32', settle_steps=50)
+  rng = np.random.default_rng(2)
+  for k in range(10):
+    eng.step(torch.as_tensor(random_actions(rng, 16), device='cuda', dtype=torch.float32), abi.STEP_PHYSICS)
+  moved = eng.state.clone()
+  mask = torch.zeros(16, dtype=torch.uint8, device='cuda')
+  mask[[1, 5, 15]] = 1
+  eng.reset(mask)
+  torch.cuda.synchronize()
+  sel = mask.bool()
+  assert torch.equal(eng.state[sel], eng.snapshot[sel])
+  assert torch.equal(eng.state[~sel], moved[~sel])
+  eng.reset()
+  torch.cuda.synchronize()
+  assert torch.equal(eng.state, eng.snapshot)
+  eng.close()
+
+
+def test_non_finite_robot_is_restored_and_counted(torch):
+  """A NaN target makes one robot's state non-finite: the kernel restores that robot from its
+  snapshot, counts it in the statistics, and its neighbours step on untouched."""
+  eng, _, _ = _engine(8, 'float32', settle_steps=50)
+  ref, _, _ = _engine(8, 'float32', settle_steps=50)
+  rng = np.random.default_rng(3)
+  a = random_actions(rng, 8).astype(np.float32)
+  bad = a.copy()
+  bad[2, 4] = np.nan
+  eng.step(torch.as_tensor(bad, device='cuda'), abi.STEP_PHYSICS)
+  ref.step(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+  torch.cuda.synchronize()
+  assert torch.isfinite(eng.state).all()
+  assert torch.equal(eng.state[2, :29], eng.snapshot[2, :29])
+  keep = [i for i in range(8) if i != 2]
+  assert torch.equal(eng.state[keep], ref.state[keep])
+  assert float(eng.stats[5]) == 1.0
+  eng.close(); ref.close()
+
+
+def test_bad_arguments_raise(torch):
+  eng, _, _ = _engine(4, 'float32', settle_steps=10)
+  with pytest.raises(ValueError):
+    eng.set_params(7, torch.ones(4, device='cuda'))
+  with pytest.raises((ValueError, TypeError)):
+    eng.step(torch.zeros(3, 12, device='cuda'), abi.STEP_PHYSICS)        # wrong batch size
+  with pytest.raises((ValueError, TypeError)):
+    eng.step(torch.zeros(4, 12, device='cuda', dtype=torch.float64), abi.STEP_PHYSICS)  # wrong dtype
+  with pytest.raises(ValueError):
+    eng.step(torch.zeros(4, 12, device='cuda'), abi.STEP_ALL)             # no program registered
+  eng.close()
