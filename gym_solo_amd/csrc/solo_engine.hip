@@ -54,6 +54,11 @@ struct Engine final : EngineBase {
   solo::KParams<T>* dparams = nullptr;
   T *state = nullptr, *snapshot = nullptr, *targets = nullptr, *params = nullptr, *obs = nullptr,
     *reward = nullptr, *settle_actions = nullptr;
+  // per-launch scratch of the output kernels: the step records [S][N][32] and, when a rollout does
+  // not record, the rewards [S][N] the returns kernel scans (S = steps per launch)
+  T *traj = nullptr, *reward_scratch = nullptr;
+  uint8_t* events = nullptr;  // [S][N] event bits of the launch's steps
+  bool skip_outputs = false;  // time_step: the step kernel alone
   uint8_t* done = nullptr;
   int32_t* term_count = nullptr;
   double* stats = nullptr;
@@ -71,7 +76,7 @@ struct Engine final : EngineBase {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : {(void*)dparams, (void*)state, (void*)snapshot, (void*)targets, (void*)params,
                     (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
-                    (void*)term_count, (void*)stats, (void*)terrain})
+                    (void*)term_count, (void*)stats, (void*)terrain, (void*)traj, (void*)reward_scratch, (void*)events})
       if (p) (void)hipFree(p);
   }
 
@@ -92,6 +97,9 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMalloc((void**)&done, (size_t)n));
     HIP_TRY(hipMalloc((void**)&term_count, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&stats, kStatsBytes));
+    HIP_TRY(hipMalloc((void**)&traj, (size_t)spl() * ns * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&reward_scratch, (size_t)spl() * n * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&events, (size_t)spl() * n));
     HIP_TRY(hipMemset(obs, 0, (size_t)n * SOLO_MAX_OBS * sizeof(T)));
     HIP_TRY(hipMemset(reward, 0, (size_t)n * sizeof(T)));
     HIP_TRY(hipMemset(done, 0, (size_t)n));
@@ -119,9 +127,9 @@ struct Engine final : EngineBase {
   solo::KBuffers<T> buffers(const T* actions, uint32_t flags) const {
     solo::KBuffers<T> b;
     b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
-    b.params = params; b.obs = obs; b.reward = reward; b.done = done; b.term_count = term_count;
+    b.params = params; b.traj = nullptr; b.events = events; b.done = done; b.term_count = term_count;
     b.stats = stats; b.terrain = terrain; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
-    b.action_stride = b.obs_stride = b.reward_stride = b.done_stride = 0;
+    b.action_stride = b.done_stride = 0;
 #ifdef SOLO_STAMPS
     b.stamps = stamps;
 #endif
@@ -204,25 +212,57 @@ struct Engine final : EngineBase {
 
   int spl() const { return cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1; }
 
-  // one chain of launches covering steps [0, k) for robots [lo, lo+count)
+  // one chain of launches covering steps [0, k) for robots [lo, lo+count): per launch the step
+  // kernel (one wave per robot, S fused steps), then - on the same stream - the output kernels
+  // over the S x count step records it left behind (one thread per robot-step / per robot)
   int launch_chain(const T* act, long long act_stride, int k, uint32_t flags, T* obs_out, T* reward_out,
                    uint8_t* done_out, hipStream_t s, int lo, int count) {
     const int S = spl();
+    const bool want_obs = (flags & SOLO_STEP_OBS) != 0, want_reward = (flags & SOLO_STEP_REWARD) != 0;
     for (int i = 0; i < k; i += S) {
+      const int steps = (k - i < S) ? (k - i) : S;
       solo::KBuffers<T> b = buffers(act ? act + (size_t)i * act_stride : nullptr, flags);
       b.env_base = lo;
-      b.steps = (k - i < S) ? (k - i) : S;
+      b.steps = steps;
       b.action_stride = act_stride;
-      if (obs_out) { b.obs = obs_out + (size_t)i * n * obs_dim; b.obs_stride = (long long)n * obs_dim; }
-      if (reward_out) { b.reward = reward_out + (size_t)i * n; b.reward_stride = n; }
+      if (want_obs || want_reward) b.traj = traj;
       if (done_out) { b.done = done_out + (size_t)i * n; b.done_stride = n; }
       // stepSimulation-only calls (settle loop, client.stepSimulation()) run the physics-only
-      // instantiation: no obs / reward / termination code, and a separate name in profiles
+      // instantiation: no termination code, and a separate name in profiles
       if (flags == SOLO_STEP_PHYSICS)
         hipLaunchKernelGGL((solo::solo_step_kernel<T, false>), dim3(count), dim3(64), 0, s, dparams, b);
       else
         hipLaunchKernelGGL((solo::solo_step_kernel<T, true>), dim3(count), dim3(64), 0, s, dparams, b);
       HIP_TRY(hipGetLastError());
+      if (skip_outputs || !(want_obs || want_reward)) continue;
+      // where this launch's outputs go: a recording rollout keeps every step ([K][N][.] buffers of
+      // the caller), otherwise only the last step's observation / reward stay in the engine's view
+      T* o = nullptr; long long o_stride = 0; int o_from = 0;
+      if (want_obs) {
+        if (obs_out) { o = obs_out + (size_t)i * n * obs_dim; o_stride = (long long)n * obs_dim; }
+        else { o = obs; o_stride = 0; o_from = steps - 1; }
+      }
+      T* r = nullptr; long long r_stride = 0;
+      if (want_reward) {
+        if (reward_out) { r = reward_out + (size_t)i * n; r_stride = n; }
+        else if (steps == 1) { r = reward; r_stride = 0; }
+        else { r = reward_scratch; r_stride = n; }
+      }
+      const long long items = (long long)steps * count;
+      const bool bookkeeping = want_reward && (flags & SOLO_STEP_DONE);
+      T* fused_returns = (bookkeeping && steps == 1) ? state : nullptr;  // single step: no third launch
+      hipLaunchKernelGGL(solo::solo_outputs_kernel<T>, dim3((unsigned)((items + solo::kOutputThreads - 1) / solo::kOutputThreads)),
+                         dim3(solo::kOutputThreads), 0, s, dparams, traj, steps, n, lo, count, o, o_stride, o_from, r, r_stride,
+                         fused_returns, events, stats);
+      HIP_TRY(hipGetLastError());
+      if (bookkeeping && steps > 1) {
+        hipLaunchKernelGGL(solo::solo_returns_kernel<T>, dim3((count + solo::kOutputThreads - 1) / solo::kOutputThreads),
+                           dim3(solo::kOutputThreads), 0, s, state, events, steps, n, lo, count, r, r_stride, stats);
+        HIP_TRY(hipGetLastError());
+      }
+      if (want_reward && r == reward_scratch)  // the view keeps the last step's reward
+        HIP_TRY(hipMemcpyAsync(reward + lo, reward_scratch + (size_t)(steps - 1) * n + lo, (size_t)count * sizeof(T),
+                               hipMemcpyDeviceToDevice, s));
     }
     return SOLO_OK;
   }
@@ -294,7 +334,10 @@ struct Engine final : EngineBase {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    if (int rc = rollout_impl((const T*)a, reps * spl(), flags, nullptr, nullptr, nullptr, s, e0, e1)) return rc;
+    skip_outputs = true;  // the dominant kernel alone (the output kernels are separate, short launches)
+    const int rc_chain = rollout_impl((const T*)a, reps * spl(), flags, nullptr, nullptr, nullptr, s, e0, e1);
+    skip_outputs = false;
+    if (rc_chain) return rc_chain;
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipStreamSynchronize(s));
     float t = 0;

@@ -91,8 +91,8 @@ struct KBuffers {
   T* targets;         // [N][12]
   const T* actions;   // [N][12] or null
   const T* params;    // [N][4]
-  T* obs;             // [N][D]
-  T* reward;          // [N]
+  T* traj;            // [steps][N][32] per-step records for the output kernels (solo_outputs.h), or null
+  uint8_t* events;    // [steps][N] per-step event bits for the returns kernel (with traj)
   uint8_t* done;      // [N]
   int32_t* term_count;  // [N][4]
   double* stats;      // [SOLO_STATS_SHARDS][8]
@@ -102,7 +102,7 @@ struct KBuffers {
   int32_t env_base;    // first robot of this launch (grid = robots of this launch)
   int32_t steps;       // env steps per launch (>= 1)
   // element strides between consecutive steps of a multi-step launch (0: reuse the buffer)
-  long long action_stride, obs_stride, reward_stride, done_stride;
+  long long action_stride, done_stride;
 #ifdef SOLO_STAMPS
   unsigned long long* stamps;  // [N][32] s_memtime stamps, DIAGNOSTIC builds only (make stamps):
                                // [0..15] absolute stamps of the launch's last step, [16+i] = ticks

@@ -1,0 +1,174 @@
+// solo_outputs.h — observations, rewards and episodic returns, evaluated PER ROBOT-STEP from the
+// state records the step kernel leaves behind.
+//
+// The step kernel (solo_step_kernel.h) is one wavefront per robot and bound by dependent-issue
+// latency; the reductions of the reference's factories
+//   ObservationFactory.get_obs   gym_solo/core/obs.py:130-159 (TorsoIMU :268-279, MotorEncoder :354-362)
+//   RewardFactory.get_reward     gym_solo/core/rewards.py:104-118 (+ the reward classes :121-373)
+// are pure functions of one robot's state after a step.  Evaluated inside the robot's wave they
+// were another ~25 % of serial latency per step (measured); evaluated here, one THREAD per
+// (step, robot) over a whole fused launch (hundreds of thousands of independent items), they are
+// throughput work that disappears next to the physics.  The functions below are plain per-item
+// code (no wave operations): the HIP kernels in solo_step_kernel.h call them per thread, the CPU
+// emulator harness (tests/emu) calls them in a loop.
+//
+// What the step kernel leaves behind per robot-step:
+//   traj   [steps][N][SOLO_STATE_STRIDE] reals: [0..28] the state after the step (before an
+//          auto-reset restores the snapshot), SOLO_S_* offsets
+//   events [steps][N] bytes: 1 = done, 2 = restarted from the snapshot
+#pragma once
+
+#include "solo_kernel_params.h"
+
+namespace solo {
+
+constexpr int kEventDone = 1, kEventRestart = 2;
+
+// Euler angles of pybullet.getEulerFromQuaternion ([recalled] pybullet.c; call sites
+// gym_solo/core/obs.py:271, rewards.py:233,265; known answer test_obs_observations.py:67-88)
+template <typename T>
+__device__ __forceinline__ void euler_from_quat(T x, T y, T z, T w, T* roll, T* pitch, T* yaw) {
+  using R = Real<T>;
+  const T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  const T sarg = T(-2) * (x * z - w * y);
+  const T half_pi = T(1.5707963267948966);
+  if (sarg <= T(-0.99999)) {
+    *roll = T(0); *pitch = -half_pi; *yaw = T(2) * R::atan2(x, -y);
+  } else if (sarg >= T(0.99999)) {
+    *roll = T(0); *pitch = half_pi; *yaw = T(2) * R::atan2(-x, y);
+  } else {
+    *roll = R::atan2(T(2) * (y * z + w * x), squ - sqx - sqy + sqz);
+    *pitch = R::asin(sarg);
+    *yaw = R::atan2(T(2) * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+}
+
+// gaussian tolerance, gym_solo/core/rewards.py:384-431 with margin_value = 0.1;
+// scale_over_margin = sqrt(-2 ln 0.1) / margin is prepared on the host (0 when margin = 0)
+template <typename T>
+__device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale_over_margin) {
+  const bool within = (lo <= x) && (x <= hi);
+  if (margin == T(0)) return within ? T(1) : T(0);
+  const T t = ((x < lo) ? (lo - x) : (x - hi)) * scale_over_margin;
+  const T v = Real<T>::exp(T(-0.5) * (t * t));
+  return within ? T(1) : v;
+}
+
+// element `src` of the observation source vector (include/solo_engine.h, SOLO_SRC_*); `src` is the
+// same for every item of a launch, so the branches are uniform
+template <typename T>
+__device__ __forceinline__ T source_value(const T* rec, int src, T roll, T pitch, T yaw) {
+  if (src < 3) return src == 0 ? roll : (src == 1 ? pitch : yaw);
+  if (src < 6) return rec[SOLO_S_LINVEL + src - 3];
+  if (src < 9) return rec[SOLO_S_ANGVEL + src - 6];
+  if (src < 33) {
+    const int j = (src - 9) % 12, off = src < 21 ? SOLO_S_Q : SOLO_S_QD;
+    return (j % 3 == 2) ? T(0) : rec[off + 2 * (j / 3) + (j % 3)];  // fixed ANKLE joints read 0
+  }
+  if (src < 36) return rec[SOLO_S_POS + src - 33];
+  if (src < 40) return rec[SOLO_S_QUAT + src - 36];
+  return T(1);
+}
+
+// observation program: per element source, scale, clip, normalise (obs.py:141-159)
+template <typename T>
+__device__ __forceinline__ void eval_observations(const KParams<T>* P, const T* rec, T roll, T pitch, T yaw, T* out) {
+  using R = Real<T>;
+  const int n = P->num_obs;
+  for (int i = 0; i < n; ++i) {
+    const ObsElemK<T>& e = P->obs[i];
+    T v = source_value<T>(rec, e.src, roll, pitch, yaw) * e.scale;
+    if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
+    if (e.flags & 2) v = R::fma(v, e.nscale, e.noff);
+    out[i] = v;
+  }
+}
+
+// reward program in three-address form (pack_program): instruction i's value goes to
+// val[i * stride]; leaves read the state, SCALE / ADD / MUL read earlier values.  Returns the value
+// of the last instruction (rewards.py:104-118: the weighted sum is compiled into the program).
+template <typename T>
+__device__ __forceinline__ T eval_reward(const KParams<T>* P, const T* rec, T roll, T pitch, T* val, int stride) {
+  using R = Real<T>;
+  const int n = P->num_reward_ops;
+  T last = T(0);
+  for (int i = 0; i < n; ++i) {
+    const RewardInstrK<T>& r = P->reward[i];
+    T v;
+    switch (r.op) {
+      case SOLO_R_UPRIGHT: {  // rewards.py:121-141: pitch relative to "fully upright" = -pi/2
+        const T fu = T(-1.5707963267948966);
+        v = fu * pitch / (fu * fu);
+        break;
+      }
+      case SOLO_R_FLAT_TORSO:  // rewards.py:256-269
+        v = tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -r.a, r.a, r.b, r.d);
+        break;
+      case SOLO_R_TORSO_HEIGHT:  // rewards.py:326-338
+        v = tolerance<T>(rec[SOLO_S_POS + 2], r.a - r.b, r.a + r.b, r.c, r.d);
+        break;
+      case SOLO_R_HORIZ_SPEED: {  // rewards.py:362-373
+        const T vx = rec[SOLO_S_LINVEL], vy = rec[SOLO_S_LINVEL + 1];
+        v = tolerance<T>(R::sqrt(vx * vx + vy * vy), r.a - r.b, r.a + r.b, r.c, r.d);
+        break;
+      }
+      case SOLO_R_SMALL_CONTROL: {  // rewards.py:290-301: mean |joint rate| over all 12 joints
+        T sum = T(0);
+        for (int j = 0; j < SOLO_NUM_DOF; ++j) sum += R::abs(rec[SOLO_S_QD + j]);
+        v = tolerance<T>(sum / T(SOLO_NUM_JOINTS), T(0), T(0), r.a, r.d);
+        break;
+      }
+      case SOLO_R_CONST: v = r.a; break;
+      case SOLO_R_SCALE: v = r.a * val[(r.src & 255) * stride]; break;
+      case SOLO_R_ADD: v = val[(r.src & 255) * stride] + val[((r.src >> 8) & 255) * stride]; break;
+      case SOLO_R_MUL: v = val[(r.src & 255) * stride] * val[((r.src >> 8) & 255) * stride]; break;
+      default: v = T(0); break;
+    }
+    val[i * stride] = v;
+    last = v;
+  }
+  return last;
+}
+
+// One robot's episodic bookkeeping over the `steps` steps of a launch, in step order: the
+// return / length accumulators live in the robot's state record (SOLO_S_RETURN / SOLO_S_EPLEN);
+// a restart closes them (and, when the episode really ended, adds it to the statistics shard).
+// Rewards and event bytes are fetched kChunk steps at a time (independent loads in flight) and
+// then consumed in order: the additions stay sequential, only the memory latency is overlapped.
+template <typename T, typename AddFn>
+__device__ __forceinline__ void accumulate_returns(T* state_rec, const uint8_t* events, long long events_stride, const T* reward,
+                                                   long long reward_stride, int steps, double* stats, AddFn add) {
+  constexpr int kChunk = 16;
+  T ret = state_rec[SOLO_S_RETURN], len = state_rec[SOLO_S_EPLEN];
+  for (int k0 = 0; k0 < steps; k0 += kChunk) {
+    T r[kChunk];
+    int ev[kChunk];
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+      const int k = (k0 + j < steps) ? k0 + j : steps - 1;  // (clamped: the tail re-reads the last step, unused)
+      r[j] = reward[(size_t)k * reward_stride];
+      ev[j] = events[(size_t)k * events_stride];
+    }
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+      if (k0 + j >= steps) break;
+      ret += r[j];
+      len += T(1);
+      if (ev[j] & kEventRestart) {
+        if (ev[j] & kEventDone) {
+          const double x = (double)ret;
+          add(&stats[0], x);
+          add(&stats[1], x * x);
+          add(&stats[2], 1.0);
+          add(&stats[3], (double)len);
+        }
+        ret = T(0);
+        len = T(0);
+      }
+    }
+  }
+  state_rec[SOLO_S_RETURN] = ret;
+  state_rec[SOLO_S_EPLEN] = len;
+}
+
+}  // namespace solo

@@ -31,6 +31,7 @@
 #pragma once
 
 #include "solo_kernel_params.h"
+#include "solo_outputs.h"
 
 // In-kernel phase stamps exist only in the diagnostic build (make -C gym_solo_amd/csrc stamps);
 // in the product build the macro expands to nothing.
@@ -86,35 +87,6 @@ template <typename T> __device__ __forceinline__ void rot_inertia_y(T c, T s, co
 }
 template <typename T> __device__ __forceinline__ T sum_over_group16(T x) { return wave_sum_group16(x); }
 
-// Euler angles of pybullet.getEulerFromQuaternion ([recalled] pybullet.c; call sites
-// gym_solo/core/obs.py:271, rewards.py:233,265; known answer test_obs_observations.py:67-88)
-template <typename T>
-__device__ __forceinline__ void euler_from_quat(T x, T y, T z, T w, T* roll, T* pitch, T* yaw) {
-  using R = Real<T>;
-  const T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
-  const T sarg = T(-2) * (x * z - w * y);
-  const T half_pi = T(1.5707963267948966);
-  if (sarg <= T(-0.99999)) {
-    *roll = T(0); *pitch = -half_pi; *yaw = T(2) * R::atan2(x, -y);
-  } else if (sarg >= T(0.99999)) {
-    *roll = T(0); *pitch = half_pi; *yaw = T(2) * R::atan2(-x, y);
-  } else {
-    *roll = R::atan2(T(2) * (y * z + w * x), squ - sqx - sqy + sqz);
-    *pitch = R::asin(sarg);
-    *yaw = R::atan2(T(2) * (x * y + w * z), squ + sqx - sqy - sqz);
-  }
-}
-
-// gaussian tolerance, gym_solo/core/rewards.py:384-431 with margin_value = 0.1;
-// scale_over_margin = sqrt(-2 ln 0.1) / margin is prepared on the host (0 when margin = 0)
-template <typename T>
-__device__ __forceinline__ T tolerance(T x, T lo, T hi, T margin, T scale_over_margin) {
-  const bool within = (lo <= x) && (x <= hi);
-  if (margin == T(0)) return within ? T(1) : T(0);
-  const T t = ((x < lo) ? (lo - x) : (x - hi)) * scale_over_margin;
-  const T v = Real<T>::exp(T(-0.5) * (t * t));
-  return within ? T(1) : v;
-}
 
 // ------------------------------------------------------------------------------------------
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
@@ -602,13 +574,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_hext[64][8];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][20];
-  __shared__ T s_src[48];
   // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
   // read them from LDS instead of paying a global-load latency each
   __shared__ LegConst<T> s_legc[4];
   __shared__ RowConst<T> s_rowc[64];
-  __shared__ ObsElemK<T> s_obsc[SOLO_MAX_OBS];
-  __shared__ RewardInstrK<T> s_rprog[SOLO_MAX_REWARD_OPS];
 
   const int lane0 = lane_id();
   const int env = block_id() + B.env_base;
@@ -634,15 +603,6 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     T* dst = reinterpret_cast<T*>(s_legc);
     for (int i = lane0; i < kLegWords; i += 64) dst[i] = src[i];
     s_rowc[lane0] = P0->row[lane0];
-    if (B.flags & SOLO_STEP_OBS) s_obsc[lane0] = P0->obs[lane0];
-  }
-  // reward program: lane i owns instruction i (leaves are evaluated lane-parallel)
-  const int n_rops = (B.flags & SOLO_STEP_REWARD) ? wave_uniform(P0->num_reward_ops) : 0;
-  if (lane0 < SOLO_MAX_REWARD_OPS) {
-    RewardInstrK<T> r0;
-    r0.op = -1; r0.src = 0; r0.a = r0.b = r0.c = r0.d = T(0);
-    if (lane0 < n_rops) r0 = P0->reward[lane0];
-    s_rprog[lane0] = r0;
   }
   // next step's action of this lane's joint, fetched one step ahead
   T act_next = T(0);
@@ -709,77 +669,9 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     }
 
     SOLO_STAMP(B, 10);
-    // ---- source vector for the observation program (see include/solo_engine.h) -------------
-    const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
-    T roll, pitch, yaw;
-    euler_from_quat<T>(qx, qy, qz, qw, &roll, &pitch, &yaw);
-    if (B.flags & SOLO_STEP_OBS) {
-      if (lane < SOLO_SRC_COUNT) {
-        T v;
-        if (lane < 3) v = lane == 0 ? roll : (lane == 1 ? pitch : yaw);
-        else if (lane < 6) v = s_state[SOLO_S_LINVEL + lane - 3];
-        else if (lane < 9) v = s_state[SOLO_S_ANGVEL + lane - 6];
-        else if (lane < 33) {
-          const int j = (lane - 9) % 12, off = lane < 21 ? SOLO_S_Q : SOLO_S_QD;
-          v = (j % 3 == 2) ? T(0) : s_state[off + 2 * (j / 3) + (j % 3)];
-        } else if (lane < 36) v = s_state[SOLO_S_POS + lane - 33];
-        else if (lane < 40) v = s_state[SOLO_S_QUAT + lane - 36];
-        else v = T(1);
-        s_src[lane] = v;
-      }
-      wave_sync();
-      if (lane < P->num_obs) {
-        const ObsElemK<T>& e = s_obsc[lane];
-        T v = s_src[e.src] * e.scale;
-        if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
-        if (e.flags & 2) v = R::fma(v, e.nscale, e.noff);
-        B.obs[(size_t)step * B.obs_stride + (size_t)env * P->num_obs + lane] = v;
-      }
-    }
-
-    SOLO_STAMP(B, 11);
-    // ---- reward: lane i evaluates leaf instruction i (all leaves at once: one tolerance() for
-    //      the wave), then the SCALE / ADD / MUL instructions are folded in program order with
-    //      v_readlane fetches of their operands (three-address form prepared on the host) ---------
-    T reward = T(0);
-    if (n_rops > 0) {
-      const RewardInstrK<T> rin = s_rprog[lane & (SOLO_MAX_REWARD_OPS - 1)];
-      const T vx = s_state[SOLO_S_LINVEL], vy = s_state[SOLO_S_LINVEL + 1];
-      T sum = T(0);
-#pragma unroll
-      for (int j = 0; j < SOLO_NUM_DOF; ++j) sum += R::abs(s_state[SOLO_S_QD + j]);
-      // argument and bounds of this lane's tolerance() (rewards.py:256-269,290-301,326-338,362-373)
-      T x = T(0), lo = T(0), hi = T(0), mg = T(1);
-      if (rin.op == SOLO_R_FLAT_TORSO) { x = R::sqrt(roll * roll + pitch * pitch); lo = -rin.a; hi = rin.a; mg = rin.b; }
-      else if (rin.op == SOLO_R_TORSO_HEIGHT) { x = s_state[SOLO_S_POS + 2]; lo = rin.a - rin.b; hi = rin.a + rin.b; mg = rin.c; }
-      else if (rin.op == SOLO_R_HORIZ_SPEED) { x = R::sqrt(vx * vx + vy * vy); lo = rin.a - rin.b; hi = rin.a + rin.b; mg = rin.c; }
-      else if (rin.op == SOLO_R_SMALL_CONTROL) { x = sum / T(SOLO_NUM_JOINTS); mg = rin.a; }  // mean over all 12 joints (rewards.py:297-300)
-      T val = tolerance<T>(x, lo, hi, mg, rin.d);
-      const T fu = T(-1.5707963267948966);
-      if (rin.op == SOLO_R_UPRIGHT) val = fu * pitch / (fu * fu);
-      if (rin.op == SOLO_R_CONST) val = rin.a;
-      for (int i = 0; i < n_rops; ++i) {
-        const int op = wave_readlane_int(rin.op, i);
-        if (op >= SOLO_R_SCALE) {
-          const int src = wave_readlane_int(rin.src, i);
-          const T x0 = wave_readlane(val, src & 255);
-          T res;
-          if (op == SOLO_R_SCALE) res = wave_readlane(rin.a, i) * x0;
-          else {
-            const T x1 = wave_readlane(val, (src >> 8) & 255);
-            res = (op == SOLO_R_ADD) ? (x0 + x1) : (x0 * x1);
-          }
-          val = (lane == i) ? res : val;
-        }
-      }
-      reward = wave_readlane(val, n_rops - 1);
-      if (lane == 0) B.reward[(size_t)step * B.reward_stride + env] = reward;
-    }
-
-    SOLO_STAMP(B, 12);
     // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83)
+    bool done = false;
     if (B.flags & SOLO_STEP_DONE) {
-      bool done = false;
 #pragma unroll
       for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
         if (t < n_terms && !done) {
@@ -791,27 +683,26 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
           }
         }
       }
-      if (B.flags & SOLO_STEP_REWARD) {
-        // episodic-return bookkeeping kept in the env record (same 128-B line as the state)
-        if (lane == 0) { s_state[SOLO_S_RETURN] += reward; s_state[SOLO_S_EPLEN] += T(1); }
-        wave_sync();
-      }
-      const bool restart = (done || diverged) && auto_reset != 0;
+    }
+    const bool restart = (B.flags & SOLO_STEP_DONE) && (done || diverged) && auto_reset != 0;
+    // ---- the step's record for the output kernels (solo_outputs.h): the state after the step,
+    //      before an auto-reset (one coalesced 32-real store), and the step's event bits
+    if (B.traj != nullptr) {
+      if (lane < SOLO_STATE_STRIDE)
+        B.traj[((size_t)step * B.num_envs + env) * SOLO_STATE_STRIDE + lane] = lane < SOLO_S_RETURN ? s_state[lane] : T(0);
+      if (lane == 0) B.events[(size_t)step * B.num_envs + env] = (uint8_t)((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
+    }
+    SOLO_STAMP(B, 11);
+    if (B.flags & SOLO_STEP_DONE) {
       if (restart) {
-        if (lane == 0 && done) {
-          const double ret = (double)s_state[SOLO_S_RETURN];
-          stats_add(&stats[0], ret);
-          stats_add(&stats[1], ret * ret);
-          stats_add(&stats[2], 1.0);
-          stats_add(&stats[3], (double)s_state[SOLO_S_EPLEN]);
-        }
-        wave_sync();
-        if (lane < SOLO_STATE_STRIDE) s_state[lane] = B.snapshot[rec + lane];
+        wave_sync();  // the record above is read from the old state first
+        if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
 #pragma unroll
         for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = 0;
       }
       if (lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
     }
+    SOLO_STAMP(B, 12);
     wave_sync();  // this step's LDS state is complete before the next step reads it
   }
   SOLO_STAMP(B, 13);
@@ -820,12 +711,63 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
 #pragma unroll
     for (int t = 0; t < SOLO_MAX_TERMS; ++t) B.term_count[(size_t)env * SOLO_MAX_TERMS + t] = cnt[t];
   }
-  if (lane1 < SOLO_STATE_STRIDE) B.state[rec + lane1] = s_state[lane1];
+  // (slots SOLO_S_RETURN.. of the record are the returns kernel's: never written from here)
+  if (lane1 < SOLO_S_RETURN) B.state[rec + lane1] = s_state[lane1];
   SOLO_STAMP(B, 14);
 #ifdef SOLO_STAMPS
   wave_sync();
   if (lane1 < 16) B.stamps[(size_t)env * 32 + 16 + lane1] = s_acc[lane1];
 #endif
+}
+
+// ---- output kernels: one THREAD per (step, robot) of a launch (see solo_outputs.h) -------------
+constexpr int kOutputThreads = 256;
+
+// observations (steps >= obs_from_step only) and rewards of `steps` x `count` robot-steps.
+// traj [steps][num_envs][32]; obs / reward: element (k, env) at k * stride + env (* num_obs).
+// A single-step launch (the closed-loop step()) also does the episodic bookkeeping here
+// (returns_state != null) instead of paying a third launch.
+template <typename T>
+__global__ __launch_bounds__(kOutputThreads) void solo_outputs_kernel(const KParams<T>* __restrict__ P, const T* __restrict__ traj,
+                                                                      int steps, int num_envs, int env_base, int count,
+                                                                      T* __restrict__ obs, long long obs_stride, int obs_from_step,
+                                                                      T* __restrict__ reward, long long reward_stride,
+                                                                      T* __restrict__ returns_state, const uint8_t* __restrict__ events,
+                                                                      double* __restrict__ stats) {
+  __shared__ T s_val[SOLO_MAX_REWARD_OPS][kOutputThreads];  // reward program values, one column per thread
+  const int tid = threadIdx.x;
+  const long long item = (long long)blockIdx.x * kOutputThreads + tid;
+  if (item >= (long long)steps * count) return;
+  const int k = (int)(item / count), env = env_base + (int)(item % count);
+  const T* rec = traj + ((size_t)k * num_envs + env) * SOLO_STATE_STRIDE;
+  T roll, pitch, yaw;
+  euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
+  if (obs != nullptr && k >= obs_from_step)
+    eval_observations<T>(P, rec, roll, pitch, yaw, obs + (size_t)k * obs_stride + (size_t)env * P->num_obs);
+  if (reward != nullptr) {
+    T* out = reward + (size_t)k * reward_stride + env;
+    *out = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kOutputThreads);
+    if (returns_state != nullptr)  // steps == 1
+      accumulate_returns<T>(returns_state + (size_t)env * SOLO_STATE_STRIDE, events + env, 0, out, 0, 1,
+                            stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH, [](double* p, double x) { stats_add(p, x); });
+  }
+}
+
+// episodic return / length accumulators and episode statistics of a multi-step launch: one thread
+// per robot, a scan over the launch's steps (rewards.py has no counterpart: bookkeeping an RL loop
+// does in Python).  Consecutive threads = consecutive robots: every load is coalesced.
+template <typename T>
+__global__ __launch_bounds__(kOutputThreads) void solo_returns_kernel(T* __restrict__ state, const uint8_t* __restrict__ events, int steps,
+                                                                      int num_envs, int env_base, int count,
+                                                                      const T* __restrict__ reward, long long reward_stride,
+                                                                      double* __restrict__ stats) {
+  const int e = blockIdx.x * kOutputThreads + threadIdx.x;
+  if (e >= count) return;
+  const int env = env_base + e;
+  // sharded: all robots of a batch finish their episodes in the same step, and same-address
+  // atomics serialise
+  accumulate_returns<T>(state + (size_t)env * SOLO_STATE_STRIDE, events + env, num_envs, reward + env, reward_stride, steps,
+                        stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH, [](double* p, double x) { stats_add(p, x); });
 }
 
 // setJointMotorControlArray without a step (solo8v2vanilla.py:87-90)

@@ -37,22 +37,44 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   if (actions) act = conv(actions, (size_t)steps * n * SOLO_NUM_JOINTS);
   std::vector<T> par = conv(params, (size_t)n * 4);
   std::vector<T> ob((size_t)steps * n * (D > 0 ? D : 1)), rew((size_t)steps * n);
+  std::vector<T> traj((size_t)steps * n * SOLO_STATE_STRIDE);
+  std::vector<uint8_t> events((size_t)steps * n);
   std::vector<T> terr;
   if (terrain) {
     terr = conv(terrain->heights, (size_t)terrain->nx * terrain->ny);
     P.terr_nx = terrain->nx; P.terr_ny = terrain->ny; P.terr_inv_cell = (T)(1.0 / terrain->cell);
     P.terr_ox = (T)terrain->origin[0]; P.terr_oy = (T)terrain->origin[1];
   }
+  const bool want_obs = (flags & SOLO_STEP_OBS) != 0, want_reward = (flags & SOLO_STEP_REWARD) != 0;
   KBuffers<T> B;
   B.terrain = terrain ? terr.data() : nullptr;
   B.state = st.data(); B.snapshot = snap.data(); B.targets = tg.data();
-  B.actions = actions ? act.data() : nullptr; B.params = par.data(); B.obs = ob.data();
-  B.reward = rew.data(); B.done = done; B.term_count = term_count; B.stats = stats;
+  B.actions = actions ? act.data() : nullptr; B.params = par.data();
+  B.traj = (want_obs || want_reward) ? traj.data() : nullptr;
+  B.events = events.data();
+  B.done = done; B.term_count = term_count; B.stats = stats;
   B.num_envs = n; B.flags = flags; B.env_base = 0; B.steps = steps;
-  B.action_stride = (long long)n * SOLO_NUM_JOINTS; B.obs_stride = (long long)n * D; B.reward_stride = n; B.done_stride = n;
+  B.action_stride = (long long)n * SOLO_NUM_JOINTS; B.done_stride = n;
   const KParams<T>* Pp = &P;
+  // the step kernel: one emulated wavefront per robot (as Engine::launch_chain launches it) ...
   for (int b = 0; b < n; ++b)
     WaveEmu::get().run_block(b, n, [&]() { solo_step_kernel<T, true>(Pp, B); });
+  // ... then the output "kernels": the same per-item functions, in plain loops
+  if (want_obs || want_reward) {
+    for (int k = 0; k < steps; ++k)
+      for (int e = 0; e < n; ++e) {
+        const T* rec = traj.data() + ((size_t)k * n + e) * SOLO_STATE_STRIDE;
+        T roll, pitch, yaw, val[SOLO_MAX_REWARD_OPS];
+        euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
+        if (want_obs) eval_observations<T>(Pp, rec, roll, pitch, yaw, ob.data() + ((size_t)k * n + e) * D);
+        if (want_reward) rew[(size_t)k * n + e] = eval_reward<T>(Pp, rec, roll, pitch, val, 1);
+      }
+    if (want_reward && (flags & SOLO_STEP_DONE))
+      for (int e = 0; e < n; ++e)
+        accumulate_returns<T>(st.data() + (size_t)e * SOLO_STATE_STRIDE, events.data() + e, n, rew.data() + e, n, steps,
+                              stats + (size_t)(e % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH,
+                              [](double* p, double x) { *p += x; });
+  }
   for (size_t i = 0; i < st.size(); ++i) state[i] = (double)st[i];
   for (size_t i = 0; i < tg.size(); ++i) targets[i] = (double)tg[i];
   if (flags & SOLO_STEP_OBS) for (size_t i = 0; i < (size_t)steps * n * D; ++i) obs[i] = (double)ob[i];
