@@ -127,7 +127,7 @@ struct Engine final : EngineBase {
   solo::KBuffers<T> buffers(const T* actions, uint32_t flags) const {
     solo::KBuffers<T> b;
     b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
-    b.params = params; b.traj = nullptr; b.events = events; b.done = done; b.term_count = term_count;
+    b.params = params; b.traj = nullptr; b.events = events; b.obs_inline = b.reward_inline = nullptr; b.done = done; b.term_count = term_count;
     b.stats = stats; b.terrain = terrain; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
     b.action_stride = b.done_stride = 0;
 #ifdef SOLO_STAMPS
@@ -225,8 +225,16 @@ struct Engine final : EngineBase {
       b.env_base = lo;
       b.steps = steps;
       b.action_stride = act_stride;
-      if (want_obs || want_reward) b.traj = traj;
       if (done_out) { b.done = done_out + (size_t)i * n; b.done_stride = n; }
+      // a single-step launch (closed-loop step(), or a rollout with steps_per_launch = 1) evaluates
+      // its outputs inside the step kernel; a fused launch leaves records for the output kernels
+      const bool inline_outputs = steps == 1 && (want_obs || want_reward);
+      if (inline_outputs) {
+        if (want_obs) b.obs_inline = obs_out ? obs_out + (size_t)i * n * obs_dim : obs;
+        if (want_reward) b.reward_inline = reward_out ? reward_out + (size_t)i * n : reward;
+      } else if (want_obs || want_reward) {
+        b.traj = traj;
+      }
       // stepSimulation-only calls (settle loop, client.stepSimulation()) run the physics-only
       // instantiation: no termination code, and a separate name in profiles
       if (flags == SOLO_STEP_PHYSICS)
@@ -234,7 +242,7 @@ struct Engine final : EngineBase {
       else
         hipLaunchKernelGGL((solo::solo_step_kernel<T, true>), dim3(count), dim3(64), 0, s, dparams, b);
       HIP_TRY(hipGetLastError());
-      if (skip_outputs || !(want_obs || want_reward)) continue;
+      if (skip_outputs || inline_outputs || !(want_obs || want_reward)) continue;
       // where this launch's outputs go: a recording rollout keeps every step ([K][N][.] buffers of
       // the caller), otherwise only the last step's observation / reward stay in the engine's view
       T* o = nullptr; long long o_stride = 0; int o_from = 0;
@@ -245,17 +253,14 @@ struct Engine final : EngineBase {
       T* r = nullptr; long long r_stride = 0;
       if (want_reward) {
         if (reward_out) { r = reward_out + (size_t)i * n; r_stride = n; }
-        else if (steps == 1) { r = reward; r_stride = 0; }
         else { r = reward_scratch; r_stride = n; }
       }
       const long long items = (long long)steps * count;
       const bool bookkeeping = want_reward && (flags & SOLO_STEP_DONE);
-      T* fused_returns = (bookkeeping && steps == 1) ? state : nullptr;  // single step: no third launch
       hipLaunchKernelGGL(solo::solo_outputs_kernel<T>, dim3((unsigned)((items + solo::kOutputThreads - 1) / solo::kOutputThreads)),
-                         dim3(solo::kOutputThreads), 0, s, dparams, traj, steps, n, lo, count, o, o_stride, o_from, r, r_stride,
-                         fused_returns, events, stats);
+                         dim3(solo::kOutputThreads), 0, s, dparams, traj, steps, n, lo, count, o, o_stride, o_from, r, r_stride);
       HIP_TRY(hipGetLastError());
-      if (bookkeeping && steps > 1) {
+      if (bookkeeping) {
         hipLaunchKernelGGL(solo::solo_returns_kernel<T>, dim3((count + solo::kOutputThreads - 1) / solo::kOutputThreads),
                            dim3(solo::kOutputThreads), 0, s, state, events, steps, n, lo, count, r, r_stride, stats);
         HIP_TRY(hipGetLastError());

@@ -93,6 +93,8 @@ struct KBuffers {
   const T* params;    // [N][4]
   T* traj;            // [steps][N][32] per-step records for the output kernels (solo_outputs.h), or null
   uint8_t* events;    // [steps][N] per-step event bits for the returns kernel (with traj)
+  T* obs_inline;      // single-step launches (the closed-loop step()): [N][D] / [N] outputs evaluated by the
+  T* reward_inline;   // robot's own wave instead of a second launch; null otherwise
   uint8_t* done;      // [N]
   int32_t* term_count;  // [N][4]
   double* stats;      // [SOLO_STATS_SHARDS][8]

@@ -70,62 +70,66 @@ __device__ __forceinline__ T source_value(const T* rec, int src, T roll, T pitch
   return T(1);
 }
 
-// observation program: per element source, scale, clip, normalise (obs.py:141-159)
+// one element of the observation program: source, scale, clip, normalise (obs.py:141-159)
+template <typename T>
+__device__ __forceinline__ T observation_value(const ObsElemK<T>& e, const T* rec, T roll, T pitch, T yaw) {
+  using R = Real<T>;
+  T v = source_value<T>(rec, e.src, roll, pitch, yaw) * e.scale;
+  if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
+  if (e.flags & 2) v = R::fma(v, e.nscale, e.noff);
+  return v;
+}
 template <typename T>
 __device__ __forceinline__ void eval_observations(const KParams<T>* P, const T* rec, T roll, T pitch, T yaw, T* out) {
-  using R = Real<T>;
   const int n = P->num_obs;
-  for (int i = 0; i < n; ++i) {
-    const ObsElemK<T>& e = P->obs[i];
-    T v = source_value<T>(rec, e.src, roll, pitch, yaw) * e.scale;
-    if (e.flags & 1) v = R::min(R::max(v, e.lo), e.hi);
-    if (e.flags & 2) v = R::fma(v, e.nscale, e.noff);
-    out[i] = v;
-  }
+  for (int i = 0; i < n; ++i) out[i] = observation_value<T>(P->obs[i], rec, roll, pitch, yaw);
 }
 
-// reward program in three-address form (pack_program): instruction i's value goes to
-// val[i * stride]; leaves read the state, SCALE / ADD / MUL read earlier values.  Returns the value
-// of the last instruction (rewards.py:104-118: the weighted sum is compiled into the program).
+// Reward program in three-address form (pack_program): instruction i's value goes to
+// val[i * stride]; LEAVES read the state, SCALE / ADD / MUL combine earlier values
+// (rewards.py:104-118: the weighted sum is compiled into the program).
+__device__ __forceinline__ bool reward_is_leaf(int op) { return op < SOLO_R_SCALE; }
+template <typename T>
+__device__ __forceinline__ T reward_leaf(const RewardInstrK<T>& r, const T* rec, T roll, T pitch) {
+  using R = Real<T>;
+  switch (r.op) {
+    case SOLO_R_UPRIGHT: {  // rewards.py:121-141: pitch relative to "fully upright" = -pi/2
+      const T fu = T(-1.5707963267948966);
+      return fu * pitch / (fu * fu);
+    }
+    case SOLO_R_FLAT_TORSO:  // rewards.py:256-269
+      return tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -r.a, r.a, r.b, r.d);
+    case SOLO_R_TORSO_HEIGHT:  // rewards.py:326-338
+      return tolerance<T>(rec[SOLO_S_POS + 2], r.a - r.b, r.a + r.b, r.c, r.d);
+    case SOLO_R_HORIZ_SPEED: {  // rewards.py:362-373
+      const T vx = rec[SOLO_S_LINVEL], vy = rec[SOLO_S_LINVEL + 1];
+      return tolerance<T>(R::sqrt(vx * vx + vy * vy), r.a - r.b, r.a + r.b, r.c, r.d);
+    }
+    case SOLO_R_SMALL_CONTROL: {  // rewards.py:290-301: mean |joint rate| over all 12 joints
+      T sum = T(0);
+      for (int j = 0; j < SOLO_NUM_DOF; ++j) sum += R::abs(rec[SOLO_S_QD + j]);
+      return tolerance<T>(sum / T(SOLO_NUM_JOINTS), T(0), T(0), r.a, r.d);
+    }
+    case SOLO_R_CONST: return r.a;
+    default: return T(0);
+  }
+}
+template <typename T>
+__device__ __forceinline__ T reward_combine(const RewardInstrK<T>& r, const T* val, int stride) {
+  const T x0 = val[(r.src & 255) * stride];
+  if (r.op == SOLO_R_SCALE) return r.a * x0;
+  const T x1 = val[((r.src >> 8) & 255) * stride];
+  return r.op == SOLO_R_ADD ? x0 + x1 : x0 * x1;
+}
+// the whole program for one item; returns the value of the last instruction
 template <typename T>
 __device__ __forceinline__ T eval_reward(const KParams<T>* P, const T* rec, T roll, T pitch, T* val, int stride) {
-  using R = Real<T>;
   const int n = P->num_reward_ops;
   T last = T(0);
   for (int i = 0; i < n; ++i) {
     const RewardInstrK<T>& r = P->reward[i];
-    T v;
-    switch (r.op) {
-      case SOLO_R_UPRIGHT: {  // rewards.py:121-141: pitch relative to "fully upright" = -pi/2
-        const T fu = T(-1.5707963267948966);
-        v = fu * pitch / (fu * fu);
-        break;
-      }
-      case SOLO_R_FLAT_TORSO:  // rewards.py:256-269
-        v = tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -r.a, r.a, r.b, r.d);
-        break;
-      case SOLO_R_TORSO_HEIGHT:  // rewards.py:326-338
-        v = tolerance<T>(rec[SOLO_S_POS + 2], r.a - r.b, r.a + r.b, r.c, r.d);
-        break;
-      case SOLO_R_HORIZ_SPEED: {  // rewards.py:362-373
-        const T vx = rec[SOLO_S_LINVEL], vy = rec[SOLO_S_LINVEL + 1];
-        v = tolerance<T>(R::sqrt(vx * vx + vy * vy), r.a - r.b, r.a + r.b, r.c, r.d);
-        break;
-      }
-      case SOLO_R_SMALL_CONTROL: {  // rewards.py:290-301: mean |joint rate| over all 12 joints
-        T sum = T(0);
-        for (int j = 0; j < SOLO_NUM_DOF; ++j) sum += R::abs(rec[SOLO_S_QD + j]);
-        v = tolerance<T>(sum / T(SOLO_NUM_JOINTS), T(0), T(0), r.a, r.d);
-        break;
-      }
-      case SOLO_R_CONST: v = r.a; break;
-      case SOLO_R_SCALE: v = r.a * val[(r.src & 255) * stride]; break;
-      case SOLO_R_ADD: v = val[(r.src & 255) * stride] + val[((r.src >> 8) & 255) * stride]; break;
-      case SOLO_R_MUL: v = val[(r.src & 255) * stride] * val[((r.src >> 8) & 255) * stride]; break;
-      default: v = T(0); break;
-    }
-    val[i * stride] = v;
-    last = v;
+    last = reward_is_leaf(r.op) ? reward_leaf<T>(r, rec, roll, pitch) : reward_combine<T>(r, val, stride);
+    val[i * stride] = last;
   }
   return last;
 }

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_hext[64][8];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][20];
+  __shared__ T s_val[SOLO_MAX_REWARD_OPS];  // reward program values of an inline evaluation (single-step launches)
   // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
   // read them from LDS instead of paying a global-load latency each
   __shared__ LegConst<T> s_legc[4];
@@ -692,6 +693,36 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
         B.traj[((size_t)step * B.num_envs + env) * SOLO_STATE_STRIDE + lane] = lane < SOLO_S_RETURN ? s_state[lane] : T(0);
       if (lane == 0) B.events[(size_t)step * B.num_envs + env] = (uint8_t)((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
     }
+    // closed-loop step() = a single-step launch: its outputs are evaluated right here with the
+    // same per-item functions the output kernels use (no second launch on the critical path of a
+    // policy loop) - lane i takes observation element i / reward leaf i, lane 0 folds the reward
+    if (B.obs_inline != nullptr || B.reward_inline != nullptr) {
+      T roll, pitch, yaw;
+      euler_from_quat<T>(s_state[SOLO_S_QUAT], s_state[SOLO_S_QUAT + 1], s_state[SOLO_S_QUAT + 2], s_state[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
+      const int n_obs = wave_uniform(P0->num_obs), n_rops = wave_uniform(P0->num_reward_ops);
+      if (B.obs_inline != nullptr && lane < n_obs)
+        B.obs_inline[(size_t)env * n_obs + lane] = observation_value<T>(P0->obs[lane], s_state, roll, pitch, yaw);
+      if (B.reward_inline != nullptr) {
+        if (lane < n_rops) {
+          const RewardInstrK<T> r = P0->reward[lane];
+          if (reward_is_leaf(r.op)) s_val[lane] = reward_leaf<T>(r, s_state, roll, pitch);
+        }
+        wave_sync();
+        if (lane == 0) {
+          T r = T(0);
+          for (int i = 0; i < n_rops; ++i) {
+            const RewardInstrK<T>& ri = P0->reward[i];
+            if (!reward_is_leaf(ri.op)) s_val[i] = reward_combine<T>(ri, s_val, 1);
+            r = s_val[i];
+          }
+          B.reward_inline[env] = r;
+          if (B.flags & SOLO_STEP_DONE) {
+            const uint8_t ev = (uint8_t)((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
+            accumulate_returns<T>(B.state + rec, &ev, 0, &r, 0, 1, stats, [](double* p, double x) { stats_add(p, x); });
+          }
+        }
+      }
+    }
     SOLO_STAMP(B, 11);
     if (B.flags & SOLO_STEP_DONE) {
       if (restart) {
@@ -725,15 +756,11 @@ constexpr int kOutputThreads = 256;
 
 // observations (steps >= obs_from_step only) and rewards of `steps` x `count` robot-steps.
 // traj [steps][num_envs][32]; obs / reward: element (k, env) at k * stride + env (* num_obs).
-// A single-step launch (the closed-loop step()) also does the episodic bookkeeping here
-// (returns_state != null) instead of paying a third launch.
 template <typename T>
 __global__ __launch_bounds__(kOutputThreads) void solo_outputs_kernel(const KParams<T>* __restrict__ P, const T* __restrict__ traj,
                                                                       int steps, int num_envs, int env_base, int count,
                                                                       T* __restrict__ obs, long long obs_stride, int obs_from_step,
-                                                                      T* __restrict__ reward, long long reward_stride,
-                                                                      T* __restrict__ returns_state, const uint8_t* __restrict__ events,
-                                                                      double* __restrict__ stats) {
+                                                                      T* __restrict__ reward, long long reward_stride) {
   __shared__ T s_val[SOLO_MAX_REWARD_OPS][kOutputThreads];  // reward program values, one column per thread
   const int tid = threadIdx.x;
   const long long item = (long long)blockIdx.x * kOutputThreads + tid;
@@ -744,13 +771,8 @@ __global__ __launch_bounds__(kOutputThreads) void solo_outputs_kernel(const KPar
   euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
   if (obs != nullptr && k >= obs_from_step)
     eval_observations<T>(P, rec, roll, pitch, yaw, obs + (size_t)k * obs_stride + (size_t)env * P->num_obs);
-  if (reward != nullptr) {
-    T* out = reward + (size_t)k * reward_stride + env;
-    *out = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kOutputThreads);
-    if (returns_state != nullptr)  // steps == 1
-      accumulate_returns<T>(returns_state + (size_t)env * SOLO_STATE_STRIDE, events + env, 0, out, 0, 1,
-                            stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH, [](double* p, double x) { stats_add(p, x); });
-  }
+  if (reward != nullptr)
+    reward[(size_t)k * reward_stride + env] = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kOutputThreads);
 }
 
 // episodic return / length accumulators and episode statistics of a multi-step launch: one thread

@@ -50,8 +50,12 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   B.terrain = terrain ? terr.data() : nullptr;
   B.state = st.data(); B.snapshot = snap.data(); B.targets = tg.data();
   B.actions = actions ? act.data() : nullptr; B.params = par.data();
-  B.traj = (want_obs || want_reward) ? traj.data() : nullptr;
+  // as Engine::launch_chain: a single-step launch evaluates its outputs inside the step kernel
+  const bool inline_outputs = steps == 1 && (want_obs || want_reward);
+  B.traj = (!inline_outputs && (want_obs || want_reward)) ? traj.data() : nullptr;
   B.events = events.data();
+  B.obs_inline = (inline_outputs && want_obs) ? ob.data() : nullptr;
+  B.reward_inline = (inline_outputs && want_reward) ? rew.data() : nullptr;
   B.done = done; B.term_count = term_count; B.stats = stats;
   B.num_envs = n; B.flags = flags; B.env_base = 0; B.steps = steps;
   B.action_stride = (long long)n * SOLO_NUM_JOINTS; B.done_stride = n;
@@ -60,7 +64,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   for (int b = 0; b < n; ++b)
     WaveEmu::get().run_block(b, n, [&]() { solo_step_kernel<T, true>(Pp, B); });
   // ... then the output "kernels": the same per-item functions, in plain loops
-  if (want_obs || want_reward) {
+  if (!inline_outputs && (want_obs || want_reward)) {
     for (int k = 0; k < steps; ++k)
       for (int e = 0; e < n; ++e) {
         const T* rec = traj.data() + ((size_t)k * n + e) * SOLO_STATE_STRIDE;
