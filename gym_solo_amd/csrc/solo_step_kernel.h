@@ -22,8 +22,11 @@
 //    subtract, compare: the compare's lane mask is the set) and only those are visited, in solver
 //    order, each one rebuilding its Delassus column from the whitened row vectors in LDS (see
 //    physics_solve).  All branching is wave-uniform: the whole wave belongs to one robot.
-//  * obs / reward / done are evaluated from the new state by the same wave (lane k = obs
-//    element k -> one coalesced store), reward as a small postfix program.
+//  * Termination (TimeBased counters) and the auto-reset stay in the robot's wave; observations,
+//    rewards and episodic returns do NOT: a fused launch leaves one 128-B record per robot-step
+//    and the output kernels at the end of this file evaluate them with one THREAD per robot-step
+//    (solo_outputs.h).  Only a single-step launch - the closed-loop step() - evaluates its outputs
+//    in place, with the same per-item functions.
 // No MFMA: there is no dense contraction here (14 dofs, <= 56 rows per robot).
 //
 // The including translation unit must provide solo::lane_id/block_id/wave_sync/wave_readlane/
