@@ -30,9 +30,11 @@ out = {'float32': {
          'over the last 10 full launches, KB*1024.  MI355X_MICROARCH.md: FETCH_SIZE under-reports wide 16-B/lane '
          'streams by 2x; this kernel loads one dword per lane (uncalibrated width), so the raw value is reported; '
          'with the 2x correction the total would be %.1f MB.' % ((2 * fetch + write) / 1e6),
-  'reading': 'below the algorithmic %d B/env-step because the fused launch keeps the 128-B state record in LDS for '
-             '100 steps (no per-step state read+write): ~%.0f B/env-step read (actions 48 + parameters/snapshot), '
-             '~%.0f B/env-step written (obs 84 B rows are not line-aligned).' % (BYTES_PER_ENV_STEP, fetch / n, write / n)}}
+  'reading': 'the STEP KERNEL alone (the filter of tools/pmc_summary.py), below the algorithmic %d B/env-step of the whole '
+             'path: the fused launch keeps the 128-B state record in LDS for all its steps (no per-step state read), '
+             '~%.0f B/env-step read (actions 48 + parameters/snapshot), ~%.0f B/env-step written (the 128-B step record '
+             'the output kernels read + done + event byte); the observations (84 B) and rewards (4 B) are written by '
+             'solo_outputs_kernel from those records.' % (BYTES_PER_ENV_STEP, fetch / n, write / n)}}
 path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 json.dump(out, open(path, 'w'), indent=1)
 print(json.dumps(out, indent=1))
