@@ -47,7 +47,7 @@ class Solo8BaseConfig:
   device: int = 0
   dtype: str = 'float32'          # arithmetic type of the engine: 'float32' | 'float64'
   solver_iterations: int = 50     # Bullet default [recalled]
-  solver_ulp_tolerance: int = 2   # impulse changes of <= this many ulps count as converged (0 = bit-exact)
+  solver_ulp_tolerance: int = 2   # impulse changes of <= this many half-ulps (relative) count as converged (0 = exact)
   motor_kp: float = 0.1           # pybullet POSITION_CONTROL default positionGain [recalled]
   motor_kd: float = 1.0           # pybullet POSITION_CONTROL default velocityGain [recalled]
   contact_erp: float = 0.2

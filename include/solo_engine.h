@@ -122,12 +122,13 @@ typedef struct SoloConfig {
                                 into one kernel launch (state stays in LDS); 0 or 1 = one step */
   int32_t rollout_streams;   /* rollouts cut the batch into this many slices that advance as
                                 independent launch chains on internal HIP streams (0/1 = off) */
-  int32_t solver_ulp_tolerance; /* a Gauss-Seidel row whose new impulse lies within this many units in the
-                                last place of its old one is left untouched, and a sweep that changes no
-                                row ends the iteration early.  0 = only the bit-exact fixed point ends it
-                                (then identical to always running solver_iterations sweeps); 2 (the host
-                                default) also stops last-bit limit cycles, which otherwise keep ~3% of the
-                                robots iterating to the cap.  Negative values are rejected. */
+  int32_t solver_ulp_tolerance; /* k: a Gauss-Seidel row whose clamped candidate differs from its impulse by
+                                at most k half-ulps relative to the impulse (|d| <= k * 2^-24 |lam| in f32,
+                                k * 2^-53 |lam| in f64) is left untouched, and a sweep that changes no row
+                                ends the iteration early.  0 = only an exact fixed point ends it (then
+                                identical to always running solver_iterations sweeps); 2 (the host default)
+                                also stops last-bit limit cycles, which otherwise keep ~3% of the robots
+                                iterating to the cap.  Negative values are rejected. */
 } SoloConfig;
 
 /* ---- fused observation / reward / termination programs ------------------ */
