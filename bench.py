@@ -126,8 +126,8 @@ def secondary_bound(dtype, env_steps_per_launch, chains, kern_ms, clock_hz):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=1000)
-  ap.add_argument('--warmup', type=int, default=100)
+  ap.add_argument('--steps', type=int, default=3000)
+  ap.add_argument('--warmup', type=int, default=250)
   ap.add_argument('--envs-per-gpu', type=int, default=4096)
   ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -198,7 +198,7 @@ def main():
 
   # dominant kernel: HIP events on the stream its launches are issued on, same rollout path and
   # workload (fresh actions every step); one launch = (n / streams) robots x spl steps
-  reps = max(1, min(k, 300) // spl)
+  reps = max(1, min(k, 1000) // spl)
   kern_ms = eng.time_step(acts[:reps * spl], abi.STEP_ALL)
   api_rate = None
   if args.api_rate:  # API-level rate through Solo8VanillaEnv.step (python loop, zero-copy outputs)

@@ -122,6 +122,14 @@ template <> struct RowDot<float> {
   }
 };
 
+// issue priority of this wave in its SIMD (0..3) by thresholds on a wave-uniform measure
+__device__ __forceinline__ void wave_set_priority(int m, int t1, int t2, int t3) {
+  if (m > t3) __builtin_amdgcn_s_setprio(3);
+  else if (m > t2) __builtin_amdgcn_s_setprio(2);
+  else if (m > t1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
 template <typename T> struct Real;
 // f32: hardware v_sqrt / v_rsq / v_rcp (<= 1 ulp each) instead of the IEEE-correct library
 // sequences (~10-25 instructions apiece), and a Cody-Waite + minimax sincos (~25 instructions,
