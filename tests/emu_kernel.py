@@ -16,7 +16,7 @@ def load(variant=''):
   path = os.path.join(_DIR, name)
   deps = [os.path.join(_DIR, f) for f in ('emu_harness.cpp', 'wave_emu.h')] + [
     os.path.join(_DIR, '..', '..', 'gym_solo_amd', 'csrc', f)
-    for f in ('solo_step_kernel.h', 'solo_kernel_params.h')]
+    for f in ('solo_step_kernel.h', 'solo_kernel_params.h', 'solo_outputs.h')]
   if not os.path.exists(path) or any(os.path.getmtime(d) > os.path.getmtime(path) for d in deps):
     subprocess.check_call(['make', '-s', '-C', _DIR, variant or 'all'])
   lib = C.CDLL(path)
