@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   }
 
   // B.steps consecutive env steps of THIS robot in one launch: the state record stays in LDS,
-  // only actions come in and obs / reward / done go out per step.  Robots are independent, so
+  // only actions come in and the step records / done flags go out per step.  Robots are independent, so
   // no wave ever waits for another one; a launch lasts as long as its slowest robot's SUM over
   // the steps, which averages out the contact-count imbalance between robots.
 #pragma unroll 1
