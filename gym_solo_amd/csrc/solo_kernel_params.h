@@ -31,8 +31,8 @@ template <typename T>
 struct LegConst {
   T hip[3];     // HFE joint origin in base frame
   T knee[3];    // KFE joint origin in upper-leg frame
-  T mU, cU[3], IU[6];  // upper leg: mass, com (link frame), inertia about com (xx yy zz xy xz yz)
-  T mL, cL[3], IL[6];  // lower leg + welded foot
+  T link[2][10];  // [0] upper leg, [1] lower leg + welded foot: mass, com[3] (link frame),
+                  // inertia about com [6] (xx yy zz xy xz yz)
 };
 
 template <typename T>
@@ -162,12 +162,12 @@ inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) 
     for (int a = 0; a < 3; ++a) {
       L.hip[a] = (T)m.joint_origin[ju][a];
       L.knee[a] = (T)m.joint_origin[jl][a];
-      L.cU[a] = (T)m.com[bu][a];
-      L.cL[a] = (T)m.com[bl][a];
+      L.link[0][1 + a] = (T)m.com[bu][a];
+      L.link[1][1 + a] = (T)m.com[bl][a];
     }
-    L.mU = (T)m.mass[bu];
-    L.mL = (T)m.mass[bl];
-    for (int a = 0; a < 6; ++a) { L.IU[a] = (T)m.inertia[bu][a]; L.IL[a] = (T)m.inertia[bl][a]; }
+    L.link[0][0] = (T)m.mass[bu];
+    L.link[1][0] = (T)m.mass[bl];
+    for (int a = 0; a < 6; ++a) { L.link[0][4 + a] = (T)m.inertia[bu][a]; L.link[1][4 + a] = (T)m.inertia[bl][a]; }
   }
   for (int lane = 0; lane < 64; ++lane) k->row[lane].type = ROW_IDLE;
   for (int d = 0; d < SOLO_NUM_DOF; ++d) {

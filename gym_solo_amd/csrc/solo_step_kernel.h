@@ -89,6 +89,12 @@ template <typename T> __device__ __forceinline__ void rot_inertia_y(T c, T s, co
   o[5] = c * I[5] - s * I[3];
 }
 template <typename T> __device__ __forceinline__ T sum_over_group16(T x) { return wave_sum_group16(x); }
+template <typename T> __device__ __forceinline__ V3<T> select(bool p, V3<T> a, V3<T> b) { return {p ? a.x : b.x, p ? a.y : b.y, p ? a.z : b.z}; }
+// the two halves (k < 8 / k >= 8) of a 16-lane row: sum of both, or the lower half's value in both
+template <typename T> __device__ __forceinline__ T both_halves(T x) { return x + wave_other_half16(x); }
+template <typename T> __device__ __forceinline__ V3<T> both_halves(V3<T> v) { return {both_halves(v.x), both_halves(v.y), both_halves(v.z)}; }
+template <typename T> __device__ __forceinline__ T from_lower(bool lower, T x) { const T o = wave_other_half16(x); return lower ? x : o; }
+template <typename T> __device__ __forceinline__ V3<T> from_lower(bool lower, V3<T> v) { return {from_lower(lower, v.x), from_lower(lower, v.y), from_lower(lower, v.z)}; }
 
 
 // ------------------------------------------------------------------------------------------
@@ -117,7 +123,12 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   const V3<T> gb = {r00 * gw.x + r10 * gw.y + r20 * gw.z, r01 * gw.x + r11 * gw.y + r21 * gw.z, r02 * gw.x + r12 * gw.y + r22 * gw.z};
   const V3<T> nb = {r20, r21, r22};  // world z (ground normal) in base coordinates
 
-  // ---- leg-local kinematics (each 16-lane group works on its own leg) -----------------------
+  // ---- leg-local kinematics.  Each 16-lane row works on its own leg, and the two HALVES of the
+  //      row on the leg's two links: lanes k < 8 carry the upper link, k >= 8 the lower link
+  //      (+ welded foot) through the same instructions; per-leg quantities are the sum of the two
+  //      halves (x + the other half's x, one DPP add: identical bits in both halves).
+  const bool lower = (k & 8) != 0;
+  const T bm = lower ? T(1) : T(0);
   const T q1 = s_state[SOLO_S_Q + 2 * leg], q2 = s_state[SOLO_S_Q + 2 * leg + 1];
   const T qd1 = s_state[SOLO_S_QD + 2 * leg], qd2 = s_state[SOLO_S_QD + 2 * leg + 1];
   T s1, c1, s12, c12;
@@ -125,25 +136,27 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   R::sincos(q1 + q2, &s12, &c12);
   const V3<T> o1 = {L.hip[0], L.hip[1], L.hip[2]};
   const V3<T> o2 = o1 + roty(c1, s1, V3<T>{L.knee[0], L.knee[1], L.knee[2]});
-  const V3<T> cU = o1 + roty(c1, s1, V3<T>{L.cU[0], L.cU[1], L.cU[2]});
-  const V3<T> cL = o2 + roty(c12, s12, V3<T>{L.cL[0], L.cL[1], L.cL[2]});
-  T IU[6], IL[6];
-  rot_inertia_y(c1, s1, L.IU, IU);
-  rot_inertia_y(c12, s12, L.IL, IL);
-  const T mU = L.mU, mL = L.mL;
+  const T cosb = lower ? c12 : c1, sinb = lower ? s12 : s1;  // this half's link orientation
+  const V3<T> ob = select(lower, o2, o1);                // ... and joint origin
+  const T* body = L.link[lower ? 1 : 0];                 // m, com[3], inertia[6] of this half's link
+  const T mB = body[0];
+  const V3<T> c = ob + roty(cosb, sinb, V3<T>{body[1], body[2], body[3]});
+  T I[6];
+  rot_inertia_y(cosb, sinb, body + 4, I);
 
   SOLO_STAMP(B, 2);
   // ---- joint-space inertia blocks of the leg (composite-rigid-body, closed form) -----------
-  const V3<T> rU1 = cU - o1, rL1 = cL - o1, rL2 = cL - o2;
-  const V3<T> tU1 = ycross(rU1), tL1 = ycross(rL1), tL2 = ycross(rL2);
-  const V3<T> IUy = {IU[3], IU[1], IU[5]}, ILy = {IL[3], IL[1], IL[5]};  // I * y_hat
+  const V3<T> r1 = c - o1, r2 = c - o2;  // r2 (and everything about joint 2) is meaningful on the lower half
+  const V3<T> t1 = ycross(r1), t2 = ycross(r2);
+  const V3<T> Iy = {I[3], I[1], I[5]};  // I * y_hat
   // column of M for dof 1 / dof 2: [n; f] = [angular momentum about the base origin; linear]
-  const V3<T> f1 = mU * tU1 + mL * tL1, f2 = mL * tL2;
-  const V3<T> n1 = IUy + ILy + mU * cross(cU, tU1) + mL * cross(cL, tL1);
-  const V3<T> n2 = ILy + mL * cross(cL, tL2);
-  const T P11 = mU * dot(tU1, tU1) + mL * dot(tL1, tL1) + IU[1] + IL[1];
-  const T P12 = mL * dot(tL1, tL2) + IL[1];
-  const T P22 = mL * dot(tL2, tL2) + IL[1];
+  const V3<T> f1 = both_halves(mB * t1);
+  const V3<T> n1 = both_halves(Iy + mB * cross(c, t1));
+  const T P11 = both_halves(mB * dot(t1, t1) + I[1]);
+  const V3<T> f2 = from_lower(lower, mB * t2);
+  const V3<T> n2 = from_lower(lower, Iy + mB * cross(c, t2));
+  const T P12 = from_lower(lower, mB * dot(t1, t2) + I[1]);
+  const T P22 = from_lower(lower, mB * dot(t2, t2) + I[1]);
   // Cholesky of the 2x2 leg block, W = Lp^-1 [F1;F2], K = P^-1 M_lb = Lp^-T W
   const T iL11 = R::rsqrt(P11);
   const T L21 = P12 * iL11;
@@ -161,31 +174,29 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   SOLO_STAMP(B, 3);
   // ---- bias forces of the leg: Newton-Euler with classical accelerations in the frame that
   //      coincides with the base at this instant (gravity + Bullet-style damping included) ----
-  const V3<T> yh = {T(0), T(1), T(0)};
-  const V3<T> wU = {om.x, om.y + qd1, om.z}, wL = {om.x, om.y + qd1 + qd2, om.z};
-  const V3<T> aU = {-qd1 * om.z, T(0), qd1 * om.x};                       // om x (qd1 y)
-  const V3<T> aL = {aU.x - qd2 * wU.z, T(0), aU.z + qd2 * wU.x};          // + wU x (qd2 y)
+  const V3<T> wU = {om.x, om.y + qd1, om.z};
+  const V3<T> wB = {om.x, wU.y + bm * qd2, om.z};                               // this half's link
+  const V3<T> aU = {-qd1 * om.z, T(0), qd1 * om.x};                             // om x (qd1 y)
+  const V3<T> a = {aU.x - (bm * qd2) * wU.z, T(0), aU.z + (bm * qd2) * wU.x};   // (+ wU x (qd2 y))
   // centripetal terms as w x (w x r) = w (w.r) - |w|^2 r
-  const T om2 = dot(om, om), wU2 = dot(wU, wU), wL2 = dot(wL, wL);
+  const T om2 = dot(om, om), wU2 = dot(wU, wU), wB2 = dot(wB, wB);
   const V3<T> a_o1 = dot(om, o1) * om - om2 * o1;
   const V3<T> d12 = o2 - o1;
-  const V3<T> a_cU = a_o1 + cross(aU, rU1) + (dot(wU, rU1) * wU - wU2 * rU1);
   const V3<T> a_o2 = a_o1 + cross(aU, d12) + (dot(wU, d12) * wU - wU2 * d12);
-  const V3<T> a_cL = a_o2 + cross(aL, rL2) + (dot(wL, rL2) * wL - wL2 * rL2);
-  const V3<T> v_cU = vb + cross(om, cU) + qd1 * tU1;
-  const V3<T> v_cL = vb + cross(om, cL) + qd1 * tL1 + qd2 * tL2;
+  const V3<T> r = c - ob;
+  const V3<T> a_c = select(lower, a_o2, a_o1) + cross(a, r) + (dot(wB, r) * wB - wB2 * r);
+  const V3<T> v_c = vb + cross(om, c) + qd1 * t1 + (bm * qd2) * t2;
   const T kl = P->lin_damp, ka = P->ang_damp;
-  const T dU = kl * (T(1) + R::sqrt(dot(v_cU, v_cU))), dL = kl * (T(1) + R::sqrt(dot(v_cL, v_cL)));
-  const T eU = ka * (T(1) + R::sqrt(wU2)), eL = ka * (T(1) + R::sqrt(wL2));
-  const V3<T> FU = mU * (a_cU - gb + dU * v_cU);
-  const V3<T> FL = mL * (a_cL - gb + dL * v_cL);
-  const V3<T> IwU = symmul(IU, wU), IwL = symmul(IL, wL);
-  const V3<T> NU = symmul(IU, aU) + cross(wU, IwU) + eU * IwU;
-  const V3<T> NL = symmul(IL, aL) + cross(wL, IwL) + eL * IwL;
-  const T h2 = dot(yh, NL + cross(rL2, FL));
-  const T h1 = dot(yh, NU + cross(rU1, FU) + NL + cross(rL1, FL));
-  const V3<T> Fleg = FU + FL;
-  const V3<T> Nleg = NU + cross(cU, FU) + NL + cross(cL, FL);
+  const T dB = kl * (T(1) + R::sqrt(dot(v_c, v_c)));
+  const T eB = ka * (T(1) + R::sqrt(wB2));
+  const V3<T> F = mB * (a_c - gb + dB * v_c);
+  const V3<T> Iw = symmul(I, wB);
+  const V3<T> N = symmul(I, a) + cross(wB, Iw) + eB * Iw;
+  // joint torques y . (N + r x F): both links load joint 1, the lower one joint 2
+  const T h1 = both_halves(N.y + (r1.z * F.x - r1.x * F.z));
+  const T h2 = from_lower(lower, N.y + (r2.z * F.x - r2.x * F.z));
+  const V3<T> Fleg = both_halves(F);
+  const V3<T> Nleg = both_halves(N + cross(c, F));
   // e = Lp^-1 h ; y = Lp^-T e = P^-1 h
   const T e1 = h1 * iL11, e2 = (h2 - L21 * e1) * iL22;
   const T y2 = e2 * iL22, y1 = (e1 - L21 * y2) * iL11;
@@ -193,15 +204,15 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   SOLO_STAMP(B, 4);
   // ---- base level: Schur complement S and right-hand side, summed over the four legs -------
   // leg composite about the base origin
-  const T mleg = mU + mL;
-  const V3<T> mc = mU * cU + mL * cL;
+  const T mleg = L.link[0][0] + L.link[1][0];
+  const V3<T> mc = both_halves(mB * c);
   T IO[6];
-  IO[0] = IU[0] + IL[0] + mU * (cU.y * cU.y + cU.z * cU.z) + mL * (cL.y * cL.y + cL.z * cL.z);
-  IO[1] = IU[1] + IL[1] + mU * (cU.x * cU.x + cU.z * cU.z) + mL * (cL.x * cL.x + cL.z * cL.z);
-  IO[2] = IU[2] + IL[2] + mU * (cU.x * cU.x + cU.y * cU.y) + mL * (cL.x * cL.x + cL.y * cL.y);
-  IO[3] = IU[3] + IL[3] - mU * cU.x * cU.y - mL * cL.x * cL.y;
-  IO[4] = IU[4] + IL[4] - mU * cU.x * cU.z - mL * cL.x * cL.z;
-  IO[5] = IU[5] + IL[5] - mU * cU.y * cU.z - mL * cL.y * cL.z;
+  IO[0] = both_halves(I[0] + mB * (c.y * c.y + c.z * c.z));
+  IO[1] = both_halves(I[1] + mB * (c.x * c.x + c.z * c.z));
+  IO[2] = both_halves(I[2] + mB * (c.x * c.x + c.y * c.y));
+  IO[3] = both_halves(I[3] - mB * c.x * c.y);
+  IO[4] = both_halves(I[4] - mB * c.x * c.z);
+  IO[5] = both_halves(I[5] - mB * c.y * c.z);
   T S[6][6];  // lower triangle used
   S[0][0] = IO[0]; S[1][0] = IO[3]; S[1][1] = IO[1]; S[2][0] = IO[4]; S[2][1] = IO[5]; S[2][2] = IO[2];
   S[3][0] = T(0);  S[3][1] = mc.z;  S[3][2] = -mc.y;

@@ -68,6 +68,8 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// the value of lane ^ 8: the other half of the caller's 16-lane row (DPP row_ror:8)
+template <typename T> __device__ __forceinline__ T wave_other_half16(T x) { return dpp_mov<0x128>(x); }
 // sum over the 16 lanes of the caller's row, result in every lane (row_ror 8,4,2,1 all-reduce)
 template <typename T> __device__ __forceinline__ T wave_sum_group16(T x) {
   x += dpp_mov<0x128>(x);

@@ -151,6 +151,7 @@ template <typename T> inline T wave_sum_legs(T x) {
   x += emu_shfl_xor(x, 32);
   return x;
 }
+template <typename T> inline T wave_other_half16(T x) { return emu_shfl_xor(x, 8); }
 template <typename T> inline T wave_sum_group16(T x) {
   x += emu_shfl_xor(x, 8);
   x += emu_shfl_xor(x, 4);
