@@ -262,12 +262,13 @@ struct Engine final : EngineBase {
       HIP_TRY(hipGetLastError());
       if (bookkeeping) {
         hipLaunchKernelGGL(solo::solo_returns_kernel<T>, dim3((count + solo::kOutputThreads - 1) / solo::kOutputThreads),
-                           dim3(solo::kOutputThreads), 0, s, state, events, steps, n, lo, count, r, r_stride, stats);
+                           dim3(solo::kOutputThreads), 0, s, state, events, steps, n, lo, count, r, r_stride, stats,
+                           r == reward_scratch ? reward : (T*)nullptr);
         HIP_TRY(hipGetLastError());
-      }
-      if (want_reward && r == reward_scratch)  // the view keeps the last step's reward
+      } else if (want_reward && r == reward_scratch) {  // the view keeps the last step's reward
         HIP_TRY(hipMemcpyAsync(reward + lo, reward_scratch + (size_t)(steps - 1) * n + lo, (size_t)count * sizeof(T),
                                hipMemcpyDeviceToDevice, s));
+      }
     }
     return SOLO_OK;
   }

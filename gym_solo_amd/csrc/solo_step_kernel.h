@@ -804,10 +804,12 @@ template <typename T>
 __global__ __launch_bounds__(kOutputThreads) void solo_returns_kernel(T* __restrict__ state, const uint8_t* __restrict__ events, int steps,
                                                                       int num_envs, int env_base, int count,
                                                                       const T* __restrict__ reward, long long reward_stride,
-                                                                      double* __restrict__ stats) {
+                                                                      double* __restrict__ stats, T* __restrict__ view_reward) {
   const int e = blockIdx.x * kOutputThreads + threadIdx.x;
   if (e >= count) return;
   const int env = env_base + e;
+  // (a rollout that does not record keeps its last step's reward in the engine's view)
+  if (view_reward != nullptr) view_reward[env] = reward[(size_t)(steps - 1) * reward_stride + env];
   // sharded: all robots of a batch finish their episodes in the same step, and same-address
   // atomics serialise
   accumulate_returns<T>(state + (size_t)env * SOLO_STATE_STRIDE, events + env, num_envs, reward + env, reward_stride, steps,
