@@ -277,7 +277,15 @@ struct Engine final : EngineBase {
     if (int rc = check_flags(flags)) return rc;
     if (k == 0) return SOLO_OK;  // an empty rollout is a no-op
     if (!a || k < 0) { err = "rollout needs actions [K][N][12]"; return SOLO_ERR_INVALID_ARG; }
-    return rollout_impl((const T*)a, k, flags, obs_out, reward_out, done_out, s, nullptr, nullptr);
+    if (int rc = rollout_impl((const T*)a, k, flags, obs_out, reward_out, done_out, s, nullptr, nullptr)) return rc;
+    // the engine's view always ends up with the LAST step's outputs, also when every step was recorded
+    if (obs_out && (flags & SOLO_STEP_OBS))
+      HIP_TRY(hipMemcpyAsync(obs, (const T*)obs_out + (size_t)(k - 1) * n * obs_dim, (size_t)n * obs_dim * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (reward_out && (flags & SOLO_STEP_REWARD))
+      HIP_TRY(hipMemcpyAsync(reward, (const T*)reward_out + (size_t)(k - 1) * n, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (done_out && (flags & SOLO_STEP_DONE))
+      HIP_TRY(hipMemcpyAsync(done, (const uint8_t*)done_out + (size_t)(k - 1) * n, (size_t)n, hipMemcpyDeviceToDevice, s));
+    return SOLO_OK;
   }
 
   // t0 / t1 (optional): timing events recorded on the stream slice 0's kernels are launched on

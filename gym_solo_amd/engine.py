@@ -158,8 +158,8 @@ class Engine:
   def rollout(self, actions, flags=abi.STEP_ALL, record=False, out=None):
     """K open-loop env steps with actions [K, N, 12]; ceil(K / steps_per_launch) fused launches.
     record=True (or out=rollout_buffers(K)) keeps every step's (obs [K,N,D], reward [K,N],
-    done [K,N] uint8) — what a rollout collector reads; otherwise only the last step's outputs
-    remain in the engine's view."""
+    done [K,N] uint8) — what a rollout collector reads; the engine's view holds the last step's
+    outputs afterwards in either case."""
     torch = self._torch
     k = int(actions.shape[0])
     p = self._dev_ptr(actions, (k, self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')

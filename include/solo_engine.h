@@ -262,8 +262,9 @@ int solo_engine_step(SoloEngine* eng, const void* actions_dev, uint32_t flags, v
 int solo_engine_rollout(SoloEngine* eng, const void* actions_dev, int32_t num_steps,
                         uint32_t flags, void* stream);
 /* Same, but every step's outputs are kept: obs_out real [K][N][D], reward_out real [K][N],
- * done_out uint8 [K][N] (caller-owned device buffers; a NULL pointer = that output is only left
- * in the engine's view for the last step).  This is what an RL rollout collector reads. */
+ * done_out uint8 [K][N] (caller-owned device buffers; a NULL pointer = that output is not recorded).
+ * The engine's view holds the last step's outputs afterwards in either case.  This is what an RL
+ * rollout collector reads. */
 int solo_engine_rollout_record(SoloEngine* eng, const void* actions_dev, int32_t num_steps,
                                uint32_t flags, void* obs_out, void* reward_out, void* done_out,
                                void* stream);
