@@ -255,10 +255,10 @@ struct Engine final : EngineBase {
         if (reward_out) { r = reward_out + (size_t)i * n; r_stride = n; }
         else { r = reward_scratch; r_stride = n; }
       }
-      const long long items = (long long)steps * count;
       const bool bookkeeping = want_reward && (flags & SOLO_STEP_DONE);
-      hipLaunchKernelGGL(solo::solo_outputs_kernel<T>, dim3((unsigned)((items + solo::kOutputThreads - 1) / solo::kOutputThreads)),
-                         dim3(solo::kOutputThreads), 0, s, dparams, traj, steps, n, lo, count, o, o_stride, o_from, r, r_stride);
+      constexpr int kT = sizeof(T) == 4 ? 128 : 64;  // threads per block: ~50 KB of LDS staging either way
+      hipLaunchKernelGGL((solo::solo_outputs_kernel<T, kT>), dim3((count + kT - 1) / kT, steps), dim3(kT), 0, s, dparams, traj, n, lo,
+                         count, o, o_stride, o_from, r, r_stride);
       HIP_TRY(hipGetLastError());
       if (bookkeeping) {
         hipLaunchKernelGGL(solo::solo_returns_kernel<T>, dim3((count + solo::kOutputThreads - 1) / solo::kOutputThreads),
