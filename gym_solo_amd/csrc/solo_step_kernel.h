@@ -796,7 +796,7 @@ __global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>
   const int nb = count - e0 < kThreads ? count - e0 : kThreads;
   const T* src = traj + ((size_t)k * num_envs + env_base + e0) * SOLO_STATE_STRIDE;
   for (int w = tid; w < nb * SOLO_STATE_STRIDE; w += kThreads) s_rec[w / SOLO_STATE_STRIDE][w % SOLO_STATE_STRIDE] = src[w];
-  __syncthreads();
+  block_sync();
   const int n_obs = P->num_obs;
   const bool want_obs = obs != nullptr && k >= obs_from_step;
   const bool staged = n_obs <= kObsStageMax;
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>
       reward[(size_t)k * reward_stride + env] = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kThreads);
   }
   if (want_obs && staged) {
-    __syncthreads();
+    block_sync();
     T* dst = obs + (size_t)k * obs_stride + (size_t)(env_base + e0) * n_obs;  // nb rows of n_obs, contiguous
     int row = tid / n_obs, col = tid % n_obs;
     const int drow = kThreads / n_obs, dcol = kThreads % n_obs;

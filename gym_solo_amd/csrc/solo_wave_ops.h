@@ -14,6 +14,8 @@ __device__ __forceinline__ int block_id() { return blockIdx.x; }
 
 // Orders this wave's LDS writes before the following LDS reads of other lanes.
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// barrier of a multi-wave block (the output kernels)
+__device__ __forceinline__ void block_sync() { __syncthreads(); }
 // wave-uniform pointer made opaque to the optimiser (no instruction): loads through the result
 // are not hoisted above this point
 template <typename P> __device__ __forceinline__ P* wave_opaque(P* p) {
