@@ -125,6 +125,7 @@ inline int wave_opaque_lane(int lane) { return lane; }
 inline int wave_uniform(int x) { return x; }
 inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
 inline void wave_set_priority(int, int, int, int) {}
+inline void block_sync() {}  // (the thread-per-item output kernels are not emulated: their per-item functions run in loops)
 template <typename T> struct RowDot {
   T g[6], h[2];
   void set(const T* gh, const T* hh) { for (int i = 0; i < 6; ++i) g[i] = gh[i]; h[0] = hh[0]; h[1] = hh[1]; }
