@@ -145,6 +145,9 @@ def test_ragged_recording_rollout_with_slices_equals_single_steps(torch):
                                                  env.engine.stats.cpu().numpy(), env.engine.obs.cpu().numpy(),
                                                  env.engine.reward.cpu().numpy()]
     env._close()
-  for a, b in zip(out[1], out[7]):
-    np.testing.assert_array_equal(a, b)
+  for i, (a, b) in enumerate(zip(out[1], out[7])):
+    if i == 5:  # episodic statistics: double atomics from 12 robots per shard, in scheduling order
+      np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
+    else:
+      np.testing.assert_array_equal(a, b)
   assert out[1][2].sum() == 2 * 777  # two episode ends (steps 10 and 20) per robot
