@@ -218,7 +218,7 @@ def main():
     bytes_per_launch = BYTES_PER_ENV_STEP[args.dtype] * env_steps_per_launch
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     line = {
-      'metric': 'env-steps/s (whole node), 4096 Solo8 envs/GPU', 'value': value, 'unit': 'env-steps/s',
+      'metric': 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X', 'value': value, 'unit': 'env-steps/s',
       'n_gpus': world, 'steps': k, 'warmup': w, 'ms_per_step': elapsed / k * 1e3,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32' if args.dtype == 'float32' else 'f64', 'data': 'synthetic',
