@@ -257,7 +257,8 @@ struct Engine final : EngineBase {
       }
       const bool bookkeeping = want_reward && (flags & SOLO_STEP_DONE);
       constexpr int kT = sizeof(T) == 4 ? 128 : 64;  // threads per block: ~50 KB of LDS staging either way
-      hipLaunchKernelGGL((solo::solo_outputs_kernel<T, kT>), dim3((count + kT - 1) / kT, steps), dim3(kT), 0, s, dparams, traj, n, lo,
+      const int gx = (count + kT - 1) / kT, gy = steps < 1024 / gx + 1 ? steps : 1024 / gx + 1;  // ~1000 blocks, each walking steps / gy steps
+      hipLaunchKernelGGL((solo::solo_outputs_kernel<T, kT>), dim3(gx, gy), dim3(kT), 0, s, dparams, traj, steps, n, lo,
                          count, o, o_stride, o_from, r, r_stride);
       HIP_TRY(hipGetLastError());
       if (bookkeeping) {

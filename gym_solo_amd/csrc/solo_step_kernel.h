@@ -778,47 +778,50 @@ constexpr int kOutputThreads = 256;   // returns kernel
 constexpr int kObsStageMax = 32;      // observations of up to this many elements leave through LDS, coalesced
 
 // Observations (steps >= obs_from_step only) and rewards of `steps` x `count` robot-steps.
-// grid = (ceil(count / kThreads), steps): a block owns kThreads consecutive robots of ONE step,
+// grid = (ceil(count / kThreads), <= steps): a block owns kThreads consecutive robots of ONE step at a time,
 // whose records are contiguous in traj [steps][num_envs][32] and whose observation rows are
 // contiguous in obs - both move through LDS with fully coalesced accesses (a thread reading its
 // own 128-B record / writing its own D-element row directly would touch 64 different lines per
 // instruction).  obs / reward: element (k, env) at k * stride + env (* num_obs).
 template <typename T, int kThreads>
 __global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>* __restrict__ P, const T* __restrict__ traj,
-                                                                int num_envs, int env_base, int count,
+                                                                int steps, int num_envs, int env_base, int count,
                                                                 T* __restrict__ obs, long long obs_stride, int obs_from_step,
                                                                 T* __restrict__ reward, long long reward_stride) {
   __shared__ T s_rec[kThreads][SOLO_STATE_STRIDE + 1];        // (+1: conflict-free row access)
   __shared__ T s_val[SOLO_MAX_REWARD_OPS][kThreads];           // reward program values, one column per thread
   __shared__ T s_obs[kThreads][kObsStageMax + 1];
-  const int tid = threadIdx.x, k = blockIdx.y;
+  const int tid = threadIdx.x;
   const int e0 = blockIdx.x * kThreads;                        // first robot of this block within the launch's slice
   const int nb = count - e0 < kThreads ? count - e0 : kThreads;
-  const T* src = traj + ((size_t)k * num_envs + env_base + e0) * SOLO_STATE_STRIDE;
-  for (int w = tid; w < nb * SOLO_STATE_STRIDE; w += kThreads) s_rec[w / SOLO_STATE_STRIDE][w % SOLO_STATE_STRIDE] = src[w];
-  block_sync();
   const int n_obs = P->num_obs;
-  const bool want_obs = obs != nullptr && k >= obs_from_step;
   const bool staged = n_obs <= kObsStageMax;
   const int env = env_base + e0 + tid;
-  if (tid < nb) {
-    const T* rec = s_rec[tid];
-    T roll, pitch, yaw;
-    euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
-    if (want_obs)
-      eval_observations<T>(P, rec, roll, pitch, yaw, staged ? &s_obs[tid][0] : obs + (size_t)k * obs_stride + (size_t)env * n_obs);
-    if (reward != nullptr)
-      reward[(size_t)k * reward_stride + env] = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kThreads);
-  }
-  if (want_obs && staged) {
+  // (a block walks several steps: few fat blocks instead of one small block per step)
+  for (int k = blockIdx.y; k < steps; k += gridDim.y) {
+    const T* src = traj + ((size_t)k * num_envs + env_base + e0) * SOLO_STATE_STRIDE;
+    for (int w = tid; w < nb * SOLO_STATE_STRIDE; w += kThreads) s_rec[w / SOLO_STATE_STRIDE][w % SOLO_STATE_STRIDE] = src[w];
     block_sync();
-    T* dst = obs + (size_t)k * obs_stride + (size_t)(env_base + e0) * n_obs;  // nb rows of n_obs, contiguous
-    int row = tid / n_obs, col = tid % n_obs;
-    const int drow = kThreads / n_obs, dcol = kThreads % n_obs;
-    for (int w = tid; w < nb * n_obs; w += kThreads) {
-      dst[w] = s_obs[row][col];
-      row += drow; col += dcol;
-      if (col >= n_obs) { col -= n_obs; row += 1; }
+    const bool want_obs = obs != nullptr && k >= obs_from_step;
+    if (tid < nb) {
+      const T* rec = s_rec[tid];
+      T roll, pitch, yaw;
+      euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
+      if (want_obs)
+        eval_observations<T>(P, rec, roll, pitch, yaw, staged ? &s_obs[tid][0] : obs + (size_t)k * obs_stride + (size_t)env * n_obs);
+      if (reward != nullptr)
+        reward[(size_t)k * reward_stride + env] = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kThreads);
+    }
+    block_sync();
+    if (want_obs && staged) {
+      T* dst = obs + (size_t)k * obs_stride + (size_t)(env_base + e0) * n_obs;  // nb rows of n_obs, contiguous
+      int row = tid / n_obs, col = tid % n_obs;
+      const int drow = kThreads / n_obs, dcol = kThreads % n_obs;
+      for (int w = tid; w < nb * n_obs; w += kThreads) {
+        dst[w] = s_obs[row][col];
+        row += drow; col += dcol;
+        if (col >= n_obs) { col -= n_obs; row += 1; }
+      }
     }
   }
 }
