@@ -93,7 +93,18 @@ def cpu_baseline(num_envs, seconds_target=12.0):
     el = time.perf_counter() - t0
     if el > seconds_target or steps >= 2000:
       break
-  return {'value': num_envs * steps / el, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+  # the same oracle on ONE core (a short sample), for the per-core figure SURVEY.md §8d asks for
+  env1 = so.OracleEnv(ca, ma, 256, [('torso_imu', {}), ('motor_encoder', {})],
+                      [(1, env_cases.BENCH_REWARD)], [('time', 1000)], threads=1)
+  if lib_path:
+    env1.phys = so.OraclePhysics(ca, ma, lib_path)
+  env1.step(rng.uniform(-2 * np.pi, 2 * np.pi, (256, 12)))
+  s1, t1 = 0, time.perf_counter()
+  while time.perf_counter() - t1 < 3.0:
+    env1.step(rng.uniform(-2 * np.pi, 2 * np.pi, (256, 12)))
+    s1 += 1
+  one_core = 256 * s1 / (time.perf_counter() - t1)
+  return {'value': num_envs * steps / el, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'value_one_core': one_core,
           'sample': '%d envs x %d steps of the same workload on the f64 C oracle (OpenMP over envs, '
                     '%d threads) + numpy obs/reward, %.1f s' % (num_envs, steps, cores, el)}
 
