@@ -46,6 +46,7 @@ OBS_NORMALIZE = 2
 T_PERPETUAL, T_TIME, T_CONST = 0, 1, 2
 
 STEP_PHYSICS, STEP_OBS, STEP_REWARD, STEP_DONE, STEP_ALL = 1, 2, 4, 8, 15
+STEP_AUTO_RESET = 16  # let a launch without STEP_PHYSICS auto-reset the robots whose `done` fires
 
 PARAM_FRICTION, PARAM_BASE_MASS_SCALE = 0, 1
 

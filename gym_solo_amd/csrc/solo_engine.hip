@@ -175,8 +175,8 @@ struct Engine final : EngineBase {
   int reset(const uint8_t* mask, hipStream_t s) override {
     HIP_TRY(hipSetDevice(device));
     const int total = n * SOLO_STATE_STRIDE;
-    hipLaunchKernelGGL(solo::solo_reset_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, state, snapshot,
-                       term_count, mask, n);
+    hipLaunchKernelGGL(solo::solo_reset_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, dparams, state, snapshot,
+                       targets, term_count, mask, n);
     HIP_TRY(hipGetLastError());
     return SOLO_OK;
   }
@@ -192,7 +192,7 @@ struct Engine final : EngineBase {
   }
 
   int check_flags(uint32_t flags) {
-    if (flags == 0 || (flags & ~SOLO_STEP_ALL)) { err = "bad step flags"; return SOLO_ERR_INVALID_ARG; }
+    if ((flags & SOLO_STEP_ALL) == 0 || (flags & ~(SOLO_STEP_ALL | SOLO_STEP_AUTO_RESET))) { err = "bad step flags"; return SOLO_ERR_INVALID_ARG; }
     if ((flags & (SOLO_STEP_OBS | SOLO_STEP_REWARD | SOLO_STEP_DONE)) && !have_program) {
       err = "no observation/reward/termination program registered";
       return SOLO_ERR_NO_PROGRAM;
@@ -289,19 +289,21 @@ struct Engine final : EngineBase {
     return SOLO_OK;
   }
 
-  // t0 / t1 (optional): timing events recorded on the stream slice 0's kernels are launched on
+  // t0 / t1 (optional, [groups] each): timing events recorded around every slice's launch chain, on
+  // the stream that chain is launched on
   int rollout_impl(const T* act, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out,
-                   hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+                   hipStream_t s, hipEvent_t* t0, hipEvent_t* t1, int* groups_out = nullptr) {
     HIP_TRY(hipSetDevice(device));
     const long long stride = act ? (long long)n * SOLO_NUM_JOINTS : 0;
     T* oo = (flags & SOLO_STEP_OBS) ? (T*)obs_out : nullptr;
     T* ro = (flags & SOLO_STEP_REWARD) ? (T*)reward_out : nullptr;
     uint8_t* dn = (flags & SOLO_STEP_DONE) ? (uint8_t*)done_out : nullptr;
-    const int groups = (rollout_streams > 1 && n >= 2 * rollout_streams && k > 1) ? rollout_streams : 1;
+    const int groups = slices();
+    if (groups_out) *groups_out = groups;
     if (groups == 1) {
-      if (t0) HIP_TRY(hipEventRecord(t0, s));
+      if (t0) HIP_TRY(hipEventRecord(t0[0], s));
       if (int rc = launch_chain(act, stride, k, flags, oo, ro, dn, s, 0, n)) return rc;
-      if (t1) HIP_TRY(hipEventRecord(t1, s));
+      if (t1) HIP_TRY(hipEventRecord(t1[0], s));
       return SOLO_OK;
     }
     // Robots are independent, so the batch can be cut into `groups` slices that advance through
@@ -309,8 +311,10 @@ struct Engine final : EngineBase {
     // boundary / tail overlaps the other slices' work.  Fork from and join into the caller's stream.
     if (int rc = ensure_streams(groups)) return rc;
     HIP_TRY(hipEventRecord(ev_fork, s));
-    for (int g = 0; g < groups; ++g) HIP_TRY(hipStreamWaitEvent(sub[g], ev_fork, 0));
-    if (t0) HIP_TRY(hipEventRecord(t0, sub[0]));
+    for (int g = 0; g < groups; ++g) {
+      HIP_TRY(hipStreamWaitEvent(sub[g], ev_fork, 0));
+      if (t0) HIP_TRY(hipEventRecord(t0[g], sub[g]));
+    }
     const int S = spl();
     for (int i = 0; i < k; i += S)
       for (int g = 0; g < groups; ++g) {
@@ -321,13 +325,16 @@ struct Engine final : EngineBase {
                                   dn ? dn + (size_t)i * n : nullptr, sub[g], lo, hi - lo))
           return rc;
       }
-    if (t1) HIP_TRY(hipEventRecord(t1, sub[0]));
     for (int g = 0; g < groups; ++g) {
+      if (t1) HIP_TRY(hipEventRecord(t1[g], sub[g]));
       HIP_TRY(hipEventRecord(ev_join[g], sub[g]));
       HIP_TRY(hipStreamWaitEvent(s, ev_join[g], 0));
     }
     return SOLO_OK;
   }
+
+  // number of independent launch chains a rollout / step is cut into
+  int slices() const { return (rollout_streams > 1 && n >= 2 * rollout_streams) ? rollout_streams : 1; }
 
   static constexpr int kMaxStreams = 8;
   int rollout_streams = 1;
@@ -346,20 +353,27 @@ struct Engine final : EngineBase {
     if (int rc = check_flags(flags)) return rc;
     if (reps <= 0 || !ms) { err = "reps must be positive"; return SOLO_ERR_INVALID_ARG; }
     HIP_TRY(hipSetDevice(device));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    struct Events {  // destroyed on every path out of this function
+      hipEvent_t e[2 * kMaxStreams] = {};
+      ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (hipEvent_t& x : ev.e) HIP_TRY(hipEventCreate(&x));
+    hipEvent_t* e0 = ev.e;
+    hipEvent_t* e1 = ev.e + kMaxStreams;
+    int groups = 1;
     skip_outputs = true;  // the dominant kernel alone (the output kernels are separate, short launches)
-    const int rc_chain = rollout_impl((const T*)a, reps * spl(), flags, nullptr, nullptr, nullptr, s, e0, e1);
+    const int rc_chain = rollout_impl((const T*)a, reps * spl(), flags, nullptr, nullptr, nullptr, s, e0, e1, &groups);
     skip_outputs = false;
     if (rc_chain) return rc_chain;
-    HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipStreamSynchronize(s));
-    float t = 0;
-    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *ms = (double)t / reps;
+    // every slice's chain is timed on its own stream; the slowest chain is reported
+    double worst = 0;
+    for (int g = 0; g < groups; ++g) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, e0[g], e1[g]));
+      if (t > worst) worst = t;
+    }
+    *ms = worst / reps;
     return SOLO_OK;
   }
 

@@ -75,6 +75,7 @@ struct KParams {
   int32_t terr_nx, terr_ny;
   T terr_inv_cell, terr_ox, terr_oy;
   T base_mass, base_I[6];
+  T settle_tgt[SOLO_NUM_JOINTS];  // motor targets a reset leaves behind [rad] (solo8v2vanilla.py:21-34,127-136)
   LegConst<T> leg[4];
   RowConst<T> row[64];
   int32_t num_obs, num_reward_ops, num_terms, pad0;
@@ -154,6 +155,7 @@ inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) 
   k->iterations = c.solver_iterations;
   k->auto_reset = c.auto_reset;
   k->ulp_tol = c.solver_ulp_tolerance;
+  for (int j = 0; j < SOLO_NUM_JOINTS; ++j) k->settle_tgt[j] = (T)c.settle_targets[j];
   k->base_mass = (T)m.mass[0];
   for (int a = 0; a < 6; ++a) k->base_I[a] = (T)m.inertia[0][a];
   for (int leg = 0; leg < 4; ++leg) {

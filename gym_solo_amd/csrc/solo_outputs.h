@@ -93,15 +93,15 @@ template <typename T>
 __device__ __forceinline__ T reward_leaf(const RewardInstrK<T>& r, const T* rec, T roll, T pitch) {
   using R = Real<T>;
   switch (r.op) {
-    case SOLO_R_UPRIGHT: {  // rewards.py:121-141: pitch relative to "fully upright" = -pi/2
+    case SOLO_R_UPRIGHT: {  // rewards.py:221-234: pitch relative to "fully upright" = -pi/2
       const T fu = T(-1.5707963267948966);
       return fu * pitch / (fu * fu);
     }
     case SOLO_R_FLAT_TORSO:  // rewards.py:256-269
       return tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -r.a, r.a, r.b, r.d);
-    case SOLO_R_TORSO_HEIGHT:  // rewards.py:326-338
+    case SOLO_R_TORSO_HEIGHT:  // rewards.py:362-373
       return tolerance<T>(rec[SOLO_S_POS + 2], r.a - r.b, r.a + r.b, r.c, r.d);
-    case SOLO_R_HORIZ_SPEED: {  // rewards.py:362-373
+    case SOLO_R_HORIZ_SPEED: {  // rewards.py:326-338
       const T vx = rec[SOLO_S_LINVEL], vy = rec[SOLO_S_LINVEL + 1];
       return tolerance<T>(R::sqrt(vx * vx + vy * vy), r.a - r.b, r.a + r.b, r.c, r.d);
     }

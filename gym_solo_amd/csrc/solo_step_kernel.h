@@ -596,6 +596,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][20];
   __shared__ T s_val[SOLO_MAX_REWARD_OPS];  // reward program values of an inline evaluation (single-step launches)
+  __shared__ int s_cnt[SOLO_MAX_TERMS];     // TimeBased step counters (termination.py:72-83)
   // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
   // read them from LDS instead of paying a global-load latency each
   __shared__ LegConst<T> s_legc[4];
@@ -633,18 +634,9 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = B.state[rec + lane0];
   const T mu = B.params[(size_t)env * 4 + 0];
   const T mass_scale = B.params[(size_t)env * 4 + 1];
-  int cnt[SOLO_MAX_TERMS];
-#pragma unroll
-  for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = B.term_count[(size_t)env * SOLO_MAX_TERMS + t];
-  // termination program: a handful of wave-uniform ints, read once per launch (scalar registers)
-  const int n_terms = (B.flags & SOLO_STEP_DONE) ? wave_uniform(P0->num_terms) : 0;
-  const int auto_reset = wave_uniform(P0->auto_reset);
-  int term_kind[SOLO_MAX_TERMS], term_param[SOLO_MAX_TERMS];
-#pragma unroll
-  for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
-    term_kind[t] = wave_uniform(P0->term_kind[t]);
-    term_param[t] = wave_uniform(P0->term_param[t]);
-  }
+  // TimeBased counters of this robot live in LDS across the launch's steps (kept in scalar
+  // registers next to the termination program they cost 25 SGPR spills in the fused step loop)
+  if (lane0 < SOLO_MAX_TERMS) s_cnt[lane0] = B.term_count[(size_t)env * SOLO_MAX_TERMS + lane0];
 
   // B.steps consecutive env steps of THIS robot in one launch: the state record stays in LDS,
   // only actions come in and the step records / done flags go out per step.  Robots are independent, so
@@ -695,19 +687,38 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83)
     bool done = false;
     if (B.flags & SOLO_STEP_DONE) {
+      // every lane evaluates the same list on the same counters; lane 0 writes them back.  The
+      // program (a few wave-uniform ints) is re-read through the per-step pointer: scalar loads,
+      // nothing carried across the step loop.
+      const int n_terms = wave_uniform(P->num_terms);
+      int c[SOLO_MAX_TERMS];
+#pragma unroll
+      for (int t = 0; t < SOLO_MAX_TERMS; ++t) c[t] = s_cnt[t];
+      wave_sync();
+      bool d = false;
 #pragma unroll
       for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
-        if (t < n_terms && !done) {
-          if (term_kind[t] == SOLO_T_TIME) {
-            cnt[t] += 1;
-            done = cnt[t] > term_param[t];
-          } else if (term_kind[t] == SOLO_T_CONST) {
-            done = term_param[t] != 0;
+        if (t < n_terms && !d) {
+          const int kind = wave_uniform(P->term_kind[t]), param = wave_uniform(P->term_param[t]);
+          if (kind == SOLO_T_TIME) {
+            c[t] += 1;
+            d = c[t] > param;
+          } else if (kind == SOLO_T_CONST) {
+            d = param != 0;
           }
         }
       }
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < SOLO_MAX_TERMS; ++t) s_cnt[t] = c[t];
+      }
+      done = wave_ballot(d) != 0ull;  // (identical in every lane; the ballot makes it a scalar)
     }
-    const bool restart = (B.flags & SOLO_STEP_DONE) && (done || diverged) && auto_reset != 0;
+    // The auto-reset belongs to a step that advanced the simulation (or asks for it explicitly):
+    // a query-only launch - TerminationFactory.is_terminated() outside step(), termination.py:38-50
+    // - never mutates the physics state.
+    const bool restart = (B.flags & SOLO_STEP_DONE) && (B.flags & (SOLO_STEP_PHYSICS | SOLO_STEP_AUTO_RESET)) &&
+                         (done || diverged) && wave_uniform(P->auto_reset) != 0;
     // ---- the step's record for the output kernels (solo_outputs.h): the state after the step,
     //      before an auto-reset (one coalesced 32-real store), and the step's event bits
     if (B.traj != nullptr) {
@@ -750,8 +761,9 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
       if (restart) {
         wave_sync();  // the record above is read from the old state first
         if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
-#pragma unroll
-        for (int t = 0; t < SOLO_MAX_TERMS; ++t) cnt[t] = 0;
+        if (lane < SOLO_MAX_TERMS) s_cnt[lane] = 0;
+        // reset() leaves the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
+        if (lane < SOLO_NUM_JOINTS) B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = P->settle_tgt[lane];
       }
       if (lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
     }
@@ -760,10 +772,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   }
   SOLO_STAMP(B, 13);
   const int lane1 = wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
-  if ((B.flags & SOLO_STEP_DONE) && lane1 == 0) {
-#pragma unroll
-    for (int t = 0; t < SOLO_MAX_TERMS; ++t) B.term_count[(size_t)env * SOLO_MAX_TERMS + t] = cnt[t];
-  }
+  if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) B.term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
   // (slots SOLO_S_RETURN.. of the record are the returns kernel's: never written from here)
   if (lane1 < SOLO_S_RETURN) B.state[rec + lane1] = s_state[lane1];
   SOLO_STAMP(B, 14);
@@ -854,14 +863,17 @@ __global__ void solo_set_targets_kernel(const T* __restrict__ actions, T* __rest
 
 // resetSimulation + settle, as a masked snapshot restore (solo8v2vanilla.py:104-143)
 template <typename T>
-__global__ void solo_reset_kernel(T* __restrict__ state, const T* __restrict__ snapshot,
-                                  int32_t* __restrict__ term_count, const uint8_t* __restrict__ mask, int num_envs) {
+__global__ void solo_reset_kernel(const KParams<T>* __restrict__ P, T* __restrict__ state, const T* __restrict__ snapshot,
+                                  T* __restrict__ targets, int32_t* __restrict__ term_count,
+                                  const uint8_t* __restrict__ mask, int num_envs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = i / SOLO_STATE_STRIDE, e = i % SOLO_STATE_STRIDE;
   if (env >= num_envs) return;
   if (mask != nullptr && mask[env] == 0) return;
   state[i] = snapshot[i];
   if (e < SOLO_MAX_TERMS) term_count[env * SOLO_MAX_TERMS + e] = 0;
+  // the settle loop ends with the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
+  if (e < SOLO_NUM_JOINTS) targets[env * SOLO_NUM_JOINTS + e] = P->settle_tgt[e];
 }
 
 // loadURDF at robot_start_pos / orientation (solo8v2vanilla.py:151-155), zero velocities

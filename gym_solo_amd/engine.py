@@ -35,10 +35,11 @@ def load_library(path=_LIB_PATH):
 
 
 class _DeviceArray:
-  """Borrowed view of engine-owned device memory for ``torch.as_tensor`` (zero copy)."""
+  """Borrowed view of engine-owned device memory for ``torch.as_tensor`` (zero copy).  It holds no
+  reference to the engine (torch keeps this object alive from C++, which Python's GC cannot see
+  through: a back-reference would make every engine immortal)."""
 
-  def __init__(self, ptr, shape, typestr, owner):
-    self._owner = owner  # keeps the engine alive while views exist
+  def __init__(self, ptr, shape, typestr):
     self.__cuda_array_interface__ = {
       'shape': tuple(int(s) for s in shape), 'typestr': typestr, 'data': (int(ptr), False),
       'version': 2, 'strides': None}
@@ -51,8 +52,21 @@ def _raise(rc, msg):
   raise EngineError('{} (status {})'.format(msg, rc))
 
 
+def _destroy(lib, handle, torch, device):
+  try:
+    torch.cuda.synchronize(device)
+  except Exception:  # noqa: BLE001 - interpreter shutdown
+    pass
+  lib.solo_engine_destroy(handle)
+
+
 class Engine:
-  """One handle per GPU/process; not thread-safe; stream-ordered on torch's current stream."""
+  """One handle per GPU/process; not thread-safe; stream-ordered on torch's current stream.
+
+  Lifetime: the device buffers belong to the engine and are freed by ``close()`` (or when the
+  Engine object is collected).  The tensors it hands out (``state``, ``obs``, ``reward`` ... and
+  the zero-copy outputs of ``Solo8VanillaEnv(copy_outputs=False)``) ALIAS those buffers: keep the
+  engine alive while they are in use, and do not touch them after ``close()``."""
 
   def __init__(self, cfg: abi.SoloConfig, model: abi.SoloModel, num_envs: int, device: int = 0):
     import torch  # plumbing only
@@ -67,15 +81,25 @@ class Engine:
     if rc != abi.OK:
       self._h = None
       _raise(rc, 'solo_engine_create: ' + self.lib.solo_last_create_error().decode())
+    import weakref
+    self._finalizer = weakref.finalize(self, _destroy, self.lib, self._h, torch, self.device)
     self.program = None
     self._action_shape = (self.num_envs, abi.NUM_JOINTS)
-    self._views = {}
     self._make_views()
 
   # ---- plumbing --------------------------------------------------------------------------
+  @property
+  def is_closed(self):
+    return self._h is None
+
+  def _handle(self):
+    if self._h is None:
+      raise EngineError('the engine was closed (its device buffers are freed)')
+    return self._h
+
   def _check(self, rc, what):
     if rc != abi.OK:
-      _raise(rc, '{}: {}'.format(what, self.lib.solo_engine_last_error(self._h).decode()))
+      _raise(rc, '{}: {}'.format(what, self.lib.solo_engine_last_error(self._handle()).decode()))
 
   def _stream(self):
     return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
@@ -83,12 +107,12 @@ class Engine:
   def _make_views(self):
     torch = self._torch
     v = abi.SoloStateView()
-    self._check(self.lib.solo_engine_get_view(self._h, C.byref(v)), 'get_view')
+    self._check(self.lib.solo_engine_get_view(self._handle(), C.byref(v)), 'get_view')
     real = '<f4' if v.dtype == abi.F32 else '<f8'
     n = v.num_envs
     dev = 'cuda:%d' % self.device
     def view(ptr, shape, typestr):
-      return torch.as_tensor(_DeviceArray(ptr, shape, typestr, self), device=dev)
+      return torch.as_tensor(_DeviceArray(ptr, shape, typestr), device=dev)
     self.state = view(v.state, (n, abi.STATE_STRIDE), real)
     self.snapshot = view(v.snapshot, (n, abi.STATE_STRIDE), real)
     self.targets = view(v.targets, (n, abi.NUM_JOINTS), real)
@@ -118,7 +142,7 @@ class Engine:
 
   # ---- C-ABI calls -----------------------------------------------------------------------
   def set_program(self, program: abi.SoloProgram):
-    self._check(self.lib.solo_engine_set_program(self._h, C.byref(program)), 'set_program')
+    self._check(self.lib.solo_engine_set_program(self._handle(), C.byref(program)), 'set_program')
     self.program = program
     self._make_views()
 
@@ -126,20 +150,20 @@ class Engine:
     p = None
     if mask is not None:
       p = self._dev_ptr(mask, (self.num_envs,), self._torch.uint8, 'mask')
-    self._check(self.lib.solo_engine_reset(self._h, p, self._stream()), 'reset')
+    self._check(self.lib.solo_engine_reset(self._handle(), p, self._stream()), 'reset')
 
   def settle(self):
-    self._check(self.lib.solo_engine_settle(self._h, self._stream()), 'settle')
+    self._check(self.lib.solo_engine_settle(self._handle(), self._stream()), 'settle')
 
   def set_targets(self, actions):
     p = self._dev_ptr(actions, (self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
-    self._check(self.lib.solo_engine_set_targets(self._h, p, self._stream()), 'set_targets')
+    self._check(self.lib.solo_engine_set_targets(self._handle(), p, self._stream()), 'set_targets')
 
   def step(self, actions=None, flags=abi.STEP_ALL):
     p = None
     if actions is not None:
       p = self._dev_ptr(actions, self._action_shape, self.tdtype, 'actions')
-    rc = self.lib.solo_engine_step(self._h, p, flags, self._stream())
+    rc = self.lib.solo_engine_step(self._handle(), p, flags, self._stream())
     if rc != abi.OK:
       self._check(rc, 'step')
 
@@ -164,14 +188,14 @@ class Engine:
     k = int(actions.shape[0])
     p = self._dev_ptr(actions, (k, self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
     if not record and out is None:
-      self._check(self.lib.solo_engine_rollout(self._h, p, k, flags, self._stream()), 'rollout')
+      self._check(self.lib.solo_engine_rollout(self._handle(), p, k, flags, self._stream()), 'rollout')
       return None
     obs, rew, done = out if out is not None else self.rollout_buffers(k)
     self._dev_ptr(obs, (k, self.num_envs, max(self.obs_dim, 1)), self.tdtype, 'obs_out')
     self._dev_ptr(rew, (k, self.num_envs), self.tdtype, 'reward_out')
     self._dev_ptr(done, (k, self.num_envs), torch.uint8, 'done_out')
     self._check(self.lib.solo_engine_rollout_record(
-      self._h, p, k, flags, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
+      self._handle(), p, k, flags, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
       C.c_void_p(done.data_ptr()), self._stream()), 'rollout_record')
     return obs, rew, done
 
@@ -186,7 +210,7 @@ class Engine:
       p = self._dev_ptr(actions[:reps * spl], (reps * spl, self.num_envs, abi.NUM_JOINTS),
                         self.tdtype, 'actions')
     ms = C.c_double()
-    self._check(self.lib.solo_engine_time_step(self._h, p, flags, reps, self._stream(),
+    self._check(self.lib.solo_engine_time_step(self._handle(), p, flags, reps, self._stream(),
                                                C.byref(ms)), 'time_step')
     return ms.value
 
@@ -194,11 +218,11 @@ class Engine:
     """terrain: abi.SoloTerrain (abi.make_terrain(heights, cell)) or None for the flat plane;
     re-settles (the reset snapshot depends on the ground)."""
     self._check(self.lib.solo_engine_set_terrain(
-      self._h, C.byref(terrain) if terrain is not None else None, self._stream()), 'set_terrain')
+      self._handle(), C.byref(terrain) if terrain is not None else None, self._stream()), 'set_terrain')
 
   def set_params(self, which, per_env):
     p = self._dev_ptr(per_env, (self.num_envs,), self.tdtype, 'per_env')
-    self._check(self.lib.solo_engine_set_params(self._h, which, p, self._stream()), 'set_params')
+    self._check(self.lib.solo_engine_set_params(self._handle(), which, p, self._stream()), 'set_params')
 
   @property
   def stats(self):
@@ -208,22 +232,16 @@ class Engine:
 
   @property
   def kernel_name(self):
-    return self.lib.solo_engine_kernel_name(self._h).decode()
+    return self.lib.solo_engine_kernel_name(self._handle()).decode()
 
   def synchronize(self):
     self._torch.cuda.synchronize(self.device)
 
   def close(self):
+    """solo_engine_destroy: frees every device buffer.  Tensors handed out earlier dangle."""
     if getattr(self, '_h', None):
-      self._torch.cuda.synchronize(self.device)
       for name in ('state', 'snapshot', 'targets', 'reward', 'done', 'done_bool', 'term_count', 'params',
                    'stats_shards', 'obs'):
         setattr(self, name, None)
-      self.lib.solo_engine_destroy(self._h)
+      self._finalizer()  # synchronises the device, then destroys the handle (runs at most once)
       self._h = None
-
-  def __del__(self):
-    try:
-      self.close()
-    except Exception:
-      pass

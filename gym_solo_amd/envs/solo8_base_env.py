@@ -56,7 +56,8 @@ class Solo8BaseEnv(ABC, spaces.Env):
     self._dirty = True
     self._copy_outputs = getattr(self, '_copy', True)
     self._fused = dict(obs=False, reward=False, done=False)
-    self._valid = dict(obs=-1, reward=-1, done=-1)
+    self._valid = dict(obs=-1, reward=-1)
+    self._done_from_step = False  # the last step()'s launch already evaluated the terminations
 
     self.reset(init_call=True)
 
@@ -150,7 +151,8 @@ class Solo8BaseEnv(ABC, spaces.Env):
     self.engine.set_program(prog)
     self._labels = of.labels if of._observations else []
     self._fused = fused
-    self._valid = dict(obs=-1, reward=-1, done=-1)
+    self._valid = dict(obs=-1, reward=-1)
+    self._done_from_step = False
     self._dirty = False
 
   def _flags(self, physics):
@@ -187,7 +189,12 @@ class Solo8BaseEnv(ABC, spaces.Env):
         if termination.is_terminated():
           return True
       return False
-    if self._valid['done'] != self.client.state_version:
+    if self._done_from_step:
+      # step()'s own launch ticked the counters for this step: hand its result out once
+      self._done_from_step = False
+    else:
+      # a direct TerminationFactory.is_terminated() call: every call ticks the stateful
+      # terminations, as in the reference (termination.py:46-48,81-83).  A query-only launch
+      # never auto-resets (the kernel ties that to SOLO_STEP_PHYSICS / SOLO_STEP_AUTO_RESET).
       self.engine.step(None, abi.STEP_DONE)
-      self._valid['done'] = self.client.state_version
     return self.engine.done.bool()

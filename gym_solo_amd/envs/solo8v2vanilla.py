@@ -99,19 +99,31 @@ class Solo8VanillaEnv(Solo8BaseEnv):
     self._ensure_program()
     eng = self.engine
     actions = self.client.as_actions(action)
-    # setJointMotorControlArray + stepSimulation + obs/reward/done reductions: ONE launch
-    eng.step(actions, self._flags(physics=True))
-    self.client.state_version += 1
-    v = self.client.state_version
     fused = self._fused
-    if fused['obs'] and fused['reward'] and fused['done'] and not self._realtime:
+    if fused['obs'] and fused['reward'] and fused['done']:
+      # setJointMotorControlArray + stepSimulation + obs/reward/done reductions: ONE launch
+      eng.step(actions, self._flags(physics=True))
+      self.client.state_version += 1
+      v = self.client.state_version
+      if not self.config.auto_reset:  # (after an in-kernel auto-reset the buffers hold the terminal outputs,
+        self._valid['obs'] = self._valid['reward'] = v  # not those of the restored state: a later pull re-evaluates)
+      if self._realtime:
+        time.sleep(self.config.dt)
       # everything was produced by that launch: hand the engine's buffers out without going
       # through the three pull-style factory calls (host time per step matters in closed loop)
-      self._valid['obs'] = self._valid['reward'] = self._valid['done'] = v
       if self._copy_outputs:
         return eng.obs.clone(), eng.reward.clone(), eng.done.bool(), {'labels': self._labels}
       return eng.obs, eng.reward, eng.done_bool, {'labels': self._labels}
-    for key in ('obs', 'reward', 'done'):
+
+    # At least one factory holds a Python-only member (a custom Observation / Reward /
+    # Termination without program()): the launch advances the physics and evaluates what is
+    # fusable; the Python members read the post-step state through the client; the terminations
+    # - and with them the auto-reset - come LAST, so that no Python member ever sees a state the
+    # kernel has already reset (reference order: get_obs, get_reward, is_terminated, :96-100).
+    eng.step(actions, self._flags(physics=True) & ~abi.STEP_DONE)
+    self.client.state_version += 1
+    v = self.client.state_version
+    for key in ('obs', 'reward'):
       if fused[key]:
         self._valid[key] = v
 
@@ -120,8 +132,26 @@ class Solo8VanillaEnv(Solo8BaseEnv):
 
     obs_values, obs_labels = self.obs_factory.get_obs()
     reward = self.reward_factory.get_reward()
+    if fused['done']:
+      eng.step(None, abi.STEP_DONE | abi.STEP_AUTO_RESET)
+      self._done_from_step = True
     done = self.termination_factory.is_terminated()
+    if self.config.auto_reset:
+      if fused['done']:
+        self.client.state_version += 1  # (the launch above restored the finished robots)
+      elif done is True or (hasattr(done, 'any') and bool(done.any())):
+        self.reset_where(done)
     return obs_values, reward, done, {'labels': obs_labels}
+
+  def reset_where(self, done):
+    """Restore the robots whose flag is set (``True`` = all) without touching the host-side
+    termination objects' per-episode state of the others."""
+    import torch
+    if done is True:
+      self.engine.reset(None)
+    else:
+      self.engine.reset(torch.as_tensor(done).to(device=self.engine.state.device, dtype=torch.uint8).contiguous())
+    self.client.state_version += 1
 
   def reset(self, init_call: bool = False, mask=None):
     """Restore the post-settle snapshot (solo8v2vanilla.py:104-143).  The reference rebuilds

@@ -228,6 +228,12 @@ typedef struct SoloEngine SoloEngine;
 #define SOLO_STEP_REWARD 4u   /* A8-A11 */
 #define SOLO_STEP_DONE 8u     /* A12 (+ auto-reset when configured) */
 #define SOLO_STEP_ALL 15u
+/* The in-kernel auto-reset (cfg.auto_reset) acts in launches that carry SOLO_STEP_PHYSICS: a
+ * query-only launch (TerminationFactory.is_terminated() outside step(), termination.py:38-50)
+ * never mutates the simulation.  A caller that evaluates `done` in a launch of its own AFTER the
+ * physics launch (a Python-side observation / reward in between) adds this bit to let that launch
+ * restore the robots whose `done` fires. */
+#define SOLO_STEP_AUTO_RESET 16u
 
 /* BulletClient(connection_mode) + setGravity + setPhysicsEngineParameter + loadURDF x2
  * (solo8_base_env.py:34-48).  Allocates device buffers, uploads the model, places every

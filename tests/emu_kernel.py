@@ -124,6 +124,7 @@ class EmuTorchEngine:
       EmuTorchEngine._settled[key] = self._e.snapshot.copy()
     self._e.snapshot[:] = EmuTorchEngine._settled[key]
     self._e.state[:] = self._e.snapshot
+    self._e.targets[:] = self._settle_targets(cfg)  # as Engine<T>::settle leaves them
     self.cfg, self.model = cfg, model
     self.num_envs, self.device = n, device
     self.tdtype = torch.float64  # emulator buffers are double; kernel arithmetic is cfg.dtype
@@ -163,15 +164,17 @@ class EmuTorchEngine:
   def set_targets(self, actions):
     self._e.targets[:] = actions.detach().cpu().numpy() * self.cfg.action_scale
 
+  @staticmethod
+  def _settle_targets(cfg):
+    return np.array(list(cfg.settle_targets))
+
   def reset(self, mask=None):
+    """solo_reset_kernel: snapshot, termination counters and the settle pose as motor targets."""
     e = self._e
-    if mask is None:
-      e.state[:] = e.snapshot
-      e.term_count[:] = 0
-    else:
-      m = mask.detach().cpu().numpy().astype(bool)
-      e.state[m] = e.snapshot[m]
-      e.term_count[m] = 0
+    m = slice(None) if mask is None else mask.detach().cpu().numpy().astype(bool)
+    e.state[m] = e.snapshot[m]
+    e.term_count[m] = 0
+    e.targets[m] = self._settle_targets(self.cfg)
 
   def settle(self):
     self._e.settle()

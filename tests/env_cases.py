@@ -178,3 +178,66 @@ def case_fused_matches_python_and_oracle(make_env, steps, tol, normalize_observa
     np.testing.assert_allclose(np_(r), orr, rtol=0, atol=tol)
     np.testing.assert_array_equal(np_(d).astype(bool), od)
   assert np_(d).all() and k == steps - 1
+
+
+class _PythonOnlyHeight(rewards.Reward):
+  """A custom reward without program(): forces the partially fused step path."""
+
+  def compute(self):
+    pos, _ = self.client.getBasePositionAndOrientation(1)
+    return pos[..., 2] * 3.0
+
+
+def case_partial_fused_auto_reset(make_env, dtype='float64'):
+  """A Python-only reward next to fused observations / terminations, with the in-kernel auto-reset:
+  the Python member must see the post-step state, never the restored one (the reference evaluates
+  get_obs, get_reward, is_terminated on the stepped state, solo8v2vanilla.py:96-100), and the reset
+  still happens.  Checked against an identical env without auto-reset."""
+  envs = []
+  for auto in (True, False):
+    cfg = Solo8VanillaConfig()
+    cfg.dtype, cfg._dtype_pinned, cfg.auto_reset = dtype, True, auto
+    env = make_env(config=cfg)
+    env.obs_factory.register_observation(solo_obs.TorsoIMU(env.robot))
+    env.reward_factory.register_reward(1, _PythonOnlyHeight())
+    env.termination_factory.register_termination(terms.TimeBasedTermination(2))
+    envs.append(env)
+  a, b = envs
+  a._ensure_program()
+  assert a._fused == dict(obs=True, reward=False, done=True)
+  home = np_(a.engine.snapshot)[:, :29].copy()
+  rng = np.random.default_rng(2)
+  for k in range(3):
+    act = torch.as_tensor(rng.uniform(-3, 3, (a.num_envs, 12)))
+    oa, ra, da, _ = a.step(act)
+    ob, rb, db, _ = b.step(act)
+    np.testing.assert_array_equal(np_(oa), np_(ob))
+    np.testing.assert_array_equal(np_(ra), np_(rb))
+    np.testing.assert_array_equal(np_(da), np_(db))
+    assert bool(np_(da).all()) == (k == 2)
+  assert np.abs(np_(ra) / 3.0 - home[:, 2]).max() > 1e-6      # the reward read the stepped state ...
+  np.testing.assert_array_equal(np_(a.engine.state)[:, :29], home)  # ... and the robots were restored
+  assert (np_(a.engine.term_count) == 0).all()
+  assert np.abs(np_(b.engine.state)[:, :29] - home).max() > 1e-6
+
+
+def case_reset_restores_motor_targets(make_env, dtype='float64'):
+  """reset() ends with the motors commanded to starting_joint_pos (the settle loop,
+  solo8v2vanilla.py:127-136): a stepSimulation() after step(); reset() equals one on a fresh env."""
+  cfg = Solo8VanillaConfig()
+  cfg.dtype, cfg._dtype_pinned = dtype, True
+  env = make_env(config=cfg)
+  fresh = make_env(config=cfg)
+  for e in (env, fresh):
+    e.reward_factory.register_reward(1, SimpleReward())
+    e.obs_factory.register_observation(CompliantObs(None))
+    e.termination_factory.register_termination(DummyTermination(0, False))
+  want = np.array([cfg.starting_joint_pos[n] for n in env.joint_ordering])
+  np.testing.assert_allclose(np_(fresh.engine.targets), np.tile(want, (env.num_envs, 1)))
+  env.step(np.full(12, 1.5))
+  assert np.abs(np_(env.engine.targets) - want).max() > 0.1
+  env.reset()
+  np.testing.assert_allclose(np_(env.engine.targets), np.tile(want, (env.num_envs, 1)))
+  env.client.stepSimulation()
+  fresh.client.stepSimulation()
+  np.testing.assert_array_equal(np_(env.engine.state)[:, :29], np_(fresh.engine.state)[:, :29])

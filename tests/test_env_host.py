@@ -20,8 +20,10 @@ class EmuSolo8VanillaEnv(Solo8VanillaEnv):
 def make_env(config=None, **kw):
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
   config = config or Solo8VanillaConfig()
-  config.dtype = 'float64'
-  config.num_envs = getattr(make_env, 'num_envs', 2)
+  if not getattr(config, '_dtype_pinned', False):
+    config.dtype = 'float64'
+  if not getattr(config, '_num_envs_pinned', False):
+    config.num_envs = getattr(make_env, 'num_envs', 2)
   return EmuSolo8VanillaEnv(config=config, **kw)
 
 
@@ -61,6 +63,14 @@ def test_disjoint_environments():
 def test_fused_matches_python_and_oracle(normalize):
   cases.case_fused_matches_python_and_oracle(make_env, steps=12, tol=1e-9,
                                              normalize_observations=normalize)
+
+
+def test_partial_fused_auto_reset():
+  cases.case_partial_fused_auto_reset(make_env)
+
+
+def test_reset_restores_motor_targets():
+  cases.case_reset_restores_motor_targets(make_env)
 
 
 def test_gui_and_realtime_flags():

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def torch():
   import torch
   if not torch.cuda.is_available():
-    pytest.skip('needs an MI355X')
+    pytest.fail('GPU tests need a visible MI355X')
   return torch
 
 

@@ -16,7 +16,8 @@ def make_env(config=None, **kw):
   config = config or Solo8VanillaConfig()
   if not getattr(config, '_dtype_pinned', False):
     config.dtype = getattr(make_env, 'dtype', 'float64')
-  config.num_envs = getattr(make_env, 'num_envs', 64)
+  if not getattr(config, '_num_envs_pinned', False):
+    config.num_envs = getattr(make_env, 'num_envs', 64)
   return Solo8VanillaEnv(config=config, **kw)
 
 
@@ -77,6 +78,16 @@ def test_fused_matches_python_f32():
     np.testing.assert_allclose(cases.np_(o), cases.np_(py_o), rtol=0, atol=2e-5)
     np.testing.assert_allclose(cases.np_(r), cases.np_(py_r), rtol=0, atol=2e-5)
     assert not cases.np_(d).any()
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_partial_fused_auto_reset(dtype):
+  cases.case_partial_fused_auto_reset(make_env, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_reset_restores_motor_targets(dtype):
+  cases.case_reset_restores_motor_targets(make_env, dtype)
 
 
 def test_auto_reset_and_stats():
