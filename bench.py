@@ -2,42 +2,52 @@
 """bench.py — env-steps/s of the batched Solo8 hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  A "step" is one pass of the whole hot path over one batch of 4096 robots
-per GPU (BASELINE.json configs[1]): fresh random actions -> action
-de-normalisation -> POSITION_CONTROL motors -> articulated forward dynamics -> ground contact PGS
--> integration -> TorsoIMU+MotorEncoder observations (21 floats) -> the examples' stand reward
--> TimeBasedTermination(1000) with auto-reset, all in ONE fused kernel through the C-ABI
-(solo_engine_rollout: open-loop, --steps-per-launch consecutive steps of each robot per launch,
-the batch cut into --rollout-streams independent launch chains).  The action pool is generated on the device before the timed
-region.  The env batch is sharded over ranks with no data-path collective; the only
-communication is one RCCL all-reduce of the 8-double episodic-return statistics vector at the
-end of the interval (inside the timed region).
+One process per GPU.  With N > 1 and no torch.distributed environment the script launches its own N
+ranks (child processes, started BEFORE anything touches the GPU; the parent only waits and forwards
+rank 0's JSON line); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+it uses the ranks it is given.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+A "step" is one pass of the whole hot path over one batch of 4096 robots per GPU (BASELINE.json
+configs[1]): fresh random actions -> action de-normalisation -> POSITION_CONTROL
+motors -> articulated forward dynamics -> ground contact PGS -> integration -> TorsoIMU +
+MotorEncoder observations (21 floats) -> the examples' stand reward -> TimeBasedTermination(1000)
+with auto-reset, through the C-ABI (solo_engine_rollout_record: every step's obs / reward / done is
+written to HBM; --steps-per-launch consecutive steps of each robot per kernel launch).  Actions are
+generated on the device before the timed region.  The env batch is sharded over ranks with no
+data-path collective; the only communication is one RCCL all-reduce of the 8-double
+episodic-return statistics vector at the end of the interval (inside the timed region).
+
+Timing: after W warm-up steps, EXACTLY K steps are timed between barrier + device synchronisation
+on both sides, max over ranks.  A K-step region can be as short as half a millisecond (the driver
+uses K = 20), so it is repeated (fresh actions, the simulation simply continues) until 0.5 s or 30
+repeats have accumulated; `value` / `ms_per_step` are the MEDIAN repeat, min / max / count are
+reported next to it.  Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline`; the same run
+also measures the reference-precision figure (`value_f64`) and the reference-granularity figure
+(`value_closed_loop`: one solo_engine_step launch per env step, as Solo8VanillaEnv.step issues it).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 BYTES_PER_ENV_STEP = {'float32': 385, 'float64': 765}  # SURVEY.md §8d algorithmic bytes
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md chip table
 NUM_SIMDS = 1024                                        # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
-VALU_ISSUE_CYCLES = 4                                   # one wave64 VALU instruction occupies its SIMD 4 cycles
-SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICROARCH.md chip table (matches the
-                                                        # in-kernel s_memtime rate measured with tools/gpu_stamps.py)
+VALU_CYCLES_SHARED = 2                                  # wave64 VALU instruction on a SIMD-32 when >= 2 waves share
+VALU_CYCLES_ALONE = 4                                   # the SIMD; 4 for one wave alone (MI355X_MICROARCH.md constants)
+SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICROARCH.md chip table
+METRIC = 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X'
 
 
 def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1):
-  import numpy as np
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
   cfg = Solo8VanillaConfig()
@@ -65,10 +75,11 @@ def host_cores():
 def cpu_baseline(num_envs, seconds_target=12.0):
   """The CPU oracle (double-precision scalar C restatement + numpy reductions) on the host
   cores, bounded sample of the same workload.  kind = "port": PyBullet itself is not
-  installable in this pipeline."""
-  import subprocess
+  installable in this pipeline.  The ONLY place bench.py touches tests/ or
+  oracle/ - as the measured CPU baseline, never inside the GPU path."""
   import tempfile
   import numpy as np
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
   from helpers import make_abi
   from oracle import solo_oracle as so
   import env_cases
@@ -109,29 +120,56 @@ def cpu_baseline(num_envs, seconds_target=12.0):
                     '%d threads) + numpy obs/reward, %.1f s' % (num_envs, steps, cores, el)}
 
 
-def pmc_profile(dtype, key):
-  """A per-launch / per-env-step figure from the committed rocprofv3 --pmc run (profiles/), or None."""
-  path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+def pmc_profile(dtype):
+  """Per-env-step figures from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
+  written by tools/make_pmc_traffic.py), or {}."""
   try:
-    with open(path) as f:
-      return json.load(f).get(dtype, {}).get(key)
+    with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+      return json.load(f).get(dtype, {})
   except Exception:  # noqa: BLE001
-    return None
+    return {}
 
 
-def secondary_bound(dtype, env_steps_per_launch, chains, kern_ms, clock_hz):
-  """The bound that actually binds (the path is VALU-issue / latency bound, not
-  HBM bound): share of the chip's VALU issue slots the launches keep busy, from the VALU
-  instruction count per env-step measured with rocprofv3 --pmc SQ_INSTS_VALU (profiles/)."""
-  valu = pmc_profile(dtype, 'valu_insts_per_env_step')
-  if not valu or not clock_hz:
-    return 'VALU-issue / latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype'
-  simd_cycles = NUM_SIMDS * kern_ms * 1e-3 * clock_hz
-  util = chains * valu * env_steps_per_launch * VALU_ISSUE_CYCLES / simd_cycles
-  return ('VALU-issue / latency bound by construction (SURVEY.md §8d), not HBM bound: %.0f VALU instructions per '
-          'env-step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/pmc_traffic.json) x %d cycles x %d env-steps x %d '
-          'concurrent launch chains = %.2f of the %d SIMDs\' issue cycles over the measured launch duration at %.2f GHz'
-          % (valu, VALU_ISSUE_CYCLES, env_steps_per_launch, chains, util, NUM_SIMDS, clock_hz / 1e9))
+def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
+  """The bound that actually binds (the path is dependent-issue-latency bound, not
+  HBM bound): share of the chip's VALU issue capacity the launches use, from the VALU instruction
+  count per env-step measured with rocprofv3 --pmc SQ_INSTS_VALU (profiles/)."""
+  valu = pmc.get('valu_insts_per_env_step')
+  if not valu:
+    return 'dependent-issue-latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype'
+  cyc = VALU_CYCLES_SHARED if waves_per_simd >= 2 else VALU_CYCLES_ALONE
+  simd_cycles = NUM_SIMDS * kern_ms * 1e-3 * SHADER_CLOCK_HZ
+  util = chains * valu * env_steps_per_launch * cyc / simd_cycles
+  return ('latency bound, not HBM bound: %.0f VALU instructions per env-step (rocprofv3 --pmc SQ_INSTS_VALU, '
+          'profiles/pmc_traffic.json) x %d cycles (wave64 on a SIMD-32 shared by %.0f waves, MI355X_MICROARCH.md) x %d '
+          'env-steps x %d concurrent launch chains = %.2f of the %d SIMDs\' VALU issue capacity over the measured launch '
+          'duration at %.1f GHz; the rest is dependent-instruction latency of one wave per robot (a Gauss-Seidel row '
+          'update is a ~20-instruction serial chain) and the launch waiting for its slowest robot (profiles/README.md)'
+          % (valu, cyc, waves_per_simd, env_steps_per_launch, chains, util, NUM_SIMDS, SHADER_CLOCK_HZ / 1e9))
+
+
+def free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks):
+  """N > 1 without a torch.distributed environment: start one child per GPU (this process has not
+  touched the GPU and never will), forward rank 0's stdout, exit with the worst child status."""
+  port = os.environ.get('MASTER_PORT') or str(free_port())
+  procs = []
+  for r in range(n_ranks):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               SOLO_BENCH_CHILD='1')
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                  stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+  out, _ = procs[0].communicate()
+  rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+  sys.stdout.write(out.decode())
+  sys.stdout.flush()
+  raise SystemExit(max(abs(rc) for rc in rcs))
 
 
 def main():
@@ -142,119 +180,171 @@ def main():
   ap.add_argument('--envs-per-gpu', type=int, default=4096)
   ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-extra', action='store_true', help='skip the value_f64 / value_closed_loop legs')
   ap.add_argument('--steps-per-launch', type=int, default=250,
                   help='env steps of every robot fused into one kernel launch by the open-loop rollout '
                        '(1 = one launch per step, the closed-loop granularity)')
   ap.add_argument('--rollout-streams', type=int, default=2,
-                  help='batch slices advancing as independent launch chains on separate HIP streams')
-  ap.add_argument('--api-rate', action='store_true',
-                  help='also time Solo8VanillaEnv.step() in a python loop (one launch per step)')
+                  help='batch slices advancing as independent launch chains on separate HIP streams '
+                       '(only used when a rollout needs more than one launch per slice)')
+  ap.add_argument('--min-seconds', type=float, default=0.5, help='repeat the K-step timed region until this much time ...')
+  ap.add_argument('--max-repeats', type=int, default=30, help='... or this many repeats have accumulated')
   args = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if args.gpus > 1 and world == 1 and 'RANK' not in os.environ:
+    launch_ranks(args.gpus)  # does not return
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
   import torch
   import torch.distributed as dist
   from gym_solo_amd import abi
   from gym_solo_amd.distributed import all_reduce_stats, rank_seed, summarize
 
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  if world != args.gpus:
-    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
   torch.cuda.set_device(local_rank)
   # under torch.distributed.run the collective path is exercised even with one rank
   distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or os.environ.get('SOLO_BENCH_FORCE_DIST') == '1'
+  log = (lambda *a: print('[bench rank %d]' % rank, *a, file=sys.stderr, flush=True)) if distributed else (lambda *a: None)
   if distributed:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29531')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local_rank))
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    log("init_process_group('nccl') ok: world_size %d, backend %s, device cuda:%d" % (world, dist.get_backend(), local_rank))
 
+  dev = 'cuda:%d' % local_rank
   n, k, w = args.envs_per_gpu, args.steps, args.warmup
-  tdtype = torch.float32 if args.dtype == 'float32' else torch.float64
-  # (a run shorter than one fused launch fuses what it has: K steps per launch)
-  spl, streams = max(1, min(args.steps_per_launch, k)), max(1, args.rollout_streams)
-  env = build_env(n, local_rank, args.dtype, steps_per_launch=spl, rollout_streams=streams)
-  eng = env.engine
-  gen = torch.Generator(device='cuda:%d' % local_rank).manual_seed(rank_seed(1234, rank))
   two_pi = 2 * 3.141592653589793
-
-  def action_pool(steps):
-    a = torch.rand(steps, n, abi.NUM_JOINTS, device='cuda:%d' % local_rank, dtype=tdtype, generator=gen)
-    return (a * 2 - 1) * two_pi
 
   def barrier():
     if distributed:
       dist.barrier()
     torch.cuda.synchronize(local_rank)
 
-  if w > 0:
-    eng.rollout(action_pool(w), abi.STEP_ALL)
-  acts = action_pool(k)
-  out = eng.rollout_buffers(k)  # every step's obs / reward / done is written out (to HBM)
-  stats_before = eng.stats.clone()
-  barrier()
-  t0 = time.perf_counter()
-  eng.rollout(acts, abi.STEP_ALL, out=out)
-  # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI
-  stats = all_reduce_stats(eng.stats - stats_before)
-  barrier()  # (all_reduce_stats is a no-op without an initialised process group)
-  elapsed = time.perf_counter() - t0
-  t = torch.tensor([elapsed], dtype=torch.float64, device='cuda:%d' % local_rank)
-  if distributed:
+  def max_over_ranks(x):
+    if not distributed:
+      return x
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-  elapsed = float(t.item())
+    return float(t.item())
 
-  # dominant kernel: HIP events on the stream its launches are issued on, same rollout path and
-  # workload (fresh actions every step); one launch = (n / streams) robots x spl steps
+  def timed(dtype, k, closed_loop, min_seconds, max_repeats):
+    """Repeats of the K-step timed region on a fresh engine; returns per-repeat seconds (max over
+    ranks), the summed episodic statistics of the timed repeats and the engine."""
+    tdtype = torch.float32 if dtype == 'float32' else torch.float64
+    # (a run shorter than one fused launch fuses what it has: K steps per launch, and then one launch
+    # chain is all there is to overlap: no stream slices)
+    spl = 1 if closed_loop else max(1, min(args.steps_per_launch, k))
+    streams = max(1, args.rollout_streams) if (k > spl and not closed_loop) else 1
+    env = build_env(n, local_rank, dtype, steps_per_launch=spl, rollout_streams=streams)
+    eng = env.engine
+    gen = torch.Generator(device=dev).manual_seed(rank_seed(1234, rank))
+
+    def action_pool(steps):
+      a = torch.rand(steps, n, abi.NUM_JOINTS, device=dev, dtype=tdtype, generator=gen)
+      return (a * 2 - 1) * two_pi
+
+    def run(acts, out):
+      if closed_loop:  # one solo_engine_step launch per env step, outputs in the engine's view
+        for i in range(acts.shape[0]):
+          eng.step(acts[i], abi.STEP_ALL)
+      else:
+        eng.rollout(acts, abi.STEP_ALL, out=out)
+
+    out = None if closed_loop else eng.rollout_buffers(k)  # every step's obs / reward / done goes to HBM
+    if w > 0:
+      run(action_pool(w), None if closed_loop else eng.rollout_buffers(w))
+    times, total = [], None
+    while True:
+      acts = action_pool(k)
+      stats_before = eng.stats_shards.clone()
+      barrier()
+      t0 = time.perf_counter()
+      run(acts, out)
+      # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI (SURVEY.md §8e)
+      stats = all_reduce_stats((eng.stats_shards - stats_before).sum(dim=0))
+      barrier()  # (all_reduce_stats is a no-op without an initialised process group)
+      times.append(max_over_ranks(time.perf_counter() - t0))
+      total = stats if total is None else total + stats
+      if sum(times) >= min_seconds or len(times) >= max_repeats:
+        break
+    return times, total, eng, env, action_pool, spl, streams
+
+  times, stats, eng, env, action_pool, spl, streams = timed(args.dtype, k, False, args.min_seconds, args.max_repeats)
+  log('timed region done: %d repeats, stats all-reduce ok (episodes %.0f)' % (len(times), float(stats[2])))
+  elapsed = statistics.median(times)
+
+  # dominant kernel: HIP events on the streams its launches are issued on (the slowest slice's chain),
+  # same rollout path and workload (fresh actions every step); one launch = (n / slices) robots x spl steps
   reps = max(1, min(k, 1000) // spl)
-  kern_ms = eng.time_step(acts[:reps * spl], abi.STEP_ALL)
-  api_rate = None
-  if args.api_rate:  # API-level rate through Solo8VanillaEnv.step (python loop, zero-copy outputs)
-    api_steps = min(k, 200)
-    torch.cuda.synchronize(local_rank)
-    ta = time.perf_counter()
-    for i in range(api_steps):
-      env.step(acts[i])
-    torch.cuda.synchronize(local_rank)
-    api_rate = n * api_steps / (time.perf_counter() - ta)
+  kern_ms = statistics.median(eng.time_step(action_pool(reps * spl), abi.STEP_ALL) for _ in range(5 if k <= 100 else 1))
+  kernel_name = eng.kernel_name
+  env._close()
 
-  st = stats.cpu().numpy()
+  extra = {}
+  if not args.no_extra:
+    ke = min(k, 500)  # (bounded intervals: f64 is ~3x, single-step launches ~4x slower per step)
+    if args.dtype == 'float32':
+      t64, _, _, e64, _, _, _ = timed('float64', ke, False, 0.3, 10)
+      extra['value_f64'] = world * n * ke / statistics.median(t64)
+      extra['value_f64_note'] = ('same workload and rollout path in float64 (the reference\'s precision, SURVEY.md §8; the '
+                                 'parity instantiation of the kernel), median of %d repeats of %d steps' % (len(t64), ke))
+      e64._close()
+    tcl, _, _, ecl, _, _, _ = timed(args.dtype, ke, True, 0.3, 10)
+    extra['value_closed_loop'] = world * n * ke / statistics.median(tcl)
+    extra['value_closed_loop_note'] = ('one solo_engine_step launch per env step (outputs evaluated in that launch), the '
+                                       'granularity of Solo8VanillaEnv.step (solo8v2vanilla.py:72-102), actions pre-generated, '
+                                       'no host synchronisation between steps; median of %d repeats of %d steps' % (len(tcl), ke))
+    ecl._close()
+
   if rank == 0:
     value = world * n * k / elapsed
-    robots_per_launch = n // streams if (streams > 1 and n >= 2 * streams and k > 1) else n
+    slices = streams if (streams > 1 and n >= 2 * streams) else 1
+    robots_per_launch = n // slices
     env_steps_per_launch = robots_per_launch * spl
     bytes_per_launch = BYTES_PER_ENV_STEP[args.dtype] * env_steps_per_launch
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    pmc = pmc_profile(args.dtype)
+    traffic = None
+    if pmc.get('hbm_bytes_per_env_step'):
+      traffic = pmc['hbm_bytes_per_env_step'] * env_steps_per_launch
     line = {
-      'metric': 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X', 'value': value, 'unit': 'env-steps/s',
+      'metric': METRIC, 'value': value, 'unit': 'env-steps/s',
       'n_gpus': world, 'steps': k, 'warmup': w, 'ms_per_step': elapsed / k * 1e3,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32' if args.dtype == 'float32' else 'f64', 'data': 'synthetic',
       'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
                              'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
                              'TimeBasedTermination(1000)+auto-reset, dt=1e-3, 50 PGS iterations' % n,
-                 'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': streams, 'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
+                 'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': slices,
+                 'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
+      'timing': {'repeats': len(times), 'statistic': 'median', 'min_ms_per_step': min(times) / k * 1e3,
+                 'max_ms_per_step': max(times) / k * 1e3, 'value_best_repeat': world * n * k / min(times),
+                 'value_worst_repeat': world * n * k / max(times),
+                 'note': 'each repeat = exactly K steps between barrier + device sync on both sides (max over ranks), '
+                         'fresh actions, the simulation continues from repeat to repeat'},
       'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                   'frac': achieved / HBM_PEAK_GBPS, 'traffic': pmc_profile(args.dtype, 'hbm_bytes_per_launch'),
-                   'kernel': eng.kernel_name, 'kernel_ms': kern_ms,
+                   'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                   'traffic_note': pmc.get('traffic_note'),
+                   'kernel': kernel_name, 'kernel_ms': kern_ms,
+                   'kernel_ms_note': 'HIP events around the launch chain of every slice, on the stream it is launched on; '
+                                     'the slowest slice; the step kernel alone (the output kernels are separate, short launches)',
                    'algorithmic_bytes_per_launch': bytes_per_launch, 'env_steps_per_launch': env_steps_per_launch,
-                   'concurrent_launch_chains': n // robots_per_launch,
-                   'achieved_all_chains': achieved * (n // robots_per_launch),
-                   'note': secondary_bound(args.dtype, env_steps_per_launch, n // robots_per_launch, kern_ms,
-                                           SHADER_CLOCK_HZ)},
-      'episodes': summarize(st),
-      'env_api_env_steps_per_s_rank0': api_rate,
+                   'concurrent_launch_chains': slices, 'achieved_all_chains': achieved * slices,
+                   'note': secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, n / NUM_SIMDS)},
+      'episodes': summarize(stats.cpu().numpy()),
     }
-    if world == 1 and not args.no_cpu_baseline:
-      line['cpu_baseline'] = cpu_baseline(n)
-    else:
-      line['cpu_baseline'] = None
+    line.update(extra)
+    line['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(n)
     print(json.dumps(line), flush=True)
   if distributed:
     dist.barrier()
+    log('final barrier ok')
     dist.destroy_process_group()
 
 

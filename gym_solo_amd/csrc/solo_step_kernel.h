@@ -38,7 +38,14 @@
 
 // In-kernel phase stamps exist only in the diagnostic build (make -C gym_solo_amd/csrc stamps);
 // in the product build the macro expands to nothing.
-#ifdef SOLO_STAMPS
+#if defined(SOLO_STAMPS) && defined(SOLO_STAMPS_LIGHT)
+// light variant (make stamps_light): only the launch's first and last stamp, nothing per step
+#define SOLO_STAMP(B, i)                                                                          \
+  do {                                                                                            \
+    if (((i) == 0 || (i) == 14) && solo::lane_id() == 0)                                          \
+      (B).stamps[(size_t)(solo::block_id() + (B).env_base) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#elif defined(SOLO_STAMPS)
 #define SOLO_STAMP(B, i)                                                                          \
   do {                                                                                            \
     if (solo::lane_id() == 0) {                                                                   \
@@ -428,6 +435,37 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   wave_sync();
 
   SOLO_STAMP(B, 7);
+  // ---- the scaled Delassus matrix, column by column, RESIDENT IN REGISTERS -------------------
+  // Column r, as lane s sees it:  col_r[s] = -(ghat_s . ghat_r + [same leg] hhat_s . hhat_r) / A_ss
+  // (0 on the row's own lane), built once per step for the rows that can move (the 8 motor rows
+  // and the three rows of every touching sphere; all branches wave-uniform, all register indices
+  // static, the LDS broadcasts of many columns in flight at once).  The Gauss-Seidel loop below
+  // then fetches the column of the row it updates with ONE register-indexed move
+  // (s_set_gpr_idx_on + v_mov) instead of an LDS round trip and a dot product on its serial chain.
+  // (f64: 64 doubles per lane do not fit next to the rest of the step in 256 VGPRs - the parity
+  // instantiation evaluates the same expression from LDS when the row is updated.)
+  const T nid = -inv_d;
+  ColumnBank<T> A;
+  A.init(gh, hh, nid, lane, &s_rowvec[0][0], &s_hext[0][2 * leg]);  // (+ 8 r: row r's joint-space part if r is on this lane's leg, else 0)
+  if (ColumnBank<T>::kResident) {
+#pragma unroll
+    for (int l2 = 0; l2 < 4; ++l2) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) A.build(16 * l2 + kk);
+    }
+#pragma unroll
+    for (int l2 = 0; l2 < 4; ++l2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r0 = 16 * l2 + 2 + 3 * j;
+        if ((touching >> r0) & 1ull) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) A.build(r0 + q);
+        }
+      }
+    }
+  }
+  SOLO_STAMP(B, 8);
   // ---- projected Gauss-Seidel, sparse in the rows that still move ---------------------------
   // Per-lane solver state: candidate v, impulse lam, bounds lo/hi (friction bounds follow their
   // contact's normal impulse), dl = clamp(v) - lam.  `pend` is the set of rows with |dl| above the
@@ -436,21 +474,16 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   // pending rows in solver order (motor rows, then contacts by sphere) with a scalar
   // find-first-set; only those rows cost anything, and after each change the set is re-evaluated,
   // so the decisions are the ones a dense sweep over every row would take.
-  const T nid = -inv_d;
   const T imp = P->motor_impulse;
   T lo = T(0), hi = T(0);
   if (is_motor) { lo = -imp; hi = imp; }
   else if (live && type == ROW_NORMAL) hi = R::big();
   T lamv = T(0);
   T v = live ? w * nid : T(0);  // lam = 0
-  SOLO_STAMP(B, 8);
   const T tol_rel = T(wave_uniform(P->ulp_tol)) * R::half_ulp();
   const int iters = wave_uniform(P->iterations);  // scalar trip count
   constexpr unsigned long long kMotorLanes = 0x0003000300030003ull;   // k = 0, 1 of each leg
   constexpr unsigned long long kNormalLanes = 0x0924092409240924ull;  // k = 2, 5, 8, 11
-  RowDot<T> own;
-  own.set(gh, hh);
-  const T* my_hext = &s_hext[0][2 * leg];  // + 8 r: row r's joint-space part if r is on this lane's leg, else 0
   T cand = R::clamp(v, lo, hi);
   T dl = cand - lamv;
   unsigned long long pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
@@ -460,33 +493,35 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   int it = 0;
 #pragma unroll 1
   for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
-#pragma unroll 1
+    // the register banks of the matrix are walked one after the other (static bank per loop): in
+    // lane order that is still "motor rows, then contact rows, each ascending"
+#pragma unroll
     for (int phase = 0; phase < 2; ++phase) {
-      unsigned long long window = phase == 0 ? kMotorLanes : ~kMotorLanes;
+#pragma unroll
+      for (int bank = 0; bank < ColumnBank<T>::kBanks; ++bank) {
+        unsigned long long window = (phase == 0 ? kMotorLanes : ~kMotorLanes) & ColumnBank<T>::bank_lanes(bank);
 #pragma unroll 1
-      while ((pend & window) != 0ull) {
-        const int r = __builtin_ctzll(pend & window);  // wave-uniform: the row to update
-        window &= ~((2ull << r) - 1ull);               // the cursor moves past it
-        // column r of the scaled Delassus matrix, from the whitened row vectors in LDS:
-        // -(ghat_s . ghat_r + [same leg] hhat_s . hhat_r) / A_ss, and 0 for the row itself
-        const T dotp = own.dot(s_rowvec[r], my_hext + 8 * r);
-        const T delta = wave_readlane(dl, r);
-        const T sd = (lane == r) ? T(0) : nid * delta;
-        v = R::fma(dotp, sd, v);
-        lamv = (lane == r) ? cand : lamv;
-        if ((kNormalLanes >> r) & 1ull) {
-          // a normal row moved: its two friction rows are limited by mu * (fresh normal impulse)
-          const T lim = mu * wave_readlane(cand, r);
-          const bool mine = (unsigned)(lane - r - 1) < 2u;
-          lo = mine ? T(0) - lim : lo;  // (0 - 0 = +0)
-          hi = mine ? lim : hi;
-        }
-        cand = R::clamp(v, lo, hi);
-        dl = cand - lamv;
-        pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
+        while ((pend & window) != 0ull) {
+          const int r = __builtin_ctzll(pend & window);  // wave-uniform: the row to update
+          window &= ~((2ull << r) - 1ull);               // the cursor moves past it
+          const T col = A.get(bank, r);                  // column r of the scaled matrix (0 for the row itself)
+          const T delta = wave_readlane(dl, r);
+          v = R::fma(col, delta, v);
+          lamv = (lane == r) ? cand : lamv;
+          if ((kNormalLanes >> r) & 1ull) {
+            // a normal row moved: its two friction rows are limited by mu * (fresh normal impulse)
+            const T lim = mu * wave_readlane(cand, r);
+            const bool mine = (unsigned)(lane - r - 1) < 2u;
+            lo = mine ? T(0) - lim : lo;  // (0 - 0 = +0)
+            hi = mine ? lim : hi;
+          }
+          cand = R::clamp(v, lo, hi);
+          dl = cand - lamv;
+          pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
 #ifdef SOLO_STAMPS
-        ++n_changed;
+          ++n_changed;
 #endif
+        }
       }
     }
     SOLO_PGS_SWEEP_HOOK(it, pend, lamv, v);

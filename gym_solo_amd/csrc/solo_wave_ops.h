@@ -126,6 +126,53 @@ template <> struct RowDot<float> {
   }
 };
 
+// The scaled Delassus matrix of a robot.  Column r as lane s sees it:
+//   col_r[s] = -(ghat_s . ghat_r + [same leg] hhat_s . hhat_r) / A_ss,  0 on the row's own lane.
+// f32: one entry per (lane, column) RESIDENT IN REGISTERS - 64 column slots per lane held in two
+// vector-typed register tuples (the widest the ISA has: 1024 bits), so that a wave-uniform column
+// index turns into one register-indexed move (s_set_gpr_idx_on / v_mov_b32 / s_set_gpr_idx_off);
+// a plain array would be demoted to scratch memory.  build() is only ever called with indices that
+// are constants after unrolling; get() with a constant bank and a uniform r inside that bank.
+// f64 (the parity instantiation): 64 doubles per lane do not fit; get() evaluates the same
+// expression from the whitened row vectors in LDS.
+typedef float solo_f32x32 __attribute__((ext_vector_type(32)));
+template <typename T> struct ColumnBank;
+template <> struct ColumnBank<float> {
+  static constexpr bool kResident = true;
+  static constexpr int kBanks = 2;
+  static __device__ __forceinline__ constexpr unsigned long long bank_lanes(int b) { return 0xffffffffull << (32 * b); }
+  RowDot<float> own;
+  float nid;
+  int lane;
+  const float* rowvec;
+  const float* hext;
+  solo_f32x32 a0, a1;
+  __device__ __forceinline__ void init(const float* gh, const float* hh, float nid_, int lane_, const float* rowvec_, const float* hext_) {
+    own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; hext = hext_;
+  }
+  // (the own-lane zero is a select on the SCALE, not on the product: selecting the product makes the
+  // compiler wrap every column's LDS reads in a divergent branch, one exposed round trip per column)
+  __device__ __forceinline__ float column(int r) const { const float m = (lane == r) ? 0.0f : nid; return m * own.dot(rowvec + 8 * r, hext + 8 * r); }
+  __device__ __forceinline__ void build(int r) { const float x = column(r); if (r < 32) a0[r] = x; else a1[r - 32] = x; }
+  __device__ __forceinline__ float get(int bank, int r) const { return bank == 0 ? a0[r & 31] : a1[r & 31]; }
+};
+template <> struct ColumnBank<double> {
+  static constexpr bool kResident = false;
+  static constexpr int kBanks = 1;
+  static __device__ __forceinline__ constexpr unsigned long long bank_lanes(int) { return ~0ull; }
+  RowDot<double> own;
+  double nid;
+  int lane;
+  const double* rowvec;
+  const double* hext;
+  __device__ __forceinline__ void init(const double* gh, const double* hh, double nid_, int lane_, const double* rowvec_, const double* hext_) {
+    own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; hext = hext_;
+  }
+  __device__ __forceinline__ double column(int r) const { const double m = (lane == r) ? 0.0 : nid; return m * own.dot(rowvec + 8 * r, hext + 8 * r); }
+  __device__ __forceinline__ void build(int) {}
+  __device__ __forceinline__ double get(int, int r) const { return column(r); }
+};
+
 // issue priority of this wave in its SIMD (0..3) by thresholds on a wave-uniform measure
 __device__ __forceinline__ void wave_set_priority(int m, int t1, int t2, int t3) {
   if (m > t3) __builtin_amdgcn_s_setprio(3);

@@ -2,6 +2,28 @@
 // wave emulator.  Built by tests/emu/Makefile into libsolo_emu.so and driven from pytest.
 #include "wave_emu.h"
 
+#ifdef SOLO_EMU_TRACE
+// DIAGNOSTIC variant (make trace): records every lane's impulse / candidate after each Gauss-Seidel
+// sweep of the LAST emulated robot-step, for tools/analyse_slow_steps.py
+static double g_trace_lam[64][64], g_trace_v[64][64];
+static unsigned long long g_trace_pend[64];
+static int g_trace_sweeps = 0;
+#define SOLO_PGS_SWEEP_HOOK(it, pend, lam, v)                                       \
+  do {                                                                              \
+    if ((it) < 64) {                                                                \
+      g_trace_lam[(it)][solo::lane_id()] = (double)(lam);                           \
+      g_trace_v[(it)][solo::lane_id()] = (double)(v);                               \
+      g_trace_pend[(it)] = (pend);                                                  \
+      g_trace_sweeps = (it) + 1;                                                    \
+    }                                                                               \
+  } while (0)
+extern "C" int solo_emu_trace(double* lam, double* v, unsigned long long* pend) {
+  for (int i = 0; i < 64 * 64; ++i) { lam[i] = (&g_trace_lam[0][0])[i]; v[i] = (&g_trace_v[0][0])[i]; }
+  for (int i = 0; i < 64; ++i) pend[i] = g_trace_pend[i];
+  return g_trace_sweeps;
+}
+#endif
+
 #include "../../gym_solo_amd/csrc/solo_step_kernel.h"
 
 #include <string>

@@ -136,6 +136,26 @@ template <typename T> struct RowDot {
   }
 };
 
+// the register-resident matrix of the GPU build (solo_wave_ops.h ColumnBank<float>) as a plain array
+template <typename T> struct ColumnBank {
+  static constexpr bool kResident = true;
+  static constexpr int kBanks = 1;
+  static constexpr unsigned long long bank_lanes(int) { return ~0ull; }
+  RowDot<T> own;
+  T nid;
+  int lane;
+  const T* rowvec;
+  const T* hext;
+  T a[64];
+  void init(const T* gh, const T* hh, T nid_, int lane_, const T* rowvec_, const T* hext_) {
+    own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; hext = hext_;
+    for (int r = 0; r < 64; ++r) a[r] = std::nan("");  // a column that was never built must never be used
+  }
+  T column(int r) const { const T m = (lane == r) ? T(0) : nid; return m * own.dot(rowvec + 8 * r, hext + 8 * r); }
+  void build(int r) { a[r] = column(r); }
+  T get(int, int r) const { return a[r]; }
+};
+
 inline float wave_readlane(float x, int lane) {
   uint32_t b; std::memcpy(&b, &x, 4);
   b = (uint32_t)WaveEmu::get().exchange(b, lane);
