@@ -198,9 +198,9 @@ struct Engine final : EngineBase {
       return SOLO_ERR_NO_PROGRAM;
     }
     // mirrors the ValueErrors of obs.py:138-139, rewards.py:115-116, termination.py:43-44
-    if ((flags & SOLO_STEP_OBS) && hparams.num_obs == 0) { err = "Need to register at least one observation instance"; return SOLO_ERR_NO_PROGRAM; }
-    if ((flags & SOLO_STEP_REWARD) && hparams.num_reward_ops == 0) { err = "Need to register at least one reward instance"; return SOLO_ERR_NO_PROGRAM; }
-    if ((flags & SOLO_STEP_DONE) && hparams.num_terms == 0) { err = "Need to register at least one termination instance"; return SOLO_ERR_NO_PROGRAM; }
+    if ((flags & SOLO_STEP_OBS) && hparams.c.num_obs == 0) { err = "Need to register at least one observation instance"; return SOLO_ERR_NO_PROGRAM; }
+    if ((flags & SOLO_STEP_REWARD) && hparams.c.num_reward_ops == 0) { err = "Need to register at least one reward instance"; return SOLO_ERR_NO_PROGRAM; }
+    if ((flags & SOLO_STEP_DONE) && hparams.c.num_terms == 0) { err = "Need to register at least one termination instance"; return SOLO_ERR_NO_PROGRAM; }
     return SOLO_OK;
   }
 
@@ -381,7 +381,7 @@ struct Engine final : EngineBase {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipDeviceSynchronize());
     if (terrain) { (void)hipFree(terrain); terrain = nullptr; }
-    hparams.terr_nx = hparams.terr_ny = 0;
+    hparams.c.terr_nx = hparams.c.terr_ny = 0;
     if (t) {
       if (t->nx < 2 || t->ny < 2 || !(t->cell > 0) || !t->heights || (long long)t->nx * t->ny > (1ll << 26)) {
         err = "terrain needs nx, ny >= 2, cell > 0 and a heights array";
@@ -392,9 +392,9 @@ struct Engine final : EngineBase {
       for (size_t i = 0; i < cnt; ++i) h[i] = (T)t->heights[i];
       HIP_TRY(hipMalloc((void**)&terrain, cnt * sizeof(T)));
       HIP_TRY(hipMemcpy(terrain, h.data(), cnt * sizeof(T), hipMemcpyHostToDevice));
-      hparams.terr_nx = t->nx; hparams.terr_ny = t->ny;
-      hparams.terr_inv_cell = (T)(1.0 / t->cell);
-      hparams.terr_ox = (T)t->origin[0]; hparams.terr_oy = (T)t->origin[1];
+      hparams.c.terr_nx = t->nx; hparams.c.terr_ny = t->ny;
+      hparams.c.terr_inv_cell = (T)(1.0 / t->cell);
+      hparams.c.terr_ox = (T)t->origin[0]; hparams.c.terr_oy = (T)t->origin[1];
     }
     HIP_TRY(hipMemcpy(dparams, &hparams, sizeof(hparams), hipMemcpyHostToDevice));
     return settle(s);

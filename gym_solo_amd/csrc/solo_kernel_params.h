@@ -60,29 +60,37 @@ struct RewardInstrK {
   T d;  // tolerance leaves: gaussian scale / margin (rewards.py:427), 0 when the margin is 0
 };
 
+// The scalars one env step reads.  The step kernel stages this block into LDS once per launch and
+// every step reads it from there (LDS broadcasts): read straight from global memory through the
+// per-step re-derived parameter pointer they were ~15 flat loads per step, each followed by an
+// exposed s_waitcnt vmcnt(0); kept in scalar registers across the fused step loop they spill.
 template <typename T>
-struct KParams {
+struct StepConst {
   T dt, inv_dt;
   T gravity[3];
   T kp_over_dt, one_minus_kd, motor_impulse;
   T lin_damp, ang_damp;
   T erp_over_dt, margin;
   T action_scale;
-  T gauss_scale;  // sqrt(-2 ln 0.1): rewards.py:427 with the default margin_value
-  int32_t iterations, auto_reset;
-  int32_t ulp_tol, pad1;  // SoloConfig::solver_ulp_tolerance
-  // heightfield ground (SoloTerrain): grid size, 1/cell, origin; heights live in KBuffers::terrain
-  int32_t terr_nx, terr_ny;
+  // heightfield ground (SoloTerrain): 1/cell, origin; grid size below; heights live in KBuffers::terrain
   T terr_inv_cell, terr_ox, terr_oy;
   T base_mass, base_I[6];
   T settle_tgt[SOLO_NUM_JOINTS];  // motor targets a reset leaves behind [rad] (solo8v2vanilla.py:21-34,127-136)
-  LegConst<T> leg[4];
-  RowConst<T> row[64];
-  int32_t num_obs, num_reward_ops, num_terms, pad0;
-  ObsElemK<T> obs[SOLO_MAX_OBS];
-  RewardInstrK<T> reward[SOLO_MAX_REWARD_OPS];
+  int32_t iterations, auto_reset;
+  int32_t ulp_tol;                // SoloConfig::solver_ulp_tolerance
+  int32_t terr_nx, terr_ny;
+  int32_t num_terms, num_obs, num_reward_ops;
   int32_t term_kind[SOLO_MAX_TERMS];
   int32_t term_param[SOLO_MAX_TERMS];
+};
+
+template <typename T>
+struct KParams {
+  StepConst<T> c;
+  LegConst<T> leg[4];
+  RowConst<T> row[64];
+  ObsElemK<T> obs[SOLO_MAX_OBS];
+  RewardInstrK<T> reward[SOLO_MAX_REWARD_OPS];
 };
 
 template <typename T>
@@ -140,24 +148,23 @@ inline int validate_model(const SoloModel& m, std::string* err) {
 template <typename T>
 inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) {
   std::memset(k, 0, sizeof(*k));
-  k->dt = (T)c.dt;
-  k->inv_dt = (T)(1.0 / c.dt);
-  for (int a = 0; a < 3; ++a) k->gravity[a] = (T)c.gravity[a];
-  k->kp_over_dt = (T)(c.motor_kp / c.dt);
-  k->one_minus_kd = (T)(1.0 - c.motor_kd);
-  k->motor_impulse = (T)(c.motor_torque_limit * c.dt);
-  k->lin_damp = (T)c.linear_damping;
-  k->ang_damp = (T)c.angular_damping;
-  k->erp_over_dt = (T)(c.contact_erp / c.dt);
-  k->margin = (T)c.contact_margin;
-  k->action_scale = (T)c.action_scale;
-  k->gauss_scale = (T)std::sqrt(-2.0 * std::log(0.1));
-  k->iterations = c.solver_iterations;
-  k->auto_reset = c.auto_reset;
-  k->ulp_tol = c.solver_ulp_tolerance;
-  for (int j = 0; j < SOLO_NUM_JOINTS; ++j) k->settle_tgt[j] = (T)c.settle_targets[j];
-  k->base_mass = (T)m.mass[0];
-  for (int a = 0; a < 6; ++a) k->base_I[a] = (T)m.inertia[0][a];
+  k->c.dt = (T)c.dt;
+  k->c.inv_dt = (T)(1.0 / c.dt);
+  for (int a = 0; a < 3; ++a) k->c.gravity[a] = (T)c.gravity[a];
+  k->c.kp_over_dt = (T)(c.motor_kp / c.dt);
+  k->c.one_minus_kd = (T)(1.0 - c.motor_kd);
+  k->c.motor_impulse = (T)(c.motor_torque_limit * c.dt);
+  k->c.lin_damp = (T)c.linear_damping;
+  k->c.ang_damp = (T)c.angular_damping;
+  k->c.erp_over_dt = (T)(c.contact_erp / c.dt);
+  k->c.margin = (T)c.contact_margin;
+  k->c.action_scale = (T)c.action_scale;
+  k->c.iterations = c.solver_iterations;
+  k->c.auto_reset = c.auto_reset;
+  k->c.ulp_tol = c.solver_ulp_tolerance;
+  for (int j = 0; j < SOLO_NUM_JOINTS; ++j) k->c.settle_tgt[j] = (T)c.settle_targets[j];
+  k->c.base_mass = (T)m.mass[0];
+  for (int a = 0; a < 6; ++a) k->c.base_I[a] = (T)m.inertia[0][a];
   for (int leg = 0; leg < 4; ++leg) {
     LegConst<T>& L = k->leg[leg];
     const int ju = 2 * leg, jl = 2 * leg + 1, bu = 1 + ju, bl = 1 + jl;
@@ -230,9 +237,9 @@ inline int pack_program(const SoloProgram& p, KParams<T>* k, std::string* err) {
     if (p.obs[i].src < 0 || p.obs[i].src >= SOLO_SRC_COUNT) return fail("obs source out of range");
   for (int i = 0; i < p.num_terms; ++i)
     if (p.term_kind[i] < SOLO_T_PERPETUAL || p.term_kind[i] > SOLO_T_CONST) return fail("bad termination kind");
-  k->num_obs = p.num_obs;
-  k->num_reward_ops = p.num_reward_ops;
-  k->num_terms = p.num_terms;
+  k->c.num_obs = p.num_obs;
+  k->c.num_reward_ops = p.num_reward_ops;
+  k->c.num_terms = p.num_terms;
   for (int i = 0; i < p.num_obs; ++i) {
     ObsElemK<T>& o = k->obs[i];
     o.src = p.obs[i].src;
@@ -257,8 +264,8 @@ inline int pack_program(const SoloProgram& p, KParams<T>* k, std::string* err) {
     k->reward[i].d = (T)(margin != 0.0 ? std::sqrt(-2.0 * std::log(0.1)) / margin : 0.0);
   }
   for (int i = 0; i < SOLO_MAX_TERMS; ++i) {
-    k->term_kind[i] = p.term_kind[i];
-    k->term_param[i] = p.term_param[i];
+    k->c.term_kind[i] = p.term_kind[i];
+    k->c.term_param[i] = p.term_param[i];
   }
   return SOLO_OK;
 }

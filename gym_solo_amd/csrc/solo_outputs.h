@@ -81,7 +81,7 @@ __device__ __forceinline__ T observation_value(const ObsElemK<T>& e, const T* re
 }
 template <typename T>
 __device__ __forceinline__ void eval_observations(const KParams<T>* P, const T* rec, T roll, T pitch, T yaw, T* out) {
-  const int n = P->num_obs;
+  const int n = P->c.num_obs;
   for (int i = 0; i < n; ++i) out[i] = observation_value<T>(P->obs[i], rec, roll, pitch, yaw);
 }
 
@@ -124,7 +124,7 @@ __device__ __forceinline__ T reward_combine(const RewardInstrK<T>& r, const T* v
 // the whole program for one item; returns the value of the last instruction
 template <typename T>
 __device__ __forceinline__ T eval_reward(const KParams<T>* P, const T* rec, T roll, T pitch, T* val, int stride) {
-  const int n = P->num_reward_ops;
+  const int n = P->c.num_reward_ops;
   T last = T(0);
   for (int i = 0; i < n; ++i) {
     const RewardInstrK<T>& r = P->reward[i];

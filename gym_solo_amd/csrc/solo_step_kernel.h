@@ -109,12 +109,12 @@ template <typename T> __device__ __forceinline__ V3<T> from_lower(bool lower, V3
 // constraint impulse; physics_finish writes s_state (new).
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, const KBuffers<T>& B, const LegConst<T>& L,
-                                           const RowConst<T>& rc, const T* s_state, const T* s_tgt, T (*s_rowvec)[8], T (*s_hext)[8],
+__device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
+                                           const RowConst<T>& rc, const T* s_state, T my_target, T (*s_rowvec)[8], T (*s_hext)[8],
                                            T* s_keep, T (*s_leg)[20], T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
-  const T dt = P->dt;
+  const T dt = C.dt;
 
   // ---- base: rotation (body -> world), velocities and gravity in base coordinates ----------
   const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
@@ -123,7 +123,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   const T r20 = T(2) * (qx * qz - qw * qy), r21 = T(2) * (qy * qz + qw * qx), r22 = T(1) - T(2) * (qx * qx + qy * qy);
   const V3<T> ww = {s_state[SOLO_S_ANGVEL], s_state[SOLO_S_ANGVEL + 1], s_state[SOLO_S_ANGVEL + 2]};
   const V3<T> vw = {s_state[SOLO_S_LINVEL], s_state[SOLO_S_LINVEL + 1], s_state[SOLO_S_LINVEL + 2]};
-  const V3<T> gw = {P->gravity[0], P->gravity[1], P->gravity[2]};
+  const V3<T> gw = {C.gravity[0], C.gravity[1], C.gravity[2]};
   // R^T v
   const V3<T> om = {r00 * ww.x + r10 * ww.y + r20 * ww.z, r01 * ww.x + r11 * ww.y + r21 * ww.z, r02 * ww.x + r12 * ww.y + r22 * ww.z};
   const V3<T> vb = {r00 * vw.x + r10 * vw.y + r20 * vw.z, r01 * vw.x + r11 * vw.y + r21 * vw.z, r02 * vw.x + r12 * vw.y + r22 * vw.z};
@@ -193,7 +193,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   const V3<T> r = c - ob;
   const V3<T> a_c = select(lower, a_o2, a_o1) + cross(a, r) + (dot(wB, r) * wB - wB2 * r);
   const V3<T> v_c = vb + cross(om, c) + qd1 * t1 + (bm * qd2) * t2;
-  const T kl = P->lin_damp, ka = P->ang_damp;
+  const T kl = C.lin_damp, ka = C.ang_damp;
   const T dB = kl * (T(1) + R::sqrt(dot(v_c, v_c)));
   const T eB = ka * (T(1) + R::sqrt(wB2));
   const V3<T> F = mB * (a_c - gb + dB * v_c);
@@ -258,10 +258,10 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   }
   // the base body itself (mass / inertia scaled per env for domain randomisation)
   {
-    const T m0 = P->base_mass * mass_scale;
+    const T m0 = C.base_mass * mass_scale;
     T I0[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) I0[i] = P->base_I[i] * mass_scale;
+    for (int i = 0; i < 6; ++i) I0[i] = C.base_I[i] * mass_scale;
     S[0][0] += I0[0]; S[1][0] += I0[3]; S[1][1] += I0[1]; S[2][0] += I0[4]; S[2][1] += I0[5]; S[2][2] += I0[2];
     S[3][3] += m0; S[4][4] += m0; S[5][5] += m0;
     const V3<T> Iw = symmul(I0, om);
@@ -352,16 +352,16 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     const T cwx = s_state[SOLO_S_POS] + r00 * cb.x + r01 * cb.y + r02 * cb.z;
     const T cwy = s_state[SOLO_S_POS + 1] + r10 * cb.x + r11 * cb.y + r12 * cb.z;
     const T cwz = s_state[SOLO_S_POS + 2] + r20 * cb.x + r21 * cb.y + r22 * cb.z;
-    const T gu = (cwx - P->terr_ox) * P->terr_inv_cell, gv = (cwy - P->terr_oy) * P->terr_inv_cell;
+    const T gu = (cwx - C.terr_ox) * C.terr_inv_cell, gv = (cwy - C.terr_oy) * C.terr_inv_cell;
     int gi = (int)R::floor(gu), gj = (int)R::floor(gv);
-    gi = gi < 0 ? 0 : (gi > P->terr_nx - 2 ? P->terr_nx - 2 : gi);
-    gj = gj < 0 ? 0 : (gj > P->terr_ny - 2 ? P->terr_ny - 2 : gj);
+    gi = gi < 0 ? 0 : (gi > C.terr_nx - 2 ? C.terr_nx - 2 : gi);
+    gj = gj < 0 ? 0 : (gj > C.terr_ny - 2 ? C.terr_ny - 2 : gj);
     const T fu = R::clamp(gu - T(gi), T(0), T(1)), fv = R::clamp(gv - T(gj), T(0), T(1));
-    const T* H = B.terrain + (size_t)gj * P->terr_nx + gi;
-    const T h00 = H[0], h10 = H[1], h01 = H[P->terr_nx], h11 = H[P->terr_nx + 1];
+    const T* H = B.terrain + (size_t)gj * C.terr_nx + gi;
+    const T h00 = H[0], h10 = H[1], h01 = H[C.terr_nx], h11 = H[C.terr_nx + 1];
     const T hh0 = (T(1) - fu) * (T(1) - fv) * h00 + fu * (T(1) - fv) * h10 + (T(1) - fu) * fv * h01 + fu * fv * h11;
-    const T hx = ((T(1) - fv) * (h10 - h00) + fv * (h11 - h01)) * P->terr_inv_cell;
-    const T hy = ((T(1) - fu) * (h01 - h00) + fu * (h11 - h10)) * P->terr_inv_cell;
+    const T hx = ((T(1) - fv) * (h10 - h00) + fv * (h11 - h01)) * C.terr_inv_cell;
+    const T hy = ((T(1) - fu) * (h01 - h00) + fu * (h11 - h10)) * C.terr_inv_cell;
     const T inv = R::rsqrt(hx * hx + hy * hy + T(1));
     const V3<T> nw = {-hx * inv, -hy * inv, inv};
     // friction directions: world x projected into the tangent plane, and n x t1
@@ -375,7 +375,7 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     nloc = V3<T>{r00 * nw.x + r10 * nw.y + r20 * nw.z, r01 * nw.x + r11 * nw.y + r21 * nw.z, r02 * nw.x + r12 * nw.y + r22 * nw.z};
     d = V3<T>{r00 * dw.x + r10 * dw.y + r20 * dw.z, r01 * dw.x + r11 * dw.y + r21 * dw.z, r02 * dw.x + r12 * dw.y + r22 * dw.z};
   }
-  const bool live = is_motor || (is_contact && dist < P->margin);
+  const bool live = is_motor || (is_contact && dist < C.margin);
   const V3<T> x = cb - rc.radius * nloc;  // contact point in base coordinates
   T jb[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   T jl1 = T(0), jl2 = T(0), bias = T(0);
@@ -384,15 +384,14 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
     jb[0] = xd.x; jb[1] = xd.y; jb[2] = xd.z; jb[3] = d.x; jb[4] = d.y; jb[5] = d.z;
     if (rc.body != BODY_BASE) jl1 = dot(d, ycross(x - o1));
     if (rc.body == BODY_LOWER) jl2 = dot(d, ycross(x - o2));
-    if (type == ROW_NORMAL) bias = (dist > T(0)) ? -dist * P->inv_dt : -P->erp_over_dt * dist;
+    if (type == ROW_NORMAL) bias = (dist > T(0)) ? -dist * C.inv_dt : -C.erp_over_dt * dist;
   } else if (is_motor) {
     // POSITION_CONTROL motor row ([recalled] btMultiBodyJointMotor): target velocity
     // kp (q* - q)/dt + (1 - kd) qd, impulse clamp +-maxForce*dt
-    const int jt = 3 * leg + k;  // pybullet joint index of this dof
     jl1 = (k == 0) ? T(1) : T(0);
     jl2 = (k == 1) ? T(1) : T(0);
     const T qj = s_leg[leg][17 + k], uj = s_leg[leg][15 + k];
-    bias = P->kp_over_dt * (s_tgt[jt] - qj) + P->one_minus_kd * uj;
+    bias = C.kp_over_dt * (my_target - qj) + C.one_minus_kd * uj;
   }
   T gh[6], hh[2];
   {
@@ -474,16 +473,16 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   // pending rows in solver order (motor rows, then contacts by sphere) with a scalar
   // find-first-set; only those rows cost anything, and after each change the set is re-evaluated,
   // so the decisions are the ones a dense sweep over every row would take.
-  const T imp = P->motor_impulse;
+  const T imp = C.motor_impulse;
   T lo = T(0), hi = T(0);
   if (is_motor) { lo = -imp; hi = imp; }
   else if (live && type == ROW_NORMAL) hi = R::big();
   T lamv = T(0);
   T v = live ? w * nid : T(0);  // lam = 0
-  const T tol_rel = T(wave_uniform(P->ulp_tol)) * R::half_ulp();
-  const int iters = wave_uniform(P->iterations);  // scalar trip count
+  const T tol_rel = T(wave_uniform(C.ulp_tol)) * R::half_ulp();
+  const int iters = wave_uniform(C.iterations);  // scalar trip count
   constexpr unsigned long long kMotorLanes = 0x0003000300030003ull;   // k = 0, 1 of each leg
-  constexpr unsigned long long kNormalLanes = 0x0924092409240924ull;  // k = 2, 5, 8, 11
+  const int my_normal = type == ROW_TAN1 ? lane - 1 : (type == ROW_TAN2 ? lane - 2 : -1);
   T cand = R::clamp(v, lo, hi);
   T dl = cand - lamv;
   unsigned long long pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
@@ -508,11 +507,14 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
           const T delta = wave_readlane(dl, r);
           v = R::fma(col, delta, v);
           lamv = (lane == r) ? cand : lamv;
-          if ((kNormalLanes >> r) & 1ull) {
-            // a normal row moved: its two friction rows are limited by mu * (fresh normal impulse)
+          {
+            // if a normal row moved, its two friction rows are limited by mu * (fresh normal impulse).
+            // Branch-free: `my_normal` is the lane of this row's normal row for a friction row and -1
+            // otherwise, so for any other kind of row r the select changes nothing - five VALU
+            // instructions instead of a scalar bit test, a taken branch and the same five.
             const T lim = mu * wave_readlane(cand, r);
-            const bool mine = (unsigned)(lane - r - 1) < 2u;
-            lo = mine ? T(0) - lim : lo;  // (0 - 0 = +0)
+            const bool mine = my_normal == r;
+            lo = mine ? -lim : lo;
             hi = mine ? lim : hi;
           }
           cand = R::clamp(v, lo, hi);
@@ -541,7 +543,16 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
   // Measured +5.5 % on the benchmark rollout; no effect on results.
   prio_sweeps += it;
   prio_steps += 1;
+#if !defined(SOLO_PRIO_MODE) || SOLO_PRIO_MODE == 0
   wave_set_priority(4 * prio_sweeps, 20 * prio_steps, 32 * prio_steps, 48 * prio_steps);
+#elif SOLO_PRIO_MODE == 1
+  wave_set_priority_level((prio_steps + wave_slot_id()) & 3);
+#elif SOLO_PRIO_MODE == 2
+  wave_set_priority_level(((prio_steps >> 2) + wave_slot_id()) & 3);
+#elif SOLO_PRIO_MODE == 3
+  { const int b = 4 * prio_sweeps > 48 * prio_steps ? 2 : (4 * prio_sweeps > 24 * prio_steps ? 1 : 0);
+    wave_set_priority_level(((prio_steps + wave_slot_id()) & 3) + b); }
+#endif
   SOLO_STAMP(B, 9);
   return lamv;
 }
@@ -549,11 +560,11 @@ __device__ __forceinline__ T physics_solve(const KParams<T>* __restrict__ P, con
 // post-solve half: apply the impulses (du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam -
 // K du_b), go back to world-frame velocities and integrate.  Everything is re-read from LDS.
 template <typename T>
-__device__ __forceinline__ void physics_finish(const KParams<T>* __restrict__ P, T* s_state, const T (*s_rowvec)[8],
+__device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, const T (*s_rowvec)[8],
                                                const T* s_keep, const T (*s_leg)[20], T lam, int lane) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
-  const T dt = P->dt;
+  const T dt = C.dt;
   T z[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) z[i] = wave_sum_all(s_rowvec[lane][i] * lam);
@@ -625,7 +636,6 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   if (!kFull) B.flags = SOLO_STEP_PHYSICS;
   using R = Real<T>;
   __shared__ T s_state[SOLO_STATE_STRIDE];
-  __shared__ T s_tgt[16];
   __shared__ T s_rowvec[64][8];
   __shared__ T s_hext[64][8];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
   __shared__ T s_keep[32];
@@ -636,6 +646,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   // read them from LDS instead of paying a global-load latency each
   __shared__ LegConst<T> s_legc[4];
   __shared__ RowConst<T> s_rowc[64];
+  __shared__ StepConst<T> s_const;          // the scalars a step reads (see solo_kernel_params.h)
 
   const int lane0 = lane_id();
   const int env = block_id() + B.env_base;
@@ -661,11 +672,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     T* dst = reinterpret_cast<T*>(s_legc);
     for (int i = lane0; i < kLegWords; i += 64) dst[i] = src[i];
     s_rowc[lane0] = P0->row[lane0];
+    constexpr int kConstWords = (int)(sizeof(StepConst<T>) / sizeof(int32_t));
+    const int32_t* csrc = reinterpret_cast<const int32_t*>(&P0->c);
+    int32_t* cdst = reinterpret_cast<int32_t*>(&s_const);
+    for (int i = lane0; i < kConstWords; i += 64) cdst[i] = csrc[i];
   }
-  // next step's action of this lane's joint, fetched one step ahead
-  T act_next = T(0);
   int prio_sweeps = 0, prio_steps = 0;
-  if (B.actions != nullptr && lane0 < SOLO_NUM_JOINTS) act_next = B.actions[(size_t)env * SOLO_NUM_JOINTS + lane0];
   if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = B.state[rec + lane0];
   const T mu = B.params[(size_t)env * 4 + 0];
   const T mass_scale = B.params[(size_t)env * 4 + 1];
@@ -677,39 +689,38 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   // only actions come in and the step records / done flags go out per step.  Robots are independent, so
   // no wave ever waits for another one; a launch lasts as long as its slowest robot's SUM over
   // the steps, which averages out the contact-count imbalance between robots.
+  wave_sync();  // the staged tables, the state record and the counters are in LDS
 #pragma unroll 1
   for (int step = 0; step < B.steps; ++step) {
-    // Re-derive the parameter pointer opaquely every step: otherwise the compiler hoists the ~60
-    // per-lane constant loads out of the step loop and keeps them live across it (spills).
-    const KParams<T>* __restrict__ P = wave_opaque(P0);  // NB: values loaded through it that steer
-    // control flow must be re-declared uniform (wave_uniform), or loops turn divergent
-    const int lane = wave_opaque_lane(lane0);  // same reason: per-lane address arithmetic stays in the step
+    const StepConst<T>& C = s_const;  // (LDS: re-read every step, nothing carried across the step loop in registers)
+    const int lane = wave_opaque_lane(lane0);  // per-lane address arithmetic stays in the step instead of being
+    // hoisted out of the fused step loop and kept live across it (spills)
     const LegConst<T>& L = s_legc[lane >> 4];
     const RowConst<T>& rc = s_rowc[lane];
-    if (lane < SOLO_NUM_JOINTS) {
-      T t;
-      if (B.actions != nullptr) {
-        // action de-normalisation (solo8v2vanilla.py:84-85) + setJointMotorControlArray (:87-90)
-        t = act_next * P->action_scale;
-        if (step + 1 < B.steps)
-          act_next = B.actions[(size_t)(step + 1) * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane];
-        if (step == B.steps - 1) B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = t;
-      } else {
-        t = B.targets[(size_t)env * SOLO_NUM_JOINTS + lane];
-      }
-      s_tgt[lane] = t;
-    }
-    wave_sync();
+    // setJointMotorControlArray (solo8v2vanilla.py:87-90): every motor lane fetches the target of ITS
+    // joint straight from global memory.  The value is consumed when the motor rows are built,
+    // thousands of cycles into the step, so the load's latency is never waited for (funnelled
+    // through LDS at the top of the step - or prefetched a step ahead into a register the compiler
+    // then copies at once - it cost an exposed global-memory round trip per step).
+    const bool motor_lane = rc.type == ROW_MOTOR;
+    const size_t tgt_at = (size_t)env * SOLO_NUM_JOINTS + (size_t)(3 * (lane >> 4) + (lane & 15));  // pybullet joint index
+    T raw_target = T(0);
+    if (motor_lane) raw_target = B.actions != nullptr ? B.actions[(size_t)step * B.action_stride + tgt_at] : B.targets[tgt_at];
+    // action de-normalisation (solo8v2vanilla.py:84-85), applied where the target is used
+    const T target_scale = B.actions != nullptr ? C.action_scale : T(1);
+    if (B.actions != nullptr && step == B.steps - 1 && lane < SOLO_NUM_JOINTS)  // the view's targets: all 12 entries
+      B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] =
+          B.actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * C.action_scale;
 
     SOLO_STAMP(B, 1);
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
-      const T lam = physics_solve<T>(P, B, L, rc, s_state, s_tgt, s_rowvec, s_hext, s_keep, s_leg, mu, mass_scale, lane, prio_sweeps, prio_steps);
-      physics_finish<T>(P, s_state, s_rowvec, s_keep, s_leg, lam, lane);
+      const T my_target = raw_target * target_scale;
+      const T lam = physics_solve<T>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, mu, mass_scale, lane, prio_sweeps, prio_steps);
+      physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, lam, lane);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted
-      const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) ||
-                       (lane < SOLO_NUM_JOINTS && !R::finite(s_tgt[lane & 15]));
+      const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) || (motor_lane && !R::finite(my_target));
       diverged = wave_ballot(bad) != 0ull;
       if (diverged) {
         if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
@@ -723,9 +734,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     bool done = false;
     if (B.flags & SOLO_STEP_DONE) {
       // every lane evaluates the same list on the same counters; lane 0 writes them back.  The
-      // program (a few wave-uniform ints) is re-read through the per-step pointer: scalar loads,
-      // nothing carried across the step loop.
-      const int n_terms = wave_uniform(P->num_terms);
+      // program (a few wave-uniform ints) is re-read from the staged constants in LDS.
+      const int n_terms = wave_uniform(C.num_terms);
       int c[SOLO_MAX_TERMS];
 #pragma unroll
       for (int t = 0; t < SOLO_MAX_TERMS; ++t) c[t] = s_cnt[t];
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
 #pragma unroll
       for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
         if (t < n_terms && !d) {
-          const int kind = wave_uniform(P->term_kind[t]), param = wave_uniform(P->term_param[t]);
+          const int kind = wave_uniform(C.term_kind[t]), param = wave_uniform(C.term_param[t]);
           if (kind == SOLO_T_TIME) {
             c[t] += 1;
             d = c[t] > param;
@@ -753,7 +763,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     // a query-only launch - TerminationFactory.is_terminated() outside step(), termination.py:38-50
     // - never mutates the physics state.
     const bool restart = (B.flags & SOLO_STEP_DONE) && (B.flags & (SOLO_STEP_PHYSICS | SOLO_STEP_AUTO_RESET)) &&
-                         (done || diverged) && wave_uniform(P->auto_reset) != 0;
+                         (done || diverged) && wave_uniform(C.auto_reset) != 0;
     // ---- the step's record for the output kernels (solo_outputs.h): the state after the step,
     //      before an auto-reset (one coalesced 32-real store), and the step's event bits
     if (B.traj != nullptr) {
@@ -767,7 +777,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     if (B.obs_inline != nullptr || B.reward_inline != nullptr) {
       T roll, pitch, yaw;
       euler_from_quat<T>(s_state[SOLO_S_QUAT], s_state[SOLO_S_QUAT + 1], s_state[SOLO_S_QUAT + 2], s_state[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
-      const int n_obs = wave_uniform(P0->num_obs), n_rops = wave_uniform(P0->num_reward_ops);
+      const int n_obs = wave_uniform(C.num_obs), n_rops = wave_uniform(C.num_reward_ops);
       if (B.obs_inline != nullptr && lane < n_obs)
         B.obs_inline[(size_t)env * n_obs + lane] = observation_value<T>(P0->obs[lane], s_state, roll, pitch, yaw);
       if (B.reward_inline != nullptr) {
@@ -785,8 +795,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
           }
           B.reward_inline[env] = r;
           if (B.flags & SOLO_STEP_DONE) {
+            // episodic return / length live in the record's slots 29, 30: loaded with the state in the
+            // prologue, updated here in LDS, stored with the state at the end of the launch
             const uint8_t ev = (uint8_t)((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
-            accumulate_returns<T>(B.state + rec, &ev, 0, &r, 0, 1, stats, [](double* p, double x) { stats_add(p, x); });
+            accumulate_returns<T>(s_state, &ev, 0, &r, 0, 1, stats, [](double* p, double x) { stats_add(p, x); });
           }
         }
       }
@@ -798,7 +810,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
         if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
         if (lane < SOLO_MAX_TERMS) s_cnt[lane] = 0;
         // reset() leaves the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
-        if (lane < SOLO_NUM_JOINTS) B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = P->settle_tgt[lane];
+        if (lane < SOLO_NUM_JOINTS) B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = C.settle_tgt[lane];
       }
       if (lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
     }
@@ -808,8 +820,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   SOLO_STAMP(B, 13);
   const int lane1 = wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
   if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) B.term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
-  // (slots SOLO_S_RETURN.. of the record are the returns kernel's: never written from here)
-  if (lane1 < SOLO_S_RETURN) B.state[rec + lane1] = s_state[lane1];
+  // (slots SOLO_S_RETURN.. of the record are the returns kernel's after a fused launch; a single-step
+  // launch that evaluated its reward in place keeps the accumulators itself)
+  const bool own_returns = B.reward_inline != nullptr && (B.flags & SOLO_STEP_DONE);
+  if (lane1 < (own_returns ? SOLO_S_SPARE : SOLO_S_RETURN)) B.state[rec + lane1] = s_state[lane1];
   SOLO_STAMP(B, 14);
 #ifdef SOLO_STAMPS
   wave_sync();
@@ -838,7 +852,7 @@ __global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * kThreads;                        // first robot of this block within the launch's slice
   const int nb = count - e0 < kThreads ? count - e0 : kThreads;
-  const int n_obs = P->num_obs;
+  const int n_obs = P->c.num_obs;
   const bool staged = n_obs <= kObsStageMax;
   const int env = env_base + e0 + tid;
   // (a block walks several steps: few fat blocks instead of one small block per step)
@@ -908,7 +922,7 @@ __global__ void solo_reset_kernel(const KParams<T>* __restrict__ P, T* __restric
   state[i] = snapshot[i];
   if (e < SOLO_MAX_TERMS) term_count[env * SOLO_MAX_TERMS + e] = 0;
   // the settle loop ends with the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
-  if (e < SOLO_NUM_JOINTS) targets[env * SOLO_NUM_JOINTS + e] = P->settle_tgt[e];
+  if (e < SOLO_NUM_JOINTS) targets[env * SOLO_NUM_JOINTS + e] = P->c.settle_tgt[e];
 }
 
 // loadURDF at robot_start_pos / orientation (solo8v2vanilla.py:151-155), zero velocities

@@ -64,8 +64,8 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   std::vector<T> terr;
   if (terrain) {
     terr = conv(terrain->heights, (size_t)terrain->nx * terrain->ny);
-    P.terr_nx = terrain->nx; P.terr_ny = terrain->ny; P.terr_inv_cell = (T)(1.0 / terrain->cell);
-    P.terr_ox = (T)terrain->origin[0]; P.terr_oy = (T)terrain->origin[1];
+    P.c.terr_nx = terrain->nx; P.c.terr_ny = terrain->ny; P.c.terr_inv_cell = (T)(1.0 / terrain->cell);
+    P.c.terr_ox = (T)terrain->origin[0]; P.c.terr_oy = (T)terrain->origin[1];
   }
   const bool want_obs = (flags & SOLO_STEP_OBS) != 0, want_reward = (flags & SOLO_STEP_REWARD) != 0;
   KBuffers<T> B;

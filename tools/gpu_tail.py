@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from gym_solo_amd import abi
 from bench import build_env
-n = 4096
+n = int(os.environ.get('N', '4096'))
 for spl in [int(a) for a in sys.argv[1:]] or (250, 20, 1):
   for streams in (1, 2):
     env = build_env(n, 0, 'float32', steps_per_launch=spl, rollout_streams=streams)
@@ -31,6 +31,20 @@ for spl in [int(a) for a in sys.argv[1:]] or (250, 20, 1):
     print('S=%d streams=%d: rollout %.3f ms = %.2f us/step ; ticks: span %d (%.1f MHz tick rate) ; per-robot life/step pct 1/50/90/99/max = %s ; mean %.0f ; mean/span = %.2f ; start skew %d' % (
       spl, streams, ms, ms * 1e3 / spl, span, span / (ms * 1e3), (np.percentile(life, [1, 50, 90, 99, 100]) / spl).astype(int).tolist(),
       life.mean() / spl, life.mean() / span, t0.max() - t0.min()))
+    hw = (buf[:, 15] >> 28).astype(np.int64); xcc = ((buf[:, 15] >> 24) & 0xf).astype(np.int64)
+    simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+    print('    by XCC: ' + ' '.join('%d:%d/%.0f' % (x, (xcc == x).sum(), life[xcc == x].mean() / spl) for x in np.unique(xcc)))
+    print('    per-XCC span/step (first start -> last end): ' + ' '.join('%d:%.0f' % (x, (t1[xcc == x].max() - t0[xcc == x].min()) / spl) for x in np.unique(xcc)))
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    u, inv = np.unique(cuid, return_inverse=True)
+    cnt = np.bincount(inv); cmean = np.bincount(inv, weights=life / spl) / cnt
+    print('    CUs used %d ; waves per CU min/max %d/%d ; per-CU mean life: min %.0f p50 %.0f max %.0f ; corr(waves on CU, mean life) %.2f' % (
+      len(u), cnt.min(), cnt.max(), cmean.min(), np.median(cmean), cmean.max(), np.corrcoef(cnt, cmean)[0, 1] if cnt.std() > 0 else 0))
+    sid = cuid * 4 + simd
+    u2, inv2 = np.unique(sid, return_inverse=True)
+    cnt2 = np.bincount(inv2)
+    print('    SIMDs used %d ; waves per SIMD histogram %s ; mean life by waves-on-SIMD: %s' % (
+      len(u2), np.bincount(cnt2).tolist(), {int(c): int((life / spl)[cnt2[inv2] == c].mean()) for c in np.unique(cnt2)}))
     for g_ in range(streams):
       lo, hi = n * g_ // streams, n * (g_ + 1) // streams
       print('    slice %d: first start %d last end %d (rel. to global first start)' % (g_, t0[lo:hi].min() - t0.min(), t1[lo:hi].max() - t0.min()))
