@@ -537,22 +537,19 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     B.acc[0] += (unsigned long long)n_changed;
   }
 #endif
-  // Robots whose solver needs many sweeps are the ones a fused launch waits for (their cost is
-  // persistent: launch-to-launch correlation 0.83), so their wave asks for priority in its SIMD's
-  // issue arbitration (s_setprio), by the launch-average sweeps per step so far: > 5, > 8, > 12.
-  // Measured +5.5 % on the benchmark rollout; no effect on results.
+  // Issue priority of this wave in its SIMD (s_setprio).  Two effects are countered (both measured
+  // with per-wave start / end stamps, tools/gpu_tail.py):
+  //  * a SIMD arbitrates its waves by priority, then AGE: at equal priority the oldest of the four
+  //    resident waves issues almost unimpeded and the youngest gets the leftovers, for the whole
+  //    launch (per-robot time per step 18 k ... 30 k cycles by age rank alone).  The waves therefore
+  //    ROTATE through priorities 0..2 by step count and wave slot, which equalises their progress;
+  //  * a launch lasts as long as its slowest robot, and slow means many Gauss-Seidel sweeps (the
+  //    cost is persistent within an episode): a robot that has averaged more than 8 sweeps per step
+  //    so far in the launch is pinned to priority 3, above the rotation.
+  // +4 % on the 250-step fused rollout, +2 % at 20 steps; no effect on results.
   prio_sweeps += it;
   prio_steps += 1;
-#if !defined(SOLO_PRIO_MODE) || SOLO_PRIO_MODE == 0
-  wave_set_priority(4 * prio_sweeps, 20 * prio_steps, 32 * prio_steps, 48 * prio_steps);
-#elif SOLO_PRIO_MODE == 1
-  wave_set_priority_level((prio_steps + wave_slot_id()) & 3);
-#elif SOLO_PRIO_MODE == 2
-  wave_set_priority_level(((prio_steps >> 2) + wave_slot_id()) & 3);
-#elif SOLO_PRIO_MODE == 3
-  { const int b = 4 * prio_sweeps > 48 * prio_steps ? 2 : (4 * prio_sweeps > 24 * prio_steps ? 1 : 0);
-    wave_set_priority_level(((prio_steps + wave_slot_id()) & 3) + b); }
-#endif
+  wave_set_priority_level(prio_sweeps > 8 * prio_steps ? 3 : (prio_steps + wave_slot_id()) % 3);
   SOLO_STAMP(B, 9);
   return lamv;
 }

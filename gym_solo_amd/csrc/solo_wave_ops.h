@@ -173,19 +173,9 @@ template <> struct ColumnBank<double> {
   __device__ __forceinline__ double get(int, int r) const { return column(r); }
 };
 
-// issue priority of this wave in its SIMD (0..3) by thresholds on a wave-uniform measure
-__device__ __forceinline__ void wave_set_priority(int m, int t1, int t2, int t3) {
-#ifdef SOLO_NO_PRIO  // (experiment switch: make EXTRA=-DSOLO_NO_PRIO)
-  return;
-#endif
-  if (m > t3) __builtin_amdgcn_s_setprio(3);
-  else if (m > t2) __builtin_amdgcn_s_setprio(2);
-  else if (m > t1) __builtin_amdgcn_s_setprio(1);
-  else __builtin_amdgcn_s_setprio(0);
-}
-
 // slot of this wave among the waves resident on its SIMD (HW_ID[3:0])
 __device__ __forceinline__ int wave_slot_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 0xf); }
+// issue priority of this wave in its SIMD
 __device__ __forceinline__ void wave_set_priority_level(int p) {  // p wave-uniform, 0..3
   if (p >= 3) __builtin_amdgcn_s_setprio(3);
   else if (p == 2) __builtin_amdgcn_s_setprio(2);

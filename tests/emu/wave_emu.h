@@ -124,7 +124,6 @@ template <typename P> inline P* wave_opaque(P* p) { return p; }
 inline int wave_opaque_lane(int lane) { return lane; }
 inline int wave_uniform(int x) { return x; }
 inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
-inline void wave_set_priority(int, int, int, int) {}
 inline void wave_set_priority_level(int) {}
 inline int wave_slot_id() { return 0; }
 inline void block_sync() {}  // (the thread-per-item output kernels are not emulated: their per-item functions run in loops)

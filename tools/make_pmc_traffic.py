@@ -1,40 +1,59 @@
 """profiles/pmc_traffic.json from the PMC summaries of tools/refresh_profiles.sh.
 
-Usage: python tools/make_pmc_traffic.py gpurun_out/<tag>  (reads pmc_hbm_f32.json, pmc_sq_f32.json)
-FETCH_SIZE / WRITE_SIZE come from SEPARATE --pmc passes (TCC slots), rocprofv3 reports them in KB.
-MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x and
-other widths are uncalibrated; this kernel loads one dword per lane, so the raw value is kept and
-the 2x-corrected total is stated next to it."""
+usage: python tools/make_pmc_traffic.py gpurun_out/<tag>   (reads pmc_hbm_f32.json, pmc_sq_f32.json)
+
+Everything is normalised PER ENV-STEP, so that bench.py can scale it to the launch size of its own
+run (roofline.traffic = hbm_bytes_per_env_step x env_steps_per_launch of that run).  FETCH_SIZE /
+WRITE_SIZE come from SEPARATE --pmc passes (TCC slots), rocprofv3 reports them in KB.
+MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE under-reports WIDE (16 B/lane) streaming
+reads by exactly 2x, WRITE_SIZE is exact for 16 B/lane stores, other widths are uncalibrated.  The
+step kernel loads one dword per lane (uncalibrated: raw value kept); the outputs kernel streams its
+records and rows coalesced (dword per lane as well).  The raw figures are reported, with the
+2x-on-reads upper bound next to them."""
 import json, os, sys
 src = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 hbm = json.load(open(os.path.join(src, 'pmc_hbm_f32.json')))
 sq = json.load(open(os.path.join(src, 'pmc_sq_f32.json')))
-robots, spl = 2048, 100              # tools/prof_driver.py: 4096 robots, 2 stream slices, 100 steps/launch
-n = robots * spl
-BYTES_PER_ENV_STEP = 385             # bench.py / DESIGN.md §3 (f32)
-fetch = hbm['FETCH_SIZE'] * 1024.0
-write = hbm['WRITE_SIZE'] * 1024.0
+meta = json.load(open(os.path.join(src, 'prof_driver.json')))   # robots per launch, steps per launch
+n = meta['robots_per_launch'] * meta['steps_per_launch']       # env-steps one launch (of each kernel) covers
+BYTES_PER_ENV_STEP = 385                                         # bench.py / SURVEY.md §8d (f32)
+per = {}
+for fam in ('step', 'outputs', 'returns'):
+  h = hbm.get(fam, {})
+  per[fam] = {'read_bytes_per_env_step': h.get('FETCH_SIZE', 0.0) * 1024.0 / n,
+              'write_bytes_per_env_step': h.get('WRITE_SIZE', 0.0) * 1024.0 / n}
+rd = sum(p['read_bytes_per_env_step'] for p in per.values())
+wr = sum(p['write_bytes_per_env_step'] for p in per.values())
+s = sq['step']
+wave_cycles = s.get('SQ_WAVE_CYCLES')
 out = {'float32': {
-  'hbm_bytes_per_launch': fetch + write,
-  'fetch_bytes_per_launch_raw': fetch,
-  'write_bytes_per_launch': write,
-  'env_steps_per_launch': n,
-  'bytes_per_env_step': (fetch + write) / n,
-  'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * n,
-  'valu_insts_per_env_step': sq['SQ_INSTS_VALU'] / n,
-  'salu_insts_per_env_step': sq['SQ_INSTS_SALU'] / n,
-  'lds_insts_per_env_step': sq['SQ_INSTS_LDS'] / n,
-  'how': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (TCC slots), SQ_INSTS_* in a third, '
-         'tools/prof_driver.py (bench workload, trajectories recorded, launches of 2048 robots x 100 steps), mean '
-         'over the last 10 full launches, KB*1024.  MI355X_MICROARCH.md: FETCH_SIZE under-reports wide 16-B/lane '
-         'streams by 2x; this kernel loads one dword per lane (uncalibrated width), so the raw value is reported; '
-         'with the 2x correction the total would be %.1f MB.' % ((2 * fetch + write) / 1e6),
-  'reading': 'the STEP KERNEL alone (the filter of tools/pmc_summary.py), below the algorithmic %d B/env-step of the whole '
-             'path: the fused launch keeps the 128-B state record in LDS for all its steps (no per-step state read), '
-             '~%.0f B/env-step read (actions 48 + parameters/snapshot), ~%.0f B/env-step written (the 128-B step record '
-             'the output kernels read + done + event byte); the observations (84 B) and rewards (4 B) are written by '
-             'solo_outputs_kernel from those records.' % (BYTES_PER_ENV_STEP, fetch / n, write / n)}}
+  'env_steps_per_profiled_launch': n,
+  'hbm_bytes_per_env_step': rd + wr,
+  'hbm_read_bytes_per_env_step': rd,
+  'hbm_write_bytes_per_env_step': wr,
+  'hbm_bytes_per_env_step_reads_doubled': 2 * rd + wr,
+  'per_kernel': per,
+  'algorithmic_bytes_per_env_step': BYTES_PER_ENV_STEP,
+  'valu_insts_per_env_step': s['SQ_INSTS_VALU'] / n,
+  'salu_insts_per_env_step': s['SQ_INSTS_SALU'] / n,
+  'lds_insts_per_env_step': s['SQ_INSTS_LDS'] / n,
+  'smem_insts_per_env_step': s.get('SQ_INSTS_SMEM', 0.0) / n,
+  'step_kernel_wave_cycle_shares': None if not wave_cycles else {
+    k: s[c] / wave_cycles for k, c in (('wait_any_parked_at_waitcnt', 'SQ_WAIT_ANY'), ('wait_inst_any_issue_stall', 'SQ_WAIT_INST_ANY'),
+                                       ('active_inst_any', 'SQ_ACTIVE_INST_ANY'), ('active_inst_valu', 'SQ_ACTIVE_INST_VALU'),
+                                       ('active_inst_sca', 'SQ_ACTIVE_INST_SCA'), ('active_inst_lds', 'SQ_ACTIVE_INST_LDS'),
+                                       ('wait_inst_lds', 'SQ_WAIT_INST_LDS')) if c in s},
+  'step_kernel_busy_cycles': s.get('SQ_BUSY_CYCLES'), 'step_kernel_wave_cycles': wave_cycles, 'step_kernel_waves': s.get('SQ_WAVES'),
+  'grbm_gui_active_per_launch': s.get('GRBM_GUI_ACTIVE'),
+  'traffic_note': 'measured HBM bytes per env-step (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, '
+                  'KB x 1024, step + outputs + returns kernels of one fused launch of %d robots x %d steps) x this run\'s '
+                  'env-steps per launch; raw FETCH_SIZE (dword-per-lane loads: uncalibrated width; with the guide\'s 2x '
+                  'correction for wide reads the total would be %.0f B/env-step); algorithmic figure of the whole path: %d '
+                  'B/env-step (a fused launch neither re-reads nor re-writes the 116-B state per step, and the returns '
+                  'kernel reads 5 B/env-step)' % (meta['robots_per_launch'], meta['steps_per_launch'], 2 * rd + wr, BYTES_PER_ENV_STEP),
+  'how': 'tools/refresh_profiles.sh: tools/prof_driver.py (bench workload, every step recorded) under rocprofv3 --pmc, one '
+         'pass per counter group; tools/pmc_summary.py averages the last 6 full-size dispatches per kernel'}}
 path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 json.dump(out, open(path, 'w'), indent=1)
 print(json.dumps(out, indent=1))

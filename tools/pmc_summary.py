@@ -1,14 +1,39 @@
-"""Averages rocprofv3 --pmc counters of solo_step_kernel dispatches (last 100) into JSON."""
-import csv, glob, json, os, sys, collections
-out = {}
+"""Averages rocprofv3 --pmc counters per kernel family over the FULL-SIZE dispatches of the
+profiled rollout (tools/prof_driver.py) into JSON.
+
+usage: pmc_summary.py out.json pmc_dir [pmc_dir ...]
+Families: step = solo_step_kernel<T, true>, outputs = solo_outputs_kernel, returns =
+solo_returns_kernel.  Per family only the dispatches with the largest grid are kept (the fused
+full-length launches of the timed rollout; the settle loop and the short tail launch have
+other names / sizes) and the last 6 of them are averaged."""
+import collections, csv, glob, json, os, sys
+
+
+def family(name):
+  if 'solo_step_kernel' in name and ('true' in name or 'Lb1' in name):
+    return 'step'
+  if 'solo_outputs_kernel' in name:
+    return 'outputs'
+  if 'solo_returns_kernel' in name:
+    return 'returns'
+  return None
+
+
+out = collections.defaultdict(dict)
 for d in sys.argv[2:]:
   for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
-    acc = collections.defaultdict(list)
+    rows = collections.defaultdict(list)  # (family, counter) -> [(grid, value, duration)]
     for r in csv.DictReader(open(f)):
-      if 'solo_step_kernel' in r['Kernel_Name'] and ('true' in r['Kernel_Name'] or 'Lb1' in r['Kernel_Name']):
-        acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    for k, v in acc.items():
-      v = v[-10:]
-      out[k] = sum(v) / len(v)
+      fam = family(r['Kernel_Name'])
+      if fam:
+        rows[(fam, r['Counter_Name'])].append((int(r['Grid_Size']), float(r['Counter_Value']),
+                                                int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+    for (fam, counter), v in rows.items():
+      gmax = max(g for g, _, _ in v)
+      full = [(x, t) for g, x, t in v if g == gmax][-6:]
+      out[fam][counter] = sum(x for x, _ in full) / len(full)
+      out[fam].setdefault('_dispatches_averaged', len(full))
+      out[fam].setdefault('_grid_size', gmax)
+      out[fam]['_duration_ns_under_pmc'] = sum(t for _, t in full) / len(full)
 json.dump(out, open(sys.argv[1], 'w'), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -1,20 +1,22 @@
-"""Runs a short physics+obs+reward rollout for profiling under rocprofv3 (not a test)."""
-import sys, os
+"""Runs the bench workload without timing code, for rocprofv3 passes (not a test).
+env: SPL (steps per launch, default 250), STREAMS (default 2), STEPS (default 2000), DTYPE, N."""
+import json, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
-sys.argv += [''] * 4
-iters = int(sys.argv[1] or 50); dtype = sys.argv[2] or 'float32'; n = int(sys.argv[3] or 4096)
 from bench import build_env
 from gym_solo_amd import abi
-env = build_env(n, 0, dtype, steps_per_launch=int(os.environ.get('SPL', '100')), rollout_streams=int(os.environ.get('STREAMS', '2')))
-if iters != 50:
-  raise SystemExit('use the config default')
+dtype = os.environ.get('DTYPE', 'float32'); n = int(os.environ.get('N', '4096'))
+spl, streams, steps = int(os.environ.get('SPL', '250')), int(os.environ.get('STREAMS', '2')), int(os.environ.get('STEPS', '2000'))
+env = build_env(n, 0, dtype, steps_per_launch=spl, rollout_streams=streams)
 eng = env.engine
 tdt = torch.float32 if dtype == 'float32' else torch.float64
 g = torch.Generator(device='cuda').manual_seed(1234)
-acts = (torch.rand(600, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
+acts = (torch.rand(steps, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
 out = eng.rollout_buffers(acts.shape[0])
 eng.rollout(acts, abi.STEP_ALL, out=out)
 torch.cuda.synchronize()
-print('done', eng.kernel_name)
+meta = {'robots_per_launch': n // streams if streams > 1 else n, 'steps_per_launch': spl, 'steps': steps, 'dtype': dtype}
+if len(sys.argv) > 1:
+  json.dump(meta, open(sys.argv[1], 'w'))
+print('done', eng.kernel_name, meta)
