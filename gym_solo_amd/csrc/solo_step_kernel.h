@@ -470,7 +470,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // contact's normal impulse), dl = clamp(v) - lam.  `pend` is the set of rows with |dl| above the
   // tolerance (solver_ulp_tolerance half-ulps of |lam|, relative) - evaluated for all 64 lanes at
   // once (v_med3, subtract, compare; the compare's lane mask IS the set).  A sweep walks the
-  // pending rows in solver order (motor rows, then contacts by sphere) with a scalar
+  // pending rows in solver order (motor rows, normal rows, friction rows) with a scalar
   // find-first-set; only those rows cost anything, and after each change the set is re-evaluated,
   // so the decisions are the ones a dense sweep over every row would take.
   const T imp = C.motor_impulse;
@@ -481,8 +481,12 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   T v = live ? w * nid : T(0);  // lam = 0
   const T tol_rel = T(wave_uniform(C.ulp_tol)) * R::half_ulp();
   const int iters = wave_uniform(C.iterations);  // scalar trip count
-  constexpr unsigned long long kMotorLanes = 0x0003000300030003ull;   // k = 0, 1 of each leg
-  const int my_normal = type == ROW_TAN1 ? lane - 1 : (type == ROW_TAN2 ? lane - 2 : -1);
+  // rows of one sweep, in solver order ([recalled] btMultiBodyConstraintSolver::solveSingleIteration):
+  // the joint motors, then ALL normal contact rows, then ALL friction rows
+  constexpr unsigned long long kPhaseLanes[3] = {0x0003000300030003ull,    // motors   k = 0, 1 of each leg
+                                                 0x0924092409240924ull,    // normals  k = 2, 5, 8, 11
+                                                 0x36d836d836d836d8ull};   // friction k = 3, 4, 6, 7, 9, 10, 12, 13
+  const bool is_tangent = type == ROW_TAN1 || type == ROW_TAN2;
   T cand = R::clamp(v, lo, hi);
   T dl = cand - lamv;
   unsigned long long pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
@@ -492,13 +496,25 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   int it = 0;
 #pragma unroll 1
   for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
-    // the register banks of the matrix are walked one after the other (static bank per loop): in
-    // lane order that is still "motor rows, then contact rows, each ascending"
+    // (the register banks of the matrix are walked one after the other - static bank per loop - which
+    // keeps the rows of a phase in ascending lane order)
 #pragma unroll
-    for (int phase = 0; phase < 2; ++phase) {
+    for (int phase = 0; phase < 3; ++phase) {
+      if (phase == 2) {
+        // the friction rows of a contact are limited by mu x the normal impulse it holds NOW: the
+        // normal rows are done for this sweep, so all limits are refreshed at once (a friction
+        // row's normal row sits one or two lanes below it: DPP row shifts) instead of per moved row
+        const T n1 = wave_lane_below<1>(lamv), n2 = wave_lane_below<2>(lamv);
+        const T lim = mu * (type == ROW_TAN1 ? n1 : n2);
+        lo = is_tangent ? -lim : lo;
+        hi = is_tangent ? lim : hi;
+        cand = R::clamp(v, lo, hi);
+        dl = cand - lamv;
+        pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
+      }
 #pragma unroll
       for (int bank = 0; bank < ColumnBank<T>::kBanks; ++bank) {
-        unsigned long long window = (phase == 0 ? kMotorLanes : ~kMotorLanes) & ColumnBank<T>::bank_lanes(bank);
+        unsigned long long window = kPhaseLanes[phase] & ColumnBank<T>::bank_lanes(bank);
 #pragma unroll 1
         while ((pend & window) != 0ull) {
           const int r = __builtin_ctzll(pend & window);  // wave-uniform: the row to update
@@ -507,16 +523,6 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
           const T delta = wave_readlane(dl, r);
           v = R::fma(col, delta, v);
           lamv = (lane == r) ? cand : lamv;
-          {
-            // if a normal row moved, its two friction rows are limited by mu * (fresh normal impulse).
-            // Branch-free: `my_normal` is the lane of this row's normal row for a friction row and -1
-            // otherwise, so for any other kind of row r the select changes nothing - five VALU
-            // instructions instead of a scalar bit test, a taken branch and the same five.
-            const T lim = mu * wave_readlane(cand, r);
-            const bool mine = my_normal == r;
-            lo = mine ? -lim : lo;
-            hi = mine ? lim : hi;
-          }
           cand = R::clamp(v, lo, hi);
           dl = cand - lamv;
           pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);

@@ -72,6 +72,8 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
 }
 // the value of lane ^ 8: the other half of the caller's 16-lane row (DPP row_ror:8)
 template <typename T> __device__ __forceinline__ T wave_other_half16(T x) { return dpp_mov<0x128>(x); }
+// the value of lane - N inside the caller's 16-lane row (DPP row_shr:N; the first N lanes of a row get 0)
+template <int N, typename T> __device__ __forceinline__ T wave_lane_below(T x) { return dpp_mov<0x110 + N>(x); }
 // sum over the 16 lanes of the caller's row, result in every lane (row_ror 8,4,2,1 all-reduce)
 template <typename T> __device__ __forceinline__ T wave_sum_group16(T x) {
   x += dpp_mov<0x128>(x);

@@ -83,9 +83,21 @@ class Solo8Model:
   # height at q = 0 is 0.32 + r = 0.33698, the target height used by
   # examples/solo8_vanilla/interactive_pos_control.py:23
   foot_radius: float = 0.01698
-  knee_radius: float = 0.015
+  # CALIBRATED on the one pybullet-extracted state the reference holds - the 12 getJointState rows
+  # "at rest" of gym_solo/core/test_obs_observations.py:256-275: |HFE| = 1.53013, |KFE| = 3.08532,
+  # joint rates ~1e-11.  At 2 N.m four saturated hip motors would press the knees down with
+  # 4 x 2 / 0.16 = 50 N and lift the 1.9 kg robot, so a state at rest 0.041 / 0.056 rad short of the
+  # folded targets is a PASSIVE rest: belly on the ground, every leg lying on its knee and its foot,
+  # the motors not carrying the links (an older, weaker-motor configuration: the vector's sign
+  # pattern predates today's starting_joint_pos as well).  Then the angles are pure geometry:
+  #   hip height - knee contact radius = 0.16 sin(pi/2 - 1.53013)              = 6.50 mm
+  #   hip height - foot contact radius = 6.50 mm + 0.16 sin(3.08532 - 1.53013 - pi/2) = 9.00 mm
+  # With the foot radius above: belly-to-hip height 0.02598 m and knee radius 0.01948 m
+  # (tests/test_oracle_physics.py::test_passive_rest_pose_reproduces_the_reference_vector, also on
+  # the HIP engine).  A calibration of two free collision parameters, not a validation.
+  knee_radius: float = 0.01948
   base_sphere_radius: float = 0.02
-  base_sphere_half_extents: Tuple[float, float, float] = (0.19, 0.055, 0.015)
+  base_sphere_half_extents: Tuple[float, float, float] = (0.19, 0.055, 0.00598)
 
   # ---- per-leg mirrored quantities -------------------------------------------------
   def leg_signs(self, leg: int) -> Tuple[float, float]:

@@ -540,8 +540,16 @@ int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, co
     diag[r] = d; lam[r] = 0;
   }
   memcpy(up, ustar, sizeof up);
+  /* row order of one iteration, [recalled] btMultiBodyConstraintSolver::solveSingleIteration: the
+   * non-contact rows (joint motors), then ALL normal contact rows, then ALL friction rows - each
+   * friction row limited by mu x the normal impulse its contact holds at that moment */
+  int order[MAXROWS], no = 0;
+  for (int r = 0; r < R.n; ++r) if (R.sphere[r] < 0) order[no++] = r;
+  for (int r = 0; r < R.n; ++r) if (R.sphere[r] >= 0 && R.normal_row[r] < 0) order[no++] = r;
+  for (int r = 0; r < R.n; ++r) if (R.sphere[r] >= 0 && R.normal_row[r] >= 0) order[no++] = r;
   for (int it = 0; it < cfg->solver_iterations; ++it)
-    for (int r = 0; r < R.n; ++r) {
+    for (int o = 0; o < no; ++o) {
+      const int r = order[o];
       double rel = 0;
       for (int i = 0; i < NV; ++i) rel += R.J[r][i] * up[i];
       double lo = R.lo[r], hi = R.hi[r];

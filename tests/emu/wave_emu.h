@@ -174,6 +174,11 @@ template <typename T> inline T wave_sum_legs(T x) {
   return x;
 }
 template <typename T> inline T wave_other_half16(T x) { return emu_shfl_xor(x, 8); }
+template <int N, typename T> inline T wave_lane_below(T x) {
+  const int l = lane_id();
+  const T y = wave_readlane(x, (l & 15) >= N ? l - N : l);
+  return (l & 15) >= N ? y : T(0);
+}
 template <typename T> inline T wave_sum_group16(T x) {
   x += emu_shfl_xor(x, 8);
   x += emu_shfl_xor(x, 4);

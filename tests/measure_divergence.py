@@ -16,11 +16,11 @@ def actions_for(regime, k, n, rng):
   if regime == 'stand-sway':      # smooth stand-up and sway: contact-rich, not chaotic
     t = k * 1e-3
     a = np.zeros((n, 12))
-    amp = 0.25 * min(1.0, t / 0.3)
+    amp = 0.2 * min(1.0, t / 0.3)
     for leg in range(4):
       s = 1.0 if leg < 2 else -1.0
-      a[:, 3 * leg] = s * (0.6 + amp * np.sin(2 * np.pi * 1.5 * t + leg))
-      a[:, 3 * leg + 1] = -s * (1.2 + amp * np.sin(2 * np.pi * 1.5 * t + leg))
+      a[:, 3 * leg] = s * (0.5 + amp * np.sin(2 * np.pi * 1.0 * t + leg))
+      a[:, 3 * leg + 1] = -s * (1.0 + amp * np.sin(2 * np.pi * 1.0 * t + leg))
     return a
   return rng.uniform(-2 * np.pi, 2 * np.pi, (n, 12))   # 'flail': the benchmark's U(-2pi, 2pi)
 
