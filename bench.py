@@ -206,6 +206,11 @@ def main():
 
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+  # rehearsal knobs for a 1-GPU box (never set by the driver): every rank on cuda:0, gloo instead of
+  # RCCL (which refuses two ranks on one device) - exercises the launcher and the multi-rank timing
+  backend = os.environ.get('SOLO_BENCH_BACKEND', 'nccl')
+  if os.environ.get('SOLO_BENCH_SHARE_GPU') == '1':
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   # under torch.distributed.run the collective path is exercised even with one rank
   distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or os.environ.get('SOLO_BENCH_FORCE_DIST') == '1'
@@ -214,8 +219,11 @@ def main():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29531')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    log("init_process_group('nccl') ok: world_size %d, backend %s, device cuda:%d" % (world, dist.get_backend(), local_rank))
+    if backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
+    log("init_process_group('%s') ok: world_size %d, backend %s, device cuda:%d" % (backend, world, dist.get_backend(), local_rank))
 
   dev = 'cuda:%d' % local_rank
   n, k, w = args.envs_per_gpu, args.steps, args.warmup

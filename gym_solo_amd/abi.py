@@ -7,7 +7,7 @@ as DATA (``SoloModel``/``SoloConfig``).
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NUM_LEGS = 4
 NUM_DOF = 8
 NUM_JOINTS = 12
@@ -64,6 +64,8 @@ class SoloModel(C.Structure):
     ('sphere_center', (C.c_double * 3) * MAX_SPHERES),
     ('sphere_radius', C.c_double * MAX_SPHERES),
     ('dof_to_joint', C.c_int32 * NUM_DOF),
+    ('joint_lower', C.c_double * NUM_DOF),
+    ('joint_upper', C.c_double * NUM_DOF),
   ]
 
 
@@ -82,6 +84,7 @@ class SoloConfig(C.Structure):
     ('restitution', C.c_double),
     ('contact_erp', C.c_double),
     ('contact_margin', C.c_double),
+    ('joint_limit_margin', C.c_double),
     ('solver_iterations', C.c_int32),
     ('settle_steps', C.c_int32),
     ('start_pos', C.c_double * 3),

@@ -52,6 +52,7 @@ class Solo8BaseConfig:
   motor_kd: float = 1.0           # pybullet POSITION_CONTROL default velocityGain [recalled]
   contact_erp: float = 0.2
   contact_margin: float = 0.005
+  joint_limit_margin: float = 0.5  # [rad] distance to a URDF joint limit below which its row is built
   settle_steps: int = 500         # gym_solo/envs/solo8v2vanilla.py:130
   auto_reset: bool = False
   steps_per_launch: int = 1       # rollouts fuse this many env steps per kernel launch
@@ -110,6 +111,7 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
   c.restitution = float(config.restitution)
   c.contact_erp = float(config.contact_erp)
   c.contact_margin = float(config.contact_margin)
+  c.joint_limit_margin = float(getattr(config, 'joint_limit_margin', 0.5))
   c.solver_iterations = int(config.solver_iterations)
   c.solver_ulp_tolerance = int(getattr(config, 'solver_ulp_tolerance', 2))
   if c.solver_ulp_tolerance < 0:

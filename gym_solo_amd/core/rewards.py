@@ -303,45 +303,44 @@ def tolerance(*args, **kwargs):
   return gaussian(*args, **kwargs)
 
 
-def gaussian(x, bounds: Tuple[float, float] = (0., 0.), margin: float = 0.,
-             margin_value: float = .1):
-  """rewards.py:384-431 — sloped reward about a bounds range; accepts scalars, numpy arrays
-  and torch tensors."""
-  lower, upper = bounds
-  _validate(lower, upper, margin, margin_value)
+def _namespace(x):
+  """(where, exp, ones_like, zeros_like) of the array library `x` belongs to."""
   if _is_tensor(x):
     import torch
-    within = (lower <= x) & (x <= upper)
-    one = torch.ones_like(x)
-    if margin == 0:
-      return torch.where(within, one, torch.zeros_like(x))
-    scale = math.sqrt(-2 * math.log(margin_value))
-    sigmas = torch.where(x < lower, lower - x, x - upper) / margin
-    values = torch.exp(-0.5 * (sigmas * scale) ** 2)
-    return torch.where(within, one, values)
+    return torch.where, torch.exp, torch.ones_like, torch.zeros_like
+  return np.where, np.exp, np.ones_like, np.zeros_like
 
-  within_bounds = np.logical_and(lower <= x, x <= upper)
+
+def gaussian(x, bounds: Tuple[float, float] = (0., 0.), margin: float = 0.,
+             margin_value: float = .1):
+  """Sloped reward about a bounds range (same contract as rewards.py:384-431): 1 inside
+  ``bounds``; outside, 0 when ``margin`` is 0, else a Gaussian of the distance d to the nearer
+  bound that equals ``margin_value`` at d = margin.  One code path for python scalars, numpy
+  arrays and torch tensors ``[N]`` (the kernel's ``tolerance()`` in csrc/solo_outputs.h is the
+  fused counterpart)."""
+  lower, upper = bounds
+  _validate(lower, upper, margin, margin_value)
+  scalar = np.isscalar(x)
+  xs = np.asarray(x, dtype=np.float64) if scalar else x
+  where, exp, ones, zeros = _namespace(xs)
+  inside = (lower <= xs) & (xs <= upper)
   if margin == 0:
-    value = np.where(within_bounds, 1., 0.)
+    outside_value = zeros(xs)
   else:
-    scale = np.sqrt(-2 * np.log(margin_value))
-    sigmas = np.where(x < lower, lower - x, x - upper) / margin
-    values = np.exp(-0.5 * (sigmas * scale) ** 2)
-    value = np.where(within_bounds, 1., values)
-  return float(value) if np.isscalar(x) else value
+    distance = where(xs < lower, lower - xs, xs - upper) / margin
+    outside_value = exp(-0.5 * (distance * math.sqrt(-2 * math.log(margin_value))) ** 2)
+  value = where(inside, ones(xs), outside_value)
+  return float(value) if scalar else value
 
 
 def linear(x: float, target: float, span: float, symmetric=False) -> float:
-  """rewards.py:434-461"""
+  """Triangular reward (same contract as rewards.py:434-461; no reward of the reference uses it):
+  1 at ``target``, falling linearly to 0 at ``target + span`` - and, when ``symmetric``, at
+  ``target - span`` too; a zero span leaves only the exact hit."""
+  offset = x - target
   if span == 0:
-    return 1. if x == target else 0.
-
-  x_delta = x - target
-  if abs(x_delta) > abs(span):
+    return 1. if offset == 0 else 0.
+  fraction = offset / span            # signed position inside the span
+  if abs(offset) > abs(span) or (fraction < 0 and not symmetric):
     return 0.
-
-  ratio = x_delta / span
-  if not symmetric and ratio < 0:
-    return 0
-
-  return 1 - abs(ratio)
+  return 1 - abs(fraction)

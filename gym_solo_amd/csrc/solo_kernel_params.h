@@ -20,8 +20,8 @@ namespace solo {
 //              4l+1 ride on leg l (knee, foot), 4l+2 and 4l+3 on the base.  Model sphere order ==
 //              ascending lane order, so "the touching spheres in solve order" is simply the set
 //              bits of the touching-lanes ballot, lowest first.
-//   k 14,15    idle
-enum RowType : int32_t { ROW_IDLE = 0, ROW_MOTOR = 1, ROW_NORMAL = 2, ROW_TAN1 = 3, ROW_TAN2 = 4 };
+//   k 14,15    joint-limit rows of the leg's HFE / KFE (the nearer limit; live only close to it)
+enum RowType : int32_t { ROW_IDLE = 0, ROW_MOTOR = 1, ROW_NORMAL = 2, ROW_TAN1 = 3, ROW_TAN2 = 4, ROW_LIMIT = 5 };
 enum BodyKind : int32_t { BODY_BASE = 0, BODY_UPPER = 1, BODY_LOWER = 2 };
 
 __host__ __device__ constexpr int motor_lane(int dof) { return 16 * (dof >> 1) + (dof & 1); }
@@ -33,6 +33,7 @@ struct LegConst {
   T knee[3];    // KFE joint origin in upper-leg frame
   T link[2][10];  // [0] upper leg, [1] lower leg + welded foot: mass, com[3] (link frame),
                   // inertia about com [6] (xx yy zz xy xz yz)
+  T limit[2][2];  // [HFE, KFE][lower, upper] URDF joint limits [rad]
 };
 
 template <typename T>
@@ -71,6 +72,7 @@ struct StepConst {
   T kp_over_dt, one_minus_kd, motor_impulse;
   T lin_damp, ang_damp;
   T erp_over_dt, margin;
+  T limit_margin;  // SoloConfig::joint_limit_margin
   T action_scale;
   // heightfield ground (SoloTerrain): 1/cell, origin; grid size below; heights live in KBuffers::terrain
   T terr_inv_cell, terr_ox, terr_oy;
@@ -135,6 +137,8 @@ inline int validate_model(const SoloModel& m, std::string* err) {
   for (int a = 0; a < 3; ++a)
     if (m.com[0][a] != 0.0) return fail("base frame must be the base CoM frame");
   if (m.num_spheres != SOLO_MAX_SPHERES) return fail("expected 16 collision spheres");
+  for (int j = 0; j < SOLO_NUM_DOF; ++j)
+    if (!(m.joint_lower[j] < m.joint_upper[j])) return fail("joint limits need lower < upper");
   for (int leg = 0; leg < 4; ++leg) {
     for (int s : {4 * leg, 4 * leg + 1})
       if (m.sphere_body[s] != 1 + 2 * leg && m.sphere_body[s] != 2 + 2 * leg)
@@ -158,6 +162,7 @@ inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) 
   k->c.ang_damp = (T)c.angular_damping;
   k->c.erp_over_dt = (T)(c.contact_erp / c.dt);
   k->c.margin = (T)c.contact_margin;
+  k->c.limit_margin = (T)c.joint_limit_margin;
   k->c.action_scale = (T)c.action_scale;
   k->c.iterations = c.solver_iterations;
   k->c.auto_reset = c.auto_reset;
@@ -177,11 +182,18 @@ inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) 
     L.link[0][0] = (T)m.mass[bu];
     L.link[1][0] = (T)m.mass[bl];
     for (int a = 0; a < 6; ++a) { L.link[0][4 + a] = (T)m.inertia[bu][a]; L.link[1][4 + a] = (T)m.inertia[bl][a]; }
+    L.limit[0][0] = (T)m.joint_lower[ju]; L.limit[0][1] = (T)m.joint_upper[ju];
+    L.limit[1][0] = (T)m.joint_lower[jl]; L.limit[1][1] = (T)m.joint_upper[jl];
   }
   for (int lane = 0; lane < 64; ++lane) k->row[lane].type = ROW_IDLE;
   for (int d = 0; d < SOLO_NUM_DOF; ++d) {
     RowConst<T>& r = k->row[motor_lane(d)];
     r.type = ROW_MOTOR;
+    r.dof = d;
+  }
+  for (int d = 0; d < SOLO_NUM_DOF; ++d) {
+    RowConst<T>& r = k->row[16 * (d >> 1) + 14 + (d & 1)];
+    r.type = ROW_LIMIT;
     r.dof = d;
   }
   for (int s = 0; s < SOLO_MAX_SPHERES; ++s)

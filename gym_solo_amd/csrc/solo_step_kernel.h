@@ -335,7 +335,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   SOLO_STAMP(B, 6);
   // ---- constraint rows: one per lane --------------------------------------------------------
   const int type = rc.type;
-  const bool is_motor = type == ROW_MOTOR, is_contact = type >= ROW_NORMAL;
+  const bool is_motor = type == ROW_MOTOR, is_contact = type >= ROW_NORMAL && type <= ROW_TAN2, is_limit = type == ROW_LIMIT;
   V3<T> cb = {rc.center[0], rc.center[1], rc.center[2]};
   if (rc.body == BODY_UPPER) cb = o1 + roty(c1, s1, cb);
   else if (rc.body == BODY_LOWER) cb = o2 + roty(c12, s12, cb);
@@ -375,7 +375,13 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     nloc = V3<T>{r00 * nw.x + r10 * nw.y + r20 * nw.z, r01 * nw.x + r11 * nw.y + r21 * nw.z, r02 * nw.x + r12 * nw.y + r22 * nw.z};
     d = V3<T>{r00 * dw.x + r10 * dw.y + r20 * dw.z, r01 * dw.x + r11 * dw.y + r21 * dw.z, r02 * dw.x + r12 * dw.y + r22 * dw.z};
   }
-  const bool live = is_motor || (is_contact && dist < C.margin);
+  // URDF joint limit of this lane's joint ([recalled] btMultiBodyJointLimitConstraint; k = 14: HFE,
+  // k = 15: KFE): distance to the NEARER limit, and the direction (+1 lower, -1 upper) that opens it
+  const int ldof = k & 1;
+  const T qlim = ldof == 0 ? q1 : q2;
+  const T c_lo = qlim - L.limit[ldof][0], c_hi = L.limit[ldof][1] - qlim;
+  const T lim_dir = c_lo < c_hi ? T(1) : T(-1), lim_dist = c_lo < c_hi ? c_lo : c_hi;
+  const bool live = is_motor || (is_contact && dist < C.margin) || (is_limit && lim_dist < C.limit_margin);
   const V3<T> x = cb - rc.radius * nloc;  // contact point in base coordinates
   T jb[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   T jl1 = T(0), jl2 = T(0), bias = T(0);
@@ -392,6 +398,12 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     jl2 = (k == 1) ? T(1) : T(0);
     const T qj = s_leg[leg][17 + k], uj = s_leg[leg][15 + k];
     bias = C.kp_over_dt * (my_target - qj) + C.one_minus_kd * uj;
+  } else if (is_limit) {
+    // speculative unilateral row, the same form as a contact normal row: v towards the limit
+    // <= distance / dt while inside, pushed back with the erp once violated
+    jl1 = (ldof == 0) ? lim_dir : T(0);
+    jl2 = (ldof == 1) ? lim_dir : T(0);
+    bias = (lim_dist > T(0)) ? -lim_dist * C.inv_dt : -C.erp_over_dt * lim_dist;
   }
   T gh[6], hh[2];
   {
@@ -431,6 +443,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   s_hext[lane][2 * leg] = hh[0];
   s_hext[lane][2 * leg + 1] = hh[1];
   const unsigned long long touching = wave_ballot(live && type == ROW_NORMAL);
+  const unsigned long long limited = wave_ballot(live && is_limit);
   wave_sync();
 
   SOLO_STAMP(B, 7);
@@ -451,6 +464,14 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     for (int l2 = 0; l2 < 4; ++l2) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) A.build(16 * l2 + kk);
+    }
+    if (limited != 0ull) {  // (a joint within reach of a limit is rare: one test for all eight rows)
+#pragma unroll
+      for (int l2 = 0; l2 < 4; ++l2) {
+#pragma unroll
+        for (int kk = 14; kk < 16; ++kk)
+          if ((limited >> (16 * l2 + kk)) & 1ull) A.build(16 * l2 + kk);
+      }
     }
 #pragma unroll
     for (int l2 = 0; l2 < 4; ++l2) {
@@ -476,14 +497,14 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   const T imp = C.motor_impulse;
   T lo = T(0), hi = T(0);
   if (is_motor) { lo = -imp; hi = imp; }
-  else if (live && type == ROW_NORMAL) hi = R::big();
+  else if (live && (type == ROW_NORMAL || is_limit)) hi = R::big();
   T lamv = T(0);
   T v = live ? w * nid : T(0);  // lam = 0
   const T tol_rel = T(wave_uniform(C.ulp_tol)) * R::half_ulp();
   const int iters = wave_uniform(C.iterations);  // scalar trip count
   // rows of one sweep, in solver order ([recalled] btMultiBodyConstraintSolver::solveSingleIteration):
-  // the joint motors, then ALL normal contact rows, then ALL friction rows
-  constexpr unsigned long long kPhaseLanes[3] = {0x0003000300030003ull,    // motors   k = 0, 1 of each leg
+  // the non-contact rows (joint motors, joint limits), then ALL normal contact rows, then ALL friction rows
+  constexpr unsigned long long kPhaseLanes[3] = {0xc003c003c003c003ull,    // motors k = 0, 1 and joint limits k = 14, 15, leg by leg
                                                  0x0924092409240924ull,    // normals  k = 2, 5, 8, 11
                                                  0x36d836d836d836d8ull};   // friction k = 3, 4, 6, 7, 9, 10, 12, 13
   const bool is_tangent = type == ROW_TAN1 || type == ROW_TAN2;

@@ -176,24 +176,21 @@ class Solo8VanillaEnv(Solo8BaseEnv):
       return obs_values
 
   def load_bodies(self):
-    """solo8v2vanilla.py:145-172"""
-    robot_id = self.client.loadURDF(
-      'solo8v2/solo.urdf', self.config.robot_start_pos,
-      self.client.getQuaternionFromEuler(self.config.robot_start_orientation_euler),
-      flags=p.URDF_USE_INERTIA_FROM_FILE, useFixedBase=False)
-
-    self._joint_cnt = self.client.getNumJoints(robot_id)
+    """Counterpart of solo8v2vanilla.py:145-172 on the batched client: the robot at the configured
+    start pose with inertias from the file, the four dynamics parameters applied to every joint's
+    link, and the 12-joint action box.  (The facade validates these calls against the engine's
+    compiled configuration; a differing lateral friction becomes the per-env parameter row.)"""
+    cfg, client = self.config, self.client
+    self.robot = client.loadURDF('solo8v2/solo.urdf', cfg.robot_start_pos,
+                                 client.getQuaternionFromEuler(cfg.robot_start_orientation_euler),
+                                 flags=p.URDF_USE_INERTIA_FROM_FILE, useFixedBase=False)
+    self._joint_cnt = client.getNumJoints(self.robot)
+    dynamics = dict(linearDamping=cfg.linear_damping, angularDamping=cfg.angular_damping,
+                    restitution=cfg.restitution, lateralFriction=cfg.lateral_friction)
+    self.joint_ordering = []
     for joint in range(self._joint_cnt):
-      self.client.changeDynamics(robot_id, joint,
-                                 linearDamping=self.config.linear_damping,
-                                 angularDamping=self.config.angular_damping,
-                                 restitution=self.config.restitution,
-                                 lateralFriction=self.config.lateral_friction)
-
-    self.robot = robot_id
+      client.changeDynamics(self.robot, joint, **dynamics)
+      self.joint_ordering.append(client.getJointInfo(self.robot, joint)[1].decode('UTF-8'))
     self._zero_gains = np.zeros(self._joint_cnt)
-    self.joint_ordering = [self.client.getJointInfo(self.robot, j)[1].decode('UTF-8')
-                           for j in range(self._joint_cnt)]
-    self._action_space = spaces.Box(-self.config.max_motor_rotation,
-                                    self.config.max_motor_rotation,
+    self._action_space = spaces.Box(-cfg.max_motor_rotation, cfg.max_motor_rotation,
                                     shape=(self._joint_cnt,))

@@ -162,6 +162,10 @@ class Solo8Model:
         out.append((0, np.array([sx * hx, sy * hy, sz * hz]), self.base_sphere_radius))
     return out
 
+  def joint_limits(self):
+    """(lower, upper) [rad] per dof: the fixture's -10 / +10 (test_obs_observations.py:123-162)."""
+    return [(-JOINT_LIMIT, JOINT_LIMIT)] * abi.NUM_DOF
+
   # ---- flattened for the C-ABI -----------------------------------------------------
   def to_abi(self) -> abi.SoloModel:
     return model_to_abi(self)
@@ -197,6 +201,9 @@ def model_to_abi(model) -> abi.SoloModel:
       put6(m.inertia[b], li.inertia)
     m.dof_to_joint[ju] = DOF_TO_JOINT[ju]
     m.dof_to_joint[jl] = DOF_TO_JOINT[jl]
+    limits = model.joint_limits() if hasattr(model, 'joint_limits') else [(-JOINT_LIMIT, JOINT_LIMIT)] * abi.NUM_DOF
+    for j in (ju, jl):
+      m.joint_lower[j], m.joint_upper[j] = float(limits[j][0]), float(limits[j][1])
   sph = model.spheres()
   if len(sph) != abi.MAX_SPHERES:
     raise ValueError('the engine expects {} collision spheres'.format(abi.MAX_SPHERES))

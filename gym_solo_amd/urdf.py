@@ -114,6 +114,19 @@ class UrdfSolo8Model:
         out[4 * leg + 1] = (2 + 2 * leg, self.ankle_origin(leg), out[4 * leg + 1][2])
     return out
 
+  def joint_limits(self):
+    """<limit lower= upper=> of the eight revolute joints, dof order (continuous joints or missing
+    limits: the built-in +-10 rad of the reference's fixture)."""
+    out = list(self._fallback.joint_limits())
+    for leg in range(abi.NUM_LEGS):
+      for d, jn in enumerate((LEGS[leg] + '_HFE', LEGS[leg] + '_KFE')):
+        lim = self._joints[jn].get('limit')
+        if lim is not None and self._joints[jn]['type'] == 'revolute':
+          if not lim[0] < lim[1]:
+            raise ValueError('joint {}: limit lower must be below upper'.format(jn))
+          out[2 * leg + d] = lim
+    return out
+
   def to_abi(self):
     return model_to_abi(self)
 
@@ -147,7 +160,9 @@ def parse_urdf(text, fallback=None) -> UrdfSolo8Model:
       'type': el.get('type'), 'parent': el.find('parent').get('link'), 'child': el.find('child').get('link'),
       'xyz': _floats(org.get('xyz') if org is not None else None, 3, (0, 0, 0)),
       'rpy': _floats(org.get('rpy') if org is not None else None, 3, (0, 0, 0)),
-      'axis': _floats(ax.get('xyz') if ax is not None else None, 3, (1, 0, 0))}
+      'axis': _floats(ax.get('xyz') if ax is not None else None, 3, (1, 0, 0)),
+      'limit': (None if el.find('limit') is None or el.find('limit').get('lower') is None else
+                (float(el.find('limit').get('lower')), float(el.find('limit').get('upper'))))}
   return UrdfSolo8Model(links, joints, fallback)
 
 

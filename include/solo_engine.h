@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SOLO_ABI_VERSION 1
+#define SOLO_ABI_VERSION 2  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets */
 
 /* ---- fixed Solo8 dimensions -------------------------------------------- */
 #define SOLO_NUM_LEGS 4
@@ -94,6 +94,11 @@ typedef struct SoloModel {
   double sphere_radius[SOLO_MAX_SPHERES];
   /* dof j <-> pybullet joint index (for getJointState facade), and the 12 names */
   int32_t dof_to_joint[SOLO_NUM_DOF];
+  /* URDF joint limits [rad] (the reference's getJointInfo fixture pins -10 / +10,
+   * gym_solo/core/test_obs_observations.py:123-162 columns 8-9): unilateral rows next to the motors
+   * ([recalled] btMultiBodyJointLimitConstraint).  lower < upper required. */
+  double joint_lower[SOLO_NUM_DOF];
+  double joint_upper[SOLO_NUM_DOF];
 } SoloModel;
 
 /* ---- physics / env configuration (gym_solo/core/configs.py:8-38) -------- */
@@ -111,6 +116,8 @@ typedef struct SoloConfig {
   double restitution;        /* configs.py:23 (0; only 0 is supported) */
   double contact_erp;        /* penetration recovery rate (Bullet erp2 0.2 [recalled]) */
   double contact_margin;     /* spheres closer than this to the ground create rows */
+  double joint_limit_margin; /* a joint closer than this [rad] to one of its limits gets that limit's row
+                                (a speculative unilateral row: exact as long as |qd| dt < margin) */
   int32_t solver_iterations; /* Bullet default 50 [recalled] */
   int32_t settle_steps;      /* solo8v2vanilla.py:130 (500) */
   double start_pos[3];       /* configs.py:15 */

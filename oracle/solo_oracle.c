@@ -33,7 +33,7 @@
 #define NB SOLO_NUM_BODIES
 #define ND SOLO_NUM_DOF
 #define NV SOLO_NV
-#define MAXROWS (ND + 3 * SOLO_MAX_SPHERES)
+#define MAXROWS (2 * ND + 3 * SOLO_MAX_SPHERES)
 
 /* ------------------------------------------------------------------ 3-vectors */
 static void v3cross(const double a[3], const double b[3], double o[3]) {
@@ -390,6 +390,7 @@ typedef struct {
   double lo[MAXROWS], hi[MAXROWS];
   int normal_row[MAXROWS]; /* >=0: friction row limited by mu * lambda[normal_row] */
   int sphere[MAXROWS];
+  int leg[MAXROWS];        /* non-contact rows: the leg they belong to (solve order), else -1 */
   double mu;
 } Rows;
 
@@ -448,7 +449,22 @@ static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const SoloTe
                 (1.0 - cfg->motor_kd) * ustar[6 + j];
     R->lo[r] = -cfg->motor_torque_limit * cfg->dt;
     R->hi[r] = cfg->motor_torque_limit * cfg->dt;
-    R->normal_row[r] = -1; R->sphere[r] = -1;
+    R->normal_row[r] = -1; R->sphere[r] = -1; R->leg[r] = j / 2;
+  }
+  /* URDF joint limits ([recalled] btMultiBodyJointLimitConstraint; the reference's fixture pins
+   * -10 / +10 rad, test_obs_observations.py:123-162 cols 8-9): a unilateral row on the nearer limit
+   * once it is closer than joint_limit_margin, in the speculative form of a contact normal row:
+   * v_towards_limit <= C/dt while C > 0, pushed back with the erp once violated */
+  for (int j = 0; j < ND; ++j) {
+    const double q = st[SOLO_S_Q + j];
+    const double c_lo = q - mdl->joint_lower[j], c_hi = mdl->joint_upper[j] - q;
+    const double s = c_lo < c_hi ? 1.0 : -1.0, c = c_lo < c_hi ? c_lo : c_hi;
+    if (!(c < cfg->joint_limit_margin)) continue;
+    int r = R->n++;
+    memset(R->J[r], 0, sizeof R->J[r]);
+    R->J[r][6 + j] = s;
+    R->rhs[r] = (c > 0) ? -c / cfg->dt : -cfg->contact_erp * c / cfg->dt;
+    R->lo[r] = 0; R->hi[r] = INFINITY; R->normal_row[r] = -1; R->sphere[r] = -1; R->leg[r] = j / 2;
   }
   /* sphere vs the tangent plane of the ground under its centre */
   for (int s = 0; s < mdl->num_spheres; ++s) {
@@ -469,12 +485,12 @@ static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const SoloTe
     point_jacobian(mdl, k, b, x, n, R->J[rn]);
     /* non-penetration: v_n >= -dist/dt if separated (speculative), else push out with erp */
     R->rhs[rn] = (dist > 0) ? -dist / cfg->dt : -cfg->contact_erp * dist / cfg->dt;
-    R->lo[rn] = 0; R->hi[rn] = INFINITY; R->normal_row[rn] = -1; R->sphere[rn] = s;
+    R->lo[rn] = 0; R->hi[rn] = INFINITY; R->normal_row[rn] = -1; R->sphere[rn] = s; R->leg[rn] = -1;
     const double* td[2] = {t1, t2};
     for (int q = 0; q < 2; ++q) {
       int rt = R->n++;
       point_jacobian(mdl, k, b, x, td[q], R->J[rt]);
-      R->rhs[rt] = 0; R->lo[rt] = 0; R->hi[rt] = 0; R->normal_row[rt] = rn; R->sphere[rt] = s;
+      R->rhs[rt] = 0; R->lo[rt] = 0; R->hi[rt] = 0; R->normal_row[rt] = rn; R->sphere[rt] = s; R->leg[rt] = -1;
     }
   }
 }
@@ -544,7 +560,9 @@ int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, co
    * non-contact rows (joint motors), then ALL normal contact rows, then ALL friction rows - each
    * friction row limited by mu x the normal impulse its contact holds at that moment */
   int order[MAXROWS], no = 0;
-  for (int r = 0; r < R.n; ++r) if (R.sphere[r] < 0) order[no++] = r;
+  /* (non-contact rows leg by leg: a leg's two motors, then its joint-limit rows) */
+  for (int leg = 0; leg < 4; ++leg)
+    for (int r = 0; r < R.n; ++r) if (R.sphere[r] < 0 && R.leg[r] == leg) order[no++] = r;
   for (int r = 0; r < R.n; ++r) if (R.sphere[r] >= 0 && R.normal_row[r] < 0) order[no++] = r;
   for (int r = 0; r < R.n; ++r) if (R.sphere[r] >= 0 && R.normal_row[r] >= 0) order[no++] = r;
   for (int it = 0; it < cfg->solver_iterations; ++it)

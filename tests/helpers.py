@@ -50,3 +50,24 @@ def trench_terrain(half=0.04, slope=4.0, n=96, cell=0.01):
   ys = (np.arange(n) - 0.5 * (n - 1)) * cell
   h = np.clip((np.abs(ys) - half) * slope, 0.0, 0.5)
   return abi.make_terrain(np.tile(h[:, None], (1, n)), cell)
+
+
+def joint_limit_case(ph, n=4, seed=0):
+  """States that drive joints into their URDF limits (+-10 rad, the reference's getJointInfo fixture,
+  gym_solo/core/test_obs_observations.py:123-162 columns 8-9): a settled robot lifted into the air
+  with some joints placed 0.02 ... 0.2 rad inside a limit and moving towards it at 5 ... 60 rad/s, the
+  motors commanding a target BEYOND the limit (12 rad, as a caller with a mutated max_motor_rotation
+  can, test_solo8v2vanilla.py:110).  Returns (state [n, 32], targets [n, 12])."""
+  from gym_solo_amd import abi
+  rng = np.random.default_rng(seed)
+  st = np.tile(ph.settle(1), (n, 1))
+  st[:, abi.S_POS + 2] = 0.6
+  tg = np.zeros((n, abi.NUM_JOINTS))
+  for e in range(n):
+    for d in range(abi.NUM_DOF):
+      if rng.random() < 0.6:
+        s = 1.0 if rng.random() < 0.5 else -1.0
+        st[e, abi.S_Q + d] = s * (10.0 - rng.uniform(0.02, 0.2))
+        st[e, abi.S_QD + d] = s * rng.uniform(5.0, 60.0)
+        tg[e, 3 * (d // 2) + d % 2] = s * 12.0
+  return st, tg

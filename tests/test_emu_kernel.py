@@ -192,3 +192,23 @@ def test_all_sixteen_spheres_in_contact():
     e.step(a, abi.STEP_PHYSICS)
     np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=1e-9, atol=1e-9, err_msg='step %d' % k)
   assert max(contacts) == 16
+
+
+@pytest.mark.parametrize('dtype,tol', [('float64', 1e-10), ('float32', 2e-3)])
+def test_joint_limit_rows_match_oracle(dtype, tol):
+  """URDF joint limits as unilateral rows on lanes k = 14, 15 ([recalled]
+  btMultiBodyJointLimitConstraint): joints driven into +-10 rad stop there, emulator == oracle."""
+  from helpers import joint_limit_case
+  ca, ma = make_abi(dtype)
+  ph = so.OraclePhysics(ca, ma)
+  st, tg = joint_limit_case(ph, n=3)
+  e = EmuEngine(ca, ma, 3)
+  e.state[:] = st
+  hit = np.zeros(st.shape[0], dtype=bool)
+  for k in range(25):
+    ph.step(st, tg)
+    e.step(tg, abi.STEP_PHYSICS)
+    assert np.abs(st[:, abi.S_Q:abi.S_Q + 8]).max() <= 10.0 + 1e-9
+    hit |= (np.abs(st[:, abi.S_Q:abi.S_Q + 8]) > 10.0 - 1e-9).any(axis=1)
+  assert hit.all()   # every robot has a joint sitting ON its limit
+  np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=tol)
