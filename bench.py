@@ -138,14 +138,15 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
   if not valu:
     return 'dependent-issue-latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype'
   cyc = VALU_CYCLES_SHARED if waves_per_simd >= 2 else VALU_CYCLES_ALONE
-  simd_cycles = NUM_SIMDS * kern_ms * 1e-3 * SHADER_CLOCK_HZ
+  clock = pmc.get('effective_clock_hz') or SHADER_CLOCK_HZ  # measured (GRBM_GUI_ACTIVE / 8 / wall) when profiled
+  simd_cycles = NUM_SIMDS * kern_ms * 1e-3 * clock
   util = chains * valu * env_steps_per_launch * cyc / simd_cycles
   return ('latency bound, not HBM bound: %.0f VALU instructions per env-step (rocprofv3 --pmc SQ_INSTS_VALU, '
           'profiles/pmc_traffic.json) x %d cycles (wave64 on a SIMD-32 shared by %.0f waves, MI355X_MICROARCH.md) x %d '
           'env-steps x %d concurrent launch chains = %.2f of the %d SIMDs\' VALU issue capacity over the measured launch '
           'duration at %.1f GHz; the rest is dependent-instruction latency of one wave per robot (a Gauss-Seidel row '
           'update is a ~20-instruction serial chain) and the launch waiting for its slowest robot (profiles/README.md)'
-          % (valu, cyc, waves_per_simd, env_steps_per_launch, chains, util, NUM_SIMDS, SHADER_CLOCK_HZ / 1e9))
+          % (valu, cyc, waves_per_simd, env_steps_per_launch, chains, util, NUM_SIMDS, clock / 1e9))
 
 
 def free_port():

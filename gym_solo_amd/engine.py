@@ -27,6 +27,10 @@ def load_library(path=_LIB_PATH):
     raise EngineError(
       'HIP engine library not found at {} — build it with `make -C gym_solo_amd/csrc` or '
       '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback.'.format(path))
+  # torch first: it carries its own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm's), and
+  # the process must end up with ONE HIP runtime - the one whose streams and tensors the engine is
+  # handed.  Loaded the other way round, the second runtime sees no device.
+  import torch  # noqa: F401
   lib = C.CDLL(path)
   abi.bind(lib)
   if lib.solo_abi_version() != abi.ABI_VERSION:

@@ -46,6 +46,9 @@ out = {'float32': {
                                        ('wait_inst_lds', 'SQ_WAIT_INST_LDS')) if c in s},
   'step_kernel_busy_cycles': s.get('SQ_BUSY_CYCLES'), 'step_kernel_wave_cycles': wave_cycles, 'step_kernel_waves': s.get('SQ_WAVES'),
   'grbm_gui_active_per_launch': s.get('GRBM_GUI_ACTIVE'),
+  # MI355X_MICROARCH.md (DVFS): effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time (same pass)
+  'effective_clock_hz': (s['GRBM_GUI_ACTIVE'] / 8.0 / (s['_duration_ns_under_pmc'] * 1e-9)) if s.get('GRBM_GUI_ACTIVE') else None,
+  'step_kernel_ms_under_pmc_serialised': s.get('_duration_ns_under_pmc', 0) * 1e-6,
   'traffic_note': 'measured HBM bytes per env-step (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, '
                   'KB x 1024, step + outputs + returns kernels of one fused launch of %d robots x %d steps) x this run\'s '
                   'env-steps per launch; raw FETCH_SIZE (dword-per-lane loads: uncalibrated width; with the guide\'s 2x '
