@@ -248,6 +248,7 @@ def pybullet_joint_info(model: Solo8Model = None) -> List[tuple]:
   parentFrameOrn = quat(Rp_child^T Rp_parent)  [field meaning recalled from the pybullet
   quickstart guide; verified against the fixture numerically]."""
   model = model or Solo8Model()
+  limits = model.joint_limits() if hasattr(model, 'joint_limits') else [(-JOINT_LIMIT, JOINT_LIMIT)] * abi.NUM_DOF
   out = []
   for leg in range(abi.NUM_LEGS):
     up, lo, ft = model.upper(leg), model.lower(leg), model.foot(leg)
@@ -267,7 +268,8 @@ def pybullet_joint_info(model: Solo8Model = None) -> List[tuple]:
       dof = JOINT_TO_DOF.get(idx)
       q_index = 7 + dof if revolute else -1
       u_index = 6 + dof if revolute else -1
+      lower, upper = limits[dof] if revolute else (-JOINT_LIMIT, JOINT_LIMIT)
       out.append((idx, JOINT_NAMES[idx].encode(), jtype, q_index, u_index, 1 if revolute else 0,
-                  0.0, 0.0, -JOINT_LIMIT, JOINT_LIMIT, JOINT_MAX_FORCE, JOINT_MAX_VEL,
+                  0.0, 0.0, float(lower), float(upper), JOINT_MAX_FORCE, JOINT_MAX_VEL,
                   LINK_NAMES[idx].encode(), axis, pos, orn, parent_idx))
   return out

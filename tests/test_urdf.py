@@ -45,3 +45,17 @@ def test_modified_urdf_changes_the_model_and_bad_urdfs_are_rejected():
     parse_urdf(text.replace('name="HR_ANKLE" type="fixed"', 'name="HR_ANKLE" type="revolute"'))
   with pytest.raises(ValueError):
     parse_urdf(text.replace('FL_KFE', 'FL_KNEE'))
+
+
+def test_joint_limits_come_from_the_urdf():
+  """<limit lower upper> of the revolute joints -> SoloModel.joint_lower / joint_upper (the fixture's
+  -10 / +10 rad, gym_solo/core/test_obs_observations.py:123-162 columns 8-9, when the file says so)."""
+  text = to_urdf()
+  m = parse_urdf(text).to_abi()
+  assert list(m.joint_lower) == [-10.0] * 8 and list(m.joint_upper) == [10.0] * 8
+  tight = text.replace('<limit lower="-10" upper="10" effort="1000" velocity="1000"/>',
+                       '<limit lower="-1.5" upper="2.5" effort="1000" velocity="1000"/>', 1)
+  m = parse_urdf(tight).to_abi()
+  assert (m.joint_lower[0], m.joint_upper[0]) == (-1.5, 2.5) and m.joint_lower[1] == -10.0
+  with pytest.raises(ValueError):
+    parse_urdf(text.replace('lower="-10" upper="10"', 'lower="3" upper="-3"', 1)).to_abi()

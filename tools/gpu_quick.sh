@@ -11,8 +11,8 @@ for args in "" "--rollout-streams 1" "--steps-per-launch 1 --rollout-streams 1";
 done
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_q
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc_q -- python3 $R/tools/prof_driver.py > $R/gpurun_out/pmc_q.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc_q -- python3 $R/tools/prof_driver.py $R/gpurun_out/pmc_q_meta.json > $R/gpurun_out/pmc_q.log 2>&1
 cd $R && python tools/pmc_summary.py gpurun_out/pmc_q.json gpurun_out/pmc_q | python -c "
 import sys, json
-d = json.load(sys.stdin); n = 204800.0
+d = json.load(sys.stdin)['step']; m = json.load(open('gpurun_out/pmc_q_meta.json')); n = float(m['robots_per_launch'] * m['steps_per_launch'])
 print('per env-step: VALU %.0f  SALU %.0f  LDS %.0f' % (d['SQ_INSTS_VALU'] / n, d['SQ_INSTS_SALU'] / n, d['SQ_INSTS_LDS'] / n))"
