@@ -175,3 +175,29 @@ def test_joint_limit_rows_match_oracle_gpu(torch):
   np.testing.assert_allclose(eng.state.cpu().numpy()[:, :29], st[:, :29], rtol=0, atol=1e-9)
   assert float(e32.state[:, abi.S_Q:abi.S_Q + 8].abs().max()) <= 10.0 + 1e-5
   eng.close(); e32.close()
+
+
+def test_engines_are_freed_without_close_and_guard_after_close(torch):
+  """Engine lifetime: an Engine that is never close()d is collected (its zero-copy views hold no
+  reference back to it) and its device buffers are freed; after close() the C-ABI calls raise
+  instead of touching freed memory."""
+  import gc
+  from gym_solo_amd.engine import Engine, EngineError
+  ca, ma = make_abi('float32', steps_per_launch=250, settle_steps=2)
+  gc.collect(); torch.cuda.synchronize()
+  free0, _ = torch.cuda.mem_get_info()
+  for _ in range(12):                       # ~150 MB each (state, traj [250][4096][32], scratch)
+    eng = Engine(ca, ma, 4096)
+    view = eng.state                        # a zero-copy view handed out
+    del view
+    del eng
+    gc.collect()
+  torch.cuda.synchronize()
+  free1, _ = torch.cuda.mem_get_info()
+  assert free0 - free1 < 200 * 2 ** 20, 'engines leaked: %d MiB' % ((free0 - free1) >> 20)
+  eng = Engine(ca, ma, 8)
+  eng.close()
+  assert eng.is_closed and eng.state is None
+  with pytest.raises(EngineError):
+    eng.step(None, abi.STEP_PHYSICS)
+  eng.close()  # idempotent
