@@ -1,6 +1,8 @@
+"""DIAGNOSTIC: host-call / device segments of the driver's 20-step rollout (K = 20, one fused launch per
+slice) in a tight repeat loop, for 1 / 2 / 4 stream slices."""
 import sys, os, time
-ROOT='/root/repo' if os.path.exists('/root/repo/bench.py') else os.environ.get('GRAFT_REPO_ROOT','.')
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch, numpy as np
 from bench import build_env
 from gym_solo_amd import abi
