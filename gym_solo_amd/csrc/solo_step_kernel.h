@@ -519,12 +519,14 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
     // (the register banks of the matrix are walked one after the other - static bank per loop - which
     // keeps the rows of a phase in ascending lane order)
+    bool normals_moved = false;  // (wave-uniform)
 #pragma unroll
     for (int phase = 0; phase < 3; ++phase) {
-      if (phase == 2) {
+      if (phase == 2 && normals_moved) {
         // the friction rows of a contact are limited by mu x the normal impulse it holds NOW: the
         // normal rows are done for this sweep, so all limits are refreshed at once (a friction
         // row's normal row sits one or two lanes below it: DPP row shifts) instead of per moved row
+        // - and only in a sweep that moved a normal row (all limits start at mu x 0 = 0)
         const T n1 = wave_lane_below<1>(lamv), n2 = wave_lane_below<2>(lamv);
         const T lim = mu * (type == ROW_TAN1 ? n1 : n2);
         lo = is_tangent ? -lim : lo;
@@ -533,6 +535,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
         dl = cand - lamv;
         pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
       }
+      if ((pend & kPhaseLanes[phase]) == 0ull) continue;  // nothing of this phase moves: one test for its banks
+      if (phase == 1) normals_moved = true;
 #pragma unroll
       for (int bank = 0; bank < ColumnBank<T>::kBanks; ++bank) {
         unsigned long long window = kPhaseLanes[phase] & ColumnBank<T>::bank_lanes(bank);
@@ -664,7 +668,6 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_hext[64][8];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][20];
-  __shared__ T s_val[SOLO_MAX_REWARD_OPS];  // reward program values of an inline evaluation (single-step launches)
   __shared__ int s_cnt[SOLO_MAX_TERMS];     // TimeBased step counters (termination.py:72-83)
   // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
   // read them from LDS instead of paying a global-load latency each
@@ -805,18 +808,25 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
       if (B.obs_inline != nullptr && lane < n_obs)
         B.obs_inline[(size_t)env * n_obs + lane] = observation_value<T>(P0->obs[lane], s_state, roll, pitch, yaw);
       if (B.reward_inline != nullptr) {
-        if (lane < n_rops) {
-          const RewardInstrK<T> r = P0->reward[lane];
-          if (reward_is_leaf(r.op)) s_val[lane] = reward_leaf<T>(r, s_state, roll, pitch);
+        // lane i holds instruction i and its value: the leaves are evaluated lane-parallel, the
+        // combining instructions (SCALE / ADD / MUL over earlier values, three-address form) in
+        // program order with wave-uniform v_readlane broadcasts - no LDS, and no chain of dependent
+        // scalar loads of the program on lane 0 (~14 x 250 cycles at the end of every closed-loop step)
+        RewardInstrK<T> ri;
+        ri.op = SOLO_R_CONST; ri.src = 0; ri.a = ri.b = ri.c = ri.d = T(0);
+        if (lane < n_rops) ri = P0->reward[lane];
+        T myval = reward_is_leaf(ri.op) ? reward_leaf<T>(ri, s_state, roll, pitch) : T(0);
+        for (int i = 0; i < n_rops; ++i) {
+          const int op = wave_readlane_int(ri.op, i);
+          if (reward_is_leaf(op)) continue;                      // (wave-uniform)
+          const int src = wave_readlane_int(ri.src, i);
+          const T x0 = wave_readlane(myval, src & 255), x1 = wave_readlane(myval, (src >> 8) & 255);
+          const T res = op == SOLO_R_SCALE ? wave_readlane(ri.a, i) * x0 : (op == SOLO_R_ADD ? x0 + x1 : x0 * x1);
+          myval = (lane == i) ? res : myval;
         }
-        wave_sync();
+        const T reward_value = wave_readlane(myval, n_rops - 1);
         if (lane == 0) {
-          T r = T(0);
-          for (int i = 0; i < n_rops; ++i) {
-            const RewardInstrK<T>& ri = P0->reward[i];
-            if (!reward_is_leaf(ri.op)) s_val[i] = reward_combine<T>(ri, s_val, 1);
-            r = s_val[i];
-          }
+          const T r = reward_value;
           B.reward_inline[env] = r;
           if (B.flags & SOLO_STEP_DONE) {
             // episodic return / length live in the record's slots 29, 30: loaded with the state in the
