@@ -176,6 +176,7 @@ class SoloStateView(C.Structure):
     ('term_count', C.c_void_p),
     ('params', C.c_void_p),
     ('stats', C.c_void_p),
+    ('cost', C.c_void_p),
   ]
 
 
@@ -195,6 +196,7 @@ ENTRY_POINTS = {
   'solo_engine_get_view': (C.c_int, [C.c_void_p, C.POINTER(SoloStateView)]),
   'solo_engine_set_params': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
   'solo_engine_set_terrain': (C.c_int, [C.c_void_p, C.POINTER(SoloTerrain), C.c_void_p]),
+  'solo_engine_set_order': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
   'solo_engine_kernel_name': (C.c_char_p, [C.c_void_p]),
   'solo_engine_time_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
                                       C.c_void_p, C.POINTER(C.c_double)]),

@@ -28,6 +28,7 @@ struct EngineBase {
   virtual int view(SoloStateView* v) = 0;
   virtual int set_params(int which, const void* p, hipStream_t s) = 0;
   virtual int set_terrain(const SoloTerrain* t, hipStream_t s) = 0;
+  virtual int set_order(const int32_t* order, hipStream_t s) = 0;
   virtual int time_step(const void* a, uint32_t flags, int reps, hipStream_t s, double* ms) = 0;
   virtual const char* kernel_name() = 0;
   std::string err;
@@ -61,6 +62,8 @@ struct Engine final : EngineBase {
   bool skip_outputs = false;  // time_step: the step kernel alone
   uint8_t* done = nullptr;
   int32_t* term_count = nullptr;
+  int32_t *order = nullptr, *cost = nullptr;  // launch order (null = identity), per-robot sweeps of the last launch
+  bool use_order = false;
   double* stats = nullptr;
   T* terrain = nullptr;
 #ifdef SOLO_STAMPS
@@ -76,7 +79,7 @@ struct Engine final : EngineBase {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : {(void*)dparams, (void*)state, (void*)snapshot, (void*)targets, (void*)params,
                     (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
-                    (void*)term_count, (void*)stats, (void*)terrain, (void*)traj, (void*)reward_scratch, (void*)events})
+                    (void*)term_count, (void*)order, (void*)cost, (void*)stats, (void*)terrain, (void*)traj, (void*)reward_scratch, (void*)events})
       if (p) (void)hipFree(p);
   }
 
@@ -97,6 +100,9 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMalloc((void**)&done, (size_t)n));
     HIP_TRY(hipMalloc((void**)&term_count, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&stats, kStatsBytes));
+    HIP_TRY(hipMalloc((void**)&order, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&cost, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(hipMemset(cost, 0, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&traj, (size_t)spl() * ns * sizeof(T)));
     HIP_TRY(hipMalloc((void**)&reward_scratch, (size_t)spl() * n * sizeof(T)));
     HIP_TRY(hipMalloc((void**)&events, (size_t)spl() * n));
@@ -128,7 +134,7 @@ struct Engine final : EngineBase {
     solo::KBuffers<T> b;
     b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
     b.params = params; b.traj = nullptr; b.events = events; b.obs_inline = b.reward_inline = nullptr; b.done = done; b.term_count = term_count;
-    b.stats = stats; b.terrain = terrain; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
+    b.stats = stats; b.terrain = terrain; b.order = use_order ? order : nullptr; b.cost = cost; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
     b.action_stride = b.done_stride = 0;
 #ifdef SOLO_STAMPS
     b.stamps = stamps;
@@ -400,13 +406,21 @@ struct Engine final : EngineBase {
     return settle(s);
   }
 
+  int set_order(const int32_t* o, hipStream_t s) override {
+    HIP_TRY(hipSetDevice(device));
+    if (o == nullptr) { use_order = false; return SOLO_OK; }
+    HIP_TRY(hipMemcpyAsync(order, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    use_order = true;
+    return SOLO_OK;
+  }
+
   int view(SoloStateView* v) override {
     v->num_envs = n;
     v->dtype = sizeof(T) == 4 ? SOLO_F32 : SOLO_F64;
     v->state_stride = SOLO_STATE_STRIDE;
     v->obs_dim = obs_dim;
     v->state = state; v->snapshot = snapshot; v->targets = targets; v->obs = obs; v->reward = reward;
-    v->done = done; v->term_count = term_count; v->params = params; v->stats = stats;
+    v->done = done; v->term_count = term_count; v->params = params; v->stats = stats; v->cost = cost;
     return SOLO_OK;
   }
 
@@ -518,6 +532,7 @@ int solo_engine_get_view(SoloEngine* eng, SoloStateView* out) {
 }
 int solo_engine_set_params(SoloEngine* eng, int32_t which, const void* p, void* stream) { return ENG_CALL(set_params(which, p, (hipStream_t)stream)); }
 int solo_engine_set_terrain(SoloEngine* eng, const SoloTerrain* t, void* stream) { return ENG_CALL(set_terrain(t, (hipStream_t)stream)); }
+int solo_engine_set_order(SoloEngine* eng, const int32_t* o, void* stream) { return ENG_CALL(set_order(o, (hipStream_t)stream)); }
 const char* solo_engine_kernel_name(SoloEngine* eng) { return eng && eng->impl ? eng->impl->kernel_name() : ""; }
 int solo_engine_time_step(SoloEngine* eng, const void* a, uint32_t flags, int32_t reps, void* stream, double* ms) {
   return ENG_CALL(time_step(a, flags, reps, (hipStream_t)stream, ms));

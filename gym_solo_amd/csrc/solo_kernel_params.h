@@ -110,6 +110,8 @@ struct KBuffers {
   int32_t* term_count;  // [N][4]
   double* stats;      // [SOLO_STATS_SHARDS][8]
   const T* terrain;   // [ny][nx] heights, or null = flat plane z = 0
+  const int32_t* order;  // [N] workgroup -> robot (solo_engine_set_order), or null = identity
+  int32_t* cost;      // [N] Gauss-Seidel sweeps of the robot in this launch, or null
   int32_t num_envs;    // total robots of the engine
   uint32_t flags;
   int32_t env_base;    // first robot of this launch (grid = robots of this launch)

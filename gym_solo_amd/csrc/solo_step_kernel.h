@@ -676,8 +676,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ StepConst<T> s_const;          // the scalars a step reads (see solo_kernel_params.h)
 
   const int lane0 = lane_id();
-  const int env = block_id() + B.env_base;
-  if (env >= B.num_envs) return;
+  // workgroup -> robot: the identity, or the cost-balanced launch order (solo_engine_set_order)
+  const int slot = block_id() + B.env_base;
+  if (slot >= B.num_envs) return;
+  const int env = B.order != nullptr ? wave_uniform(B.order[slot]) : slot;
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
 #ifdef SOLO_STAMPS
   __shared__ unsigned long long s_acc[17];
@@ -854,6 +856,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   SOLO_STAMP(B, 13);
   const int lane1 = wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
   if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) B.term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
+  if (B.cost != nullptr && (B.flags & SOLO_STEP_PHYSICS) && lane1 == 0) B.cost[env] = prio_sweeps;
   // (slots SOLO_S_RETURN.. of the record are the returns kernel's after a fused launch; a single-step
   // launch that evaluated its reward in place keeps the accumulators itself)
   const bool own_returns = B.reward_inline != nullptr && (B.flags & SOLO_STEP_DONE);

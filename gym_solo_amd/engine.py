@@ -126,6 +126,7 @@ class Engine:
     self.term_count = view(v.term_count, (n, abi.MAX_TERMS), '<i4')
     self.params = view(v.params, (n, 4), real)
     self.stats_shards = view(v.stats, (abi.STATS_SHARDS, abi.STATS_WIDTH), '<f8')
+    self.cost = view(v.cost, (n,), '<i4')
     self.obs_dim = v.obs_dim
     self._obs_ptr, self._real = v.obs, real
     self.obs = view(v.obs, (n, max(v.obs_dim, 1)), real) if v.obs_dim else None
@@ -224,6 +225,27 @@ class Engine:
     self._check(self.lib.solo_engine_set_terrain(
       self._handle(), C.byref(terrain) if terrain is not None else None, self._stream()), 'set_terrain')
 
+  def set_order(self, order=None):
+    """Launch order of the robots: int32 [N] permutation (workgroup b steps robot order[b]) or None =
+    identity.  With rollout slices every slice's positions must hold that slice's own robots."""
+    p = None
+    if order is not None:
+      p = self._dev_ptr(order, (self.num_envs,), self._torch.int32, 'order')
+    self._check(self.lib.solo_engine_set_order(self._handle(), p, self._stream()), 'set_order')
+
+  def balance(self):
+    """Cost-balanced scheduling: dispatch the costliest robots first (Gauss-Seidel sweeps of the last
+    launch, persistent within an episode), slice by slice.  Matters when N exceeds the chip's 4096
+    resident waves; results do not depend on it."""
+    torch = self._torch
+    g = max(1, int(self.cfg.rollout_streams))
+    g = g if (g > 1 and self.num_envs >= 2 * g) else 1
+    parts = []
+    for s in range(g):
+      lo, hi = self.num_envs * s // g, self.num_envs * (s + 1) // g
+      parts.append(torch.argsort(self.cost[lo:hi], descending=True, stable=True).to(torch.int32) + lo)
+    self.set_order(torch.cat(parts).contiguous())
+
   def set_params(self, which, per_env):
     p = self._dev_ptr(per_env, (self.num_envs,), self.tdtype, 'per_env')
     self._check(self.lib.solo_engine_set_params(self._handle(), which, p, self._stream()), 'set_params')
@@ -245,7 +267,7 @@ class Engine:
     """solo_engine_destroy: frees every device buffer.  Tensors handed out earlier dangle."""
     if getattr(self, '_h', None):
       for name in ('state', 'snapshot', 'targets', 'reward', 'done', 'done_bool', 'term_count', 'params',
-                   'stats_shards', 'obs'):
+                   'stats_shards', 'obs', 'cost'):
         setattr(self, name, None)
       self._finalizer()  # synchronises the device, then destroys the handle (runs at most once)
       self._h = None

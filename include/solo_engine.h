@@ -225,6 +225,8 @@ typedef struct SoloStateView {
   void* params;         /* real  [N][4]: lateral friction, base-mass scale, 2 spare */
   void* stats;          /* double[SOLO_STATS_SHARDS][8], sum over the shard axis: sum return, sum return^2,
                            episodes, sum length, (unused), diverged robots restored, 2 spare */
+  void* cost;           /* int32 [N]: Gauss-Seidel sweeps each robot ran in the LAST launch that stepped it
+                           (its cost is persistent within an episode): input of solo_engine_set_order */
 } SoloStateView;
 
 typedef struct SoloEngine SoloEngine;
@@ -289,6 +291,13 @@ int solo_engine_set_params(SoloEngine* eng, int32_t which, const void* per_env_d
 /* Replaces loadURDF('plane.urdf') (solo8_base_env.py:47): NULL = the flat plane z = 0.  Re-runs the
  * settle loop (the reset snapshot depends on the ground).  Synchronises the device. */
 int solo_engine_set_terrain(SoloEngine* eng, const SoloTerrain* terrain, void* stream);
+/* Launch order of the robots (cost-balanced scheduling): order_dev int32 [N], a permutation of 0..N-1
+ * that maps workgroup b of a launch to robot order[b]; NULL = identity.  With cfg.rollout_streams = G
+ * the positions [N g / G, N (g+1) / G) must hold a permutation of the same robot range (every slice
+ * keeps its robots).  Results do not depend on the order (robots are independent); it matters when
+ * N exceeds the 4096 resident waves of the chip: dispatching the costliest robots first (view.cost,
+ * descending) keeps the tail of a launch short.  Copied into an engine-owned buffer. */
+int solo_engine_set_order(SoloEngine* eng, const int32_t* order_dev, void* stream);
 /* name of the dominant kernel (for rocprof cross-checks) and its last launch geometry */
 const char* solo_engine_kernel_name(SoloEngine* eng);
 /* Times a rollout of reps * steps_per_launch steps exactly as solo_engine_rollout runs it (same

@@ -70,6 +70,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   const bool want_obs = (flags & SOLO_STEP_OBS) != 0, want_reward = (flags & SOLO_STEP_REWARD) != 0;
   KBuffers<T> B;
   B.terrain = terrain ? terr.data() : nullptr;
+  B.order = nullptr; B.cost = nullptr;
   B.state = st.data(); B.snapshot = snap.data(); B.targets = tg.data();
   B.actions = actions ? act.data() : nullptr; B.params = par.data();
   // as Engine::launch_chain: a single-step launch evaluates its outputs inside the step kernel
