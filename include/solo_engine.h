@@ -301,10 +301,11 @@ int solo_engine_set_order(SoloEngine* eng, const int32_t* order_dev, void* strea
 /* name of the dominant kernel (for rocprof cross-checks) and its last launch geometry */
 const char* solo_engine_kernel_name(SoloEngine* eng);
 /* Times a rollout of reps * steps_per_launch steps exactly as solo_engine_rollout runs it (same
- * slicing, same fused launches) with hipEvents recorded ON THE STREAM THE KERNELS ARE LAUNCHED ON
- * (slice 0's internal stream when rollout_streams > 1, else `stream`) and returns the mean
- * milliseconds per LAUNCH of that chain; one launch covers N / max(1, rollout_streams) robots x
- * steps_per_launch steps.  actions_dev: real [reps * steps_per_launch][N][12] or NULL. */
+ * slicing, same fused launches; the step kernel alone, without the output kernels) with hipEvents
+ * recorded ON THE STREAMS THE KERNELS ARE LAUNCHED ON (every slice's internal stream when
+ * rollout_streams > 1, else `stream`) and returns the mean milliseconds per LAUNCH over all slices;
+ * one launch covers N / max(1, rollout_streams) robots x steps_per_launch steps.
+ * actions_dev: real [reps * steps_per_launch][N][12] or NULL. */
 int solo_engine_time_step(SoloEngine* eng, const void* actions_dev, uint32_t flags,
                           int32_t reps, void* stream, double* ms_per_launch);
 const char* solo_engine_last_error(SoloEngine* eng);

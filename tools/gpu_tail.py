@@ -27,14 +27,13 @@ for spl in [int(a) for a in sys.argv[1:]] or (250, 20, 1):
     assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
     t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 14].astype(np.int64)
     life = (t1 - t0)
-    span = t1.max() - t0.min()
-    print('S=%d streams=%d: rollout %.3f ms = %.2f us/step ; ticks: span %d (%.1f MHz tick rate) ; per-robot life/step pct 1/50/90/99/max = %s ; mean %.0f ; mean/span = %.2f ; start skew %d' % (
-      spl, streams, ms, ms * 1e3 / spl, span, span / (ms * 1e3), (np.percentile(life, [1, 50, 90, 99, 100]) / spl).astype(int).tolist(),
-      life.mean() / spl, life.mean() / span, t0.max() - t0.min()))
+    # (s_memtime counters are not synchronised across CUs: only per-wave DIFFERENCES are meaningful)
+    print('S=%d streams=%d N=%d: rollout %.3f ms = %.2f us/step ; per-robot wave lifetime per step (ticks) pct 1/50/90/99/max = %s ; mean %.0f ; max/mean %.2f' % (
+      spl, streams, n, ms, ms * 1e3 / spl, (np.percentile(life, [1, 50, 90, 99, 100]) / spl).astype(int).tolist(),
+      life.mean() / spl, life.max() / life.mean()))
     hw = (buf[:, 15] >> 28).astype(np.int64); xcc = ((buf[:, 15] >> 24) & 0xf).astype(np.int64)
     simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
     print('    by XCC: ' + ' '.join('%d:%d/%.0f' % (x, (xcc == x).sum(), life[xcc == x].mean() / spl) for x in np.unique(xcc)))
-    print('    per-XCC span/step (first start -> last end): ' + ' '.join('%d:%.0f' % (x, (t1[xcc == x].max() - t0[xcc == x].min()) / spl) for x in np.unique(xcc)))
     cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     u, inv = np.unique(cuid, return_inverse=True)
     cnt = np.bincount(inv); cmean = np.bincount(inv, weights=life / spl) / cnt
@@ -45,7 +44,4 @@ for spl in [int(a) for a in sys.argv[1:]] or (250, 20, 1):
     cnt2 = np.bincount(inv2)
     print('    SIMDs used %d ; waves per SIMD histogram %s ; mean life by waves-on-SIMD: %s' % (
       len(u2), np.bincount(cnt2).tolist(), {int(c): int((life / spl)[cnt2[inv2] == c].mean()) for c in np.unique(cnt2)}))
-    for g_ in range(streams):
-      lo, hi = n * g_ // streams, n * (g_ + 1) // streams
-      print('    slice %d: first start %d last end %d (rel. to global first start)' % (g_, t0[lo:hi].min() - t0.min(), t1[lo:hi].max() - t0.min()))
     env._close()
