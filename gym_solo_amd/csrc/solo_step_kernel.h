@@ -593,10 +593,15 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = C.dt;
-  T z[6];
+  // z = sum over all rows of ghat * lam (6 wave-wide sums), yl = per-leg sums of hhat * lam (2 sums over
+  // the 16 lanes of a leg): eight reductions, interleaved stage by stage (wave_reduce_rows)
+  T z[6], yl[2];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) z[i] = wave_sum_all(s_rowvec[lane][i] * lam);
-  const T yl1 = sum_over_group16(s_rowvec[lane][6] * lam), yl2 = sum_over_group16(s_rowvec[lane][7] * lam);
+  for (int i = 0; i < 6; ++i) z[i] = s_rowvec[lane][i] * lam;
+  yl[0] = s_rowvec[lane][6] * lam;
+  yl[1] = s_rowvec[lane][7] * lam;
+  wave_reduce_rows(z, yl);
+  const T yl1 = yl[0], yl2 = yl[1];
   // C^T x = z (back substitution with the parked Cholesky factor)
 #pragma unroll
   for (int i = 5; i >= 0; --i) {

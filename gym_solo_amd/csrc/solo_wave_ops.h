@@ -96,6 +96,46 @@ __device__ __forceinline__ float wave_sum_all(float x) {
 __device__ __forceinline__ double wave_sum_all(double x) { return wave_sum_legs(wave_sum_group16(x)); }
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 
+// Six wave-wide sums (z, returned wave-uniform) and two 16-lane sums (y, in every lane of the row) at
+// once.  One at a time each reduction is a serial chain of DPP adds with an s_nop between every two
+// stages (VALU write -> DPP read of the same register needs two wait states): ~16 instructions per
+// sum, 114 for the eight.  Interleaved stage by stage the other seven chains fill the wait states:
+// 44 DPP adds + 6 v_readlane, no nops, no dependent-issue stalls.  Same association as wave_sum_all /
+// wave_sum_group16: row all-reduce (ror 8, 4, 2, 1), then row_bcast:15 into rows 1, 3 and
+// row_bcast:31 into rows 2, 3, total in lane 63.
+__device__ __forceinline__ void wave_reduce_rows(float (&z)[6], float (&y)[2]) {
+#define SOLO_DPP_STAGE8(CTRL)                                                                      \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+  "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+  "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+  "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                \
+  "v_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define SOLO_DPP_STAGE6(CTRL, MASK)                                                                \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t"  // (the eight inputs were just written by VALU instructions)
+      SOLO_DPP_STAGE8("row_ror:8") SOLO_DPP_STAGE8("row_ror:4") SOLO_DPP_STAGE8("row_ror:2") SOLO_DPP_STAGE8("row_ror:1")
+      SOLO_DPP_STAGE6("row_bcast:15", "0xa") SOLO_DPP_STAGE6("row_bcast:31", "0xc")
+      : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(y[0]), "+v"(y[1]));
+#undef SOLO_DPP_STAGE8
+#undef SOLO_DPP_STAGE6
+#pragma unroll
+  for (int i = 0; i < 6; ++i) z[i] = wave_readlane(z[i], 63);
+}
+__device__ __forceinline__ void wave_reduce_rows(double (&z)[6], double (&y)[2]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) z[i] = wave_sum_all(z[i]);
+  y[0] = wave_sum_group16(y[0]);
+  y[1] = wave_sum_group16(y[1]);
+}
+
 // ghat_s . ghat_r + hhat_s . x for the Delassus columns: the lane's own whitened row stays in
 // registers, the other row comes from LDS.  f32: four v_pk_fma_f32 (two terms each) + one add.
 typedef float solo_f32x2 __attribute__((ext_vector_type(2)));

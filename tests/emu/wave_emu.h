@@ -187,6 +187,11 @@ template <typename T> inline T wave_sum_group16(T x) {
   return x;
 }
 template <typename T> inline T wave_sum_all(T x) { return wave_sum_legs(wave_sum_group16(x)); }
+template <typename T> inline void wave_reduce_rows(T (&z)[6], T (&y)[2]) {
+  for (int i = 0; i < 6; ++i) z[i] = wave_sum_all(z[i]);
+  y[0] = wave_sum_group16(y[0]);
+  y[1] = wave_sum_group16(y[1]);
+}
 inline unsigned long long wave_ballot(bool p) {
   WaveEmu& e = WaveEmu::get();
   e.post(p ? 1 : 0);
