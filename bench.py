@@ -120,6 +120,47 @@ def cpu_baseline(num_envs, seconds_target=12.0):
                     '%d threads) + numpy obs/reward, %.1f s' % (num_envs, steps, cores, el)}
 
 
+def pybullet_baseline(seconds_target=5.0):
+  """BASELINE.md §4 (opportunistic): if pybullet happens to be importable on this box, time BASELINE
+  configs[0] - ONE Solo8 on PyBullet DIRECT, random actions, the reference's own call sequence
+  (solo8v2vanilla.py:87-91) on a URDF written from the build's model constants.  Never the case in
+  this pipeline (no network, only the repo travels); then the field says so and no number is quoted."""
+  try:
+    import pybullet as p
+    import pybullet_data
+  except Exception:  # noqa: BLE001
+    return {'available': False, 'note': 'PyBullet unavailable - reference CPU timing not measured'}
+  try:
+    import tempfile
+    import numpy as np
+    from gym_solo_amd.urdf import to_urdf
+    path = os.path.join(tempfile.mkdtemp(prefix='solo_urdf_'), 'solo.urdf')
+    with open(path, 'w') as f:
+      f.write(to_urdf())
+    cid = p.connect(p.DIRECT)
+    p.setAdditionalSearchPath(pybullet_data.getDataPath(), physicsClientId=cid)
+    p.setGravity(0, 0, -9.81, physicsClientId=cid)
+    p.setPhysicsEngineParameter(fixedTimeStep=1e-3, numSubSteps=1, physicsClientId=cid)
+    p.loadURDF('plane.urdf', physicsClientId=cid)
+    robot = p.loadURDF(path, [0, 0, 0.5], p.getQuaternionFromEuler([0, 0, 0]), flags=p.URDF_USE_INERTIA_FROM_FILE,
+                       useFixedBase=False, physicsClientId=cid)
+    n_j = p.getNumJoints(robot, physicsClientId=cid)
+    rng = np.random.default_rng(1234)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_target:
+      a = rng.uniform(-2 * np.pi, 2 * np.pi, n_j)
+      p.setJointMotorControlArray(robot, np.arange(n_j), p.POSITION_CONTROL, targetPositions=a, forces=[2.0] * n_j,
+                                  physicsClientId=cid)
+      p.stepSimulation(physicsClientId=cid)
+      steps += 1
+    el = time.perf_counter() - t0
+    p.disconnect(cid)
+    return {'available': True, 'value': steps / el, 'unit': 'env-steps/s', 'cores': 1,
+            'sample': '1 Solo8 on PyBullet DIRECT (%s), physics calls only, %d steps' % (getattr(p, '__version__', '?'), steps)}
+  except Exception as e:  # noqa: BLE001
+    return {'available': False, 'note': 'pybullet importable but the run failed: %r' % (e,)}
+
+
 def pmc_profile(dtype):
   """Per-env-step figures from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
   written by tools/make_pmc_traffic.py), or {}."""
@@ -350,6 +391,8 @@ def main():
     }
     line.update(extra)
     line['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(n)
+    if line['cpu_baseline'] is not None:
+      line['cpu_baseline']['pybullet'] = pybullet_baseline()
     print(json.dumps(line), flush=True)
   if distributed:
     dist.barrier()
