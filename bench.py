@@ -208,6 +208,10 @@ def launch_ranks(n_ranks):
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                   stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
   out, _ = procs[0].communicate()
+  if procs[0].returncode != 0:  # rank 0 failed: do not leave the others waiting in a collective
+    for p in procs[1:]:
+      if p.poll() is None:
+        p.terminate()
   rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
   sys.stdout.write(out.decode())
   sys.stdout.flush()
