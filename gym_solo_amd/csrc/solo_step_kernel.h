@@ -767,31 +767,16 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83)
     bool done = false;
     if (B.flags & SOLO_STEP_DONE) {
-      // every lane evaluates the same list on the same counters; lane 0 writes them back.  The
-      // program (a few wave-uniform ints) is re-read from the staged constants in LDS.
-      const int n_terms = wave_uniform(C.num_terms);
-      int c[SOLO_MAX_TERMS];
-#pragma unroll
-      for (int t = 0; t < SOLO_MAX_TERMS; ++t) c[t] = s_cnt[t];
-      wave_sync();
-      bool d = false;
-#pragma unroll
-      for (int t = 0; t < SOLO_MAX_TERMS; ++t) {
-        if (t < n_terms && !d) {
-          const int kind = wave_uniform(C.term_kind[t]), param = wave_uniform(C.term_param[t]);
-          if (kind == SOLO_T_TIME) {
-            c[t] += 1;
-            d = c[t] > param;
-          } else if (kind == SOLO_T_CONST) {
-            d = param != 0;
-          }
-        }
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int t = 0; t < SOLO_MAX_TERMS; ++t) s_cnt[t] = c[t];
-      }
-      done = wave_ballot(d) != 0ull;  // (identical in every lane; the ballot makes it a scalar)
+      // lane t evaluates termination t on its own counter (LDS); the OR short-circuits: once an
+      // earlier termination fires, the later ones are not ticked (termination.py:46-48)
+      const int tl = lane & (SOLO_MAX_TERMS - 1);
+      const int kind = C.term_kind[tl], param = C.term_param[tl], cnt = s_cnt[tl] + 1;
+      const bool mine = lane < wave_uniform(C.num_terms);  // (num_terms <= SOLO_MAX_TERMS)
+      const bool fire = mine && ((kind == SOLO_T_TIME && cnt > param) || (kind == SOLO_T_CONST && param != 0));
+      const unsigned long long fired = wave_ballot(fire);
+      done = fired != 0ull;
+      const int first = done ? __builtin_ctzll(fired) : SOLO_MAX_TERMS;  // wave-uniform
+      if (mine && kind == SOLO_T_TIME && lane <= first) s_cnt[lane] = cnt;
     }
     // The auto-reset belongs to a step that advanced the simulation (or asks for it explicitly):
     // a query-only launch - TerminationFactory.is_terminated() outside step(), termination.py:38-50
