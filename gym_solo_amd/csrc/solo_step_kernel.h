@@ -684,7 +684,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   // workgroup -> robot: the identity, or the cost-balanced launch order (solo_engine_set_order)
   const int slot = block_id() + B.env_base;
   if (slot >= B.num_envs) return;
-  const int env = B.order != nullptr ? wave_uniform(B.order[slot]) : slot;
+  const int32_t* order = wave_cold_args(Bin)->order;
+  const int env = order != nullptr ? wave_uniform(order[slot]) : slot;
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
 #ifdef SOLO_STAMPS
   __shared__ unsigned long long s_acc[17];
@@ -695,7 +696,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   SOLO_STAMP(B, 0);
   // episodic statistics are sharded over SOLO_STATS_SHARDS rows: all robots of a batch finish
   // their episodes in the same step, and same-address atomics serialise at ~12 ns each
-  double* stats = B.stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH;
+  // (the rarely touched buffers are re-read from the kernarg segment where they are used: wave_cold_args)
+#define SOLO_STATS_ROW (wave_cold_args(Bin)->stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH)
 
   const KParams<T>* __restrict__ const P0 = Pin;
 #pragma unroll
@@ -712,12 +714,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     for (int i = lane0; i < kConstWords; i += 64) cdst[i] = csrc[i];
   }
   int prio_sweeps = 0, prio_steps = 0;
-  if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = B.state[rec + lane0];
-  const T mu = B.params[(size_t)env * 4 + 0];
-  const T mass_scale = B.params[(size_t)env * 4 + 1];
+  if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = wave_cold_args(Bin)->state[rec + lane0];
+  const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
+  const T mass_scale = wave_cold_args(Bin)->params[(size_t)env * 4 + 1];
   // TimeBased counters of this robot live in LDS across the launch's steps (kept in scalar
   // registers next to the termination program they cost 25 SGPR spills in the fused step loop)
-  if (lane0 < SOLO_MAX_TERMS) s_cnt[lane0] = B.term_count[(size_t)env * SOLO_MAX_TERMS + lane0];
+  if (lane0 < SOLO_MAX_TERMS) s_cnt[lane0] = wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane0];
 
   // B.steps consecutive env steps of THIS robot in one launch: the state record stays in LDS,
   // only actions come in and the step records / done flags go out per step.  Robots are independent, so
@@ -739,11 +741,11 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     const bool motor_lane = rc.type == ROW_MOTOR;
     const size_t tgt_at = (size_t)env * SOLO_NUM_JOINTS + (size_t)(3 * (lane >> 4) + (lane & 15));  // pybullet joint index
     T raw_target = T(0);
-    if (motor_lane) raw_target = B.actions != nullptr ? B.actions[(size_t)step * B.action_stride + tgt_at] : B.targets[tgt_at];
+    if (motor_lane) raw_target = B.actions != nullptr ? B.actions[(size_t)step * B.action_stride + tgt_at] : wave_cold_args(Bin)->targets[tgt_at];
     // action de-normalisation (solo8v2vanilla.py:84-85), applied where the target is used
     const T target_scale = B.actions != nullptr ? C.action_scale : T(1);
     if (B.actions != nullptr && step == B.steps - 1 && lane < SOLO_NUM_JOINTS)  // the view's targets: all 12 entries
-      B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] =
+      wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] =
           B.actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * C.action_scale;
 
     SOLO_STAMP(B, 1);
@@ -757,8 +759,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
       const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) || (motor_lane && !R::finite(my_target));
       diverged = wave_ballot(bad) != 0ull;
       if (diverged) {
-        if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
-        if (lane == 0) stats_add(&stats[5], 1.0);
+        if (lane < SOLO_S_RETURN) s_state[lane] = wave_cold_args(Bin)->snapshot[rec + lane];
+        if (lane == 0) stats_add(&SOLO_STATS_ROW[5], 1.0);
         wave_sync();
       }
     }
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
             // episodic return / length live in the record's slots 29, 30: loaded with the state in the
             // prologue, updated here in LDS, stored with the state at the end of the launch
             const uint8_t ev = (uint8_t)((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
-            accumulate_returns<T>(s_state, &ev, 0, &r, 0, 1, stats, [](double* p, double x) { stats_add(p, x); });
+            accumulate_returns<T>(s_state, &ev, 0, &r, 0, 1, SOLO_STATS_ROW, [](double* p, double x) { stats_add(p, x); });
           }
         }
       }
@@ -833,10 +835,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     if (B.flags & SOLO_STEP_DONE) {
       if (restart) {
         wave_sync();  // the record above is read from the old state first
-        if (lane < SOLO_S_RETURN) s_state[lane] = B.snapshot[rec + lane];
+        if (lane < SOLO_S_RETURN) s_state[lane] = wave_cold_args(Bin)->snapshot[rec + lane];
         if (lane < SOLO_MAX_TERMS) s_cnt[lane] = 0;
         // reset() leaves the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
-        if (lane < SOLO_NUM_JOINTS) B.targets[(size_t)env * SOLO_NUM_JOINTS + lane] = C.settle_tgt[lane];
+        if (lane < SOLO_NUM_JOINTS) wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = C.settle_tgt[lane];
       }
       if (lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
     }
@@ -845,12 +847,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   }
   SOLO_STAMP(B, 13);
   const int lane1 = wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
-  if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) B.term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
-  if (B.cost != nullptr && (B.flags & SOLO_STEP_PHYSICS) && lane1 == 0) B.cost[env] = prio_sweeps;
+  if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
+  if ((B.flags & SOLO_STEP_PHYSICS) && lane1 == 0) { int32_t* cost = wave_cold_args(Bin)->cost; if (cost != nullptr) cost[env] = prio_sweeps; }
   // (slots SOLO_S_RETURN.. of the record are the returns kernel's after a fused launch; a single-step
   // launch that evaluated its reward in place keeps the accumulators itself)
   const bool own_returns = B.reward_inline != nullptr && (B.flags & SOLO_STEP_DONE);
-  if (lane1 < (own_returns ? SOLO_S_SPARE : SOLO_S_RETURN)) B.state[rec + lane1] = s_state[lane1];
+  if (lane1 < (own_returns ? SOLO_S_SPARE : SOLO_S_RETURN)) wave_cold_args(Bin)->state[rec + lane1] = s_state[lane1];
   SOLO_STAMP(B, 14);
 #ifdef SOLO_STAMPS
   wave_sync();

@@ -215,6 +215,21 @@ template <> struct ColumnBank<double> {
   __device__ __forceinline__ double get(int, int r) const { return column(r); }
 };
 
+// The kernel's by-value buffer block, re-read from the kernarg segment (constant address space ->
+// s_load at the use site) instead of living in scalar registers for the whole launch: for the fields
+// the step loop touches rarely or only in the prologue / epilogue (snapshot, statistics, targets,
+// counters, cost).  Kept in registers they pushed the kernel over its SGPR budget (15 spills with
+// reloads all over the step loop).  `by_value` is the kernel parameter itself (second parameter,
+// after one 8-byte pointer).
+template <typename B> using ColdArgs = const __attribute__((address_space(4))) B*;
+template <typename B> __device__ __forceinline__ ColdArgs<B> wave_cold_args(const B& by_value) {
+  (void)by_value;
+  auto base = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  ColdArgs<B> p = (ColdArgs<B>)(base + sizeof(void*));
+  asm volatile("" : "+s"(p));  // (opaque: every use site issues its own scalar load)
+  return p;
+}
+
 // slot of this wave among the waves resident on its SIMD (HW_ID[3:0])
 __device__ __forceinline__ int wave_slot_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 0xf); }
 // issue priority of this wave in its SIMD

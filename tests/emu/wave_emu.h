@@ -125,6 +125,8 @@ inline int wave_opaque_lane(int lane) { return lane; }
 inline int wave_uniform(int x) { return x; }
 inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
 inline void wave_set_priority_level(int) {}
+template <typename B> using ColdArgs = const B*;
+template <typename B> inline ColdArgs<B> wave_cold_args(const B& by_value) { return &by_value; }
 inline int wave_slot_id() { return 0; }
 inline void block_sync() {}  // (the thread-per-item output kernels are not emulated: their per-item functions run in loops)
 template <typename T> struct RowDot {
