@@ -631,10 +631,10 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
   const V3<T> wn = {r00 * ub[0] + r01 * ub[1] + r02 * ub[2], r10 * ub[0] + r11 * ub[1] + r12 * ub[2], r20 * ub[0] + r21 * ub[1] + r22 * ub[2]};
   const V3<T> vn = {r00 * ub[3] + r01 * ub[4] + r02 * ub[5], r10 * ub[3] + r11 * ub[4] + r12 * ub[5], r20 * ub[3] + r21 * ub[4] + r22 * ub[5]};
   // q+ = exp(dt w / 2) (x) q, renormalised
-  const T th = R::sqrt(dot(wn, wn)) * dt;
-  T sh, ch;
-  R::sincos(T(0.5) * th, &sh, &ch);
-  const T sc = (th > T(1e-12)) ? sh * R::rcp(th) * dt : T(0.5) * dt;
+  // exp(dt w / 2) = (w sin(x) / |w|, cos(x)) with x = |w| dt / 2: sin(x) / |w| = (dt / 2) sinc(x)
+  T sinc_x, ch;
+  R::sinc_cos(T(0.25) * dt * dt * dot(wn, wn), &sinc_x, &ch);  // argument: x^2
+  const T sc = T(0.5) * dt * sinc_x;
   const T dx = wn.x * sc, dy = wn.y * sc, dz = wn.z * sc, dw = ch;
   T nx = dw * qx + dx * qw + dy * qz - dz * qy;
   T ny = dw * qy - dx * qz + dy * qw + dz * qx;

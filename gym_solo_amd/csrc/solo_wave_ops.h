@@ -267,6 +267,27 @@ template <> struct Real<float> {
     *s = (q & 2) ? -a : a;
     *c = ((q + 1) & 2) ? -b : b;
   }
+  // sinc(x) = sin(x) / x and cos(x) from x^2, for the half rotation angle of one step (x = |w| dt / 2,
+  // ~1e-2): even Taylor polynomials, exact to f32 round-off for x^2 < 1/16 (truncation < 5e-11 /
+  // 3e-9 relative); beyond that (|w| > 500 rad/s at dt = 1e-3: never in a sane simulation) the
+  // library path.  No sqrt, no range reduction: 8 fused multiply-adds instead of ~35 instructions.
+  static __device__ __forceinline__ void sinc_cos(float x2, float* sinc, float* c) {
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(__float_as_int(x2)) > 0x3d800000, 0)) {  // x2 > 1/16 (wave-uniform: one robot)
+      const float x = __builtin_amdgcn_sqrtf(x2);
+      float sn, cs;
+      sincos(x, &sn, &cs);
+      *sinc = sn * __builtin_amdgcn_rcpf(x);
+      *c = cs;
+      return;
+    }
+    float sp = __builtin_fmaf(x2, -1.9841270e-4f, 8.3333333e-3f);
+    sp = __builtin_fmaf(x2, sp, -1.6666667e-1f);
+    *sinc = __builtin_fmaf(x2, sp, 1.0f);
+    float cp = __builtin_fmaf(x2, 2.4801587e-5f, -1.3888889e-3f);
+    cp = __builtin_fmaf(x2, cp, 4.1666667e-2f);
+    cp = __builtin_fmaf(x2, cp, -0.5f);
+    *c = __builtin_fmaf(x2, cp, 1.0f);
+  }
   // atan2 by octant reduction + odd minimax polynomial on [0, 1] (max error 1.5e-7 rad), ~22
   // instructions instead of libm's ~60; asin(x) = atan2(x, sqrt(1 - x^2)).  These feed the Euler
   // angles of the observation / reward programs (obs.py:271, rewards.py:233).
@@ -305,6 +326,12 @@ template <> struct Real<double> {
   static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
   static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
   static __device__ __forceinline__ void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
+  static __device__ __forceinline__ void sinc_cos(double x2, double* sinc, double* c) {
+    const double x = ::sqrt(x2);
+    double sn;
+    ::sincos(x, &sn, c);
+    *sinc = x > 1e-12 ? sn / x : 1.0;
+  }
   static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
   static __device__ __forceinline__ double asin(double x) { return ::asin(x); }
   static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
