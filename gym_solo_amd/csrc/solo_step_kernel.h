@@ -138,12 +138,15 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   const T bm = lower ? T(1) : T(0);
   const T q1 = s_state[SOLO_S_Q + 2 * leg], q2 = s_state[SOLO_S_Q + 2 * leg + 1];
   const T qd1 = s_state[SOLO_S_QD + 2 * leg], qd2 = s_state[SOLO_S_QD + 2 * leg + 1];
-  T s1, c1, s12, c12;
-  R::sincos(q1, &s1, &c1);
-  R::sincos(q1 + q2, &s12, &c12);
+  // ONE sincos per lane - of its own link's absolute angle (q1 on the upper half, q1 + q2 on the lower) -
+  // and the other link's pair from the other half of the 16-lane row (two DPP moves)
+  T sinb, cosb;  // this half's link orientation
+  R::sincos(lower ? q1 + q2 : q1, &sinb, &cosb);
+  const T sino = wave_other_half16(sinb), coso = wave_other_half16(cosb);
+  const T s1 = lower ? sino : sinb, c1 = lower ? coso : cosb;
+  const T s12 = lower ? sinb : sino, c12 = lower ? cosb : coso;
   const V3<T> o1 = {L.hip[0], L.hip[1], L.hip[2]};
   const V3<T> o2 = o1 + roty(c1, s1, V3<T>{L.knee[0], L.knee[1], L.knee[2]});
-  const T cosb = lower ? c12 : c1, sinb = lower ? s12 : s1;  // this half's link orientation
   const V3<T> ob = select(lower, o2, o1);                // ... and joint origin
   const T* body = L.link[lower ? 1 : 0];                 // m, com[3], inertia[6] of this half's link
   const T mB = body[0];
