@@ -240,3 +240,26 @@ def test_launch_order_does_not_change_results(torch, streams):
   for mode in ('random', 'balanced'):
     for a, b in zip(out['identity'], out[mode]):
       np.testing.assert_array_equal(a, b)
+
+
+def test_fast_spin_takes_the_library_rotation_path(torch):
+  """The f32 rotation update uses even Taylor polynomials in (|w| dt / 2)^2 and falls back to the
+  library sincos above 1/16 (|w| > 500 rad/s): a base spinning at 300 / 700 rad/s in the air, one
+  step, f32 engine vs oracle - both paths agree with the exact update."""
+  from oracle import solo_oracle as so
+  eng, ca, ma = _engine(4, 'float32')
+  ca64, _ = make_abi('float64')
+  ph = so.OraclePhysics(ca64, ma)
+  st = np.tile(ph.settle(1), (4, 1))
+  st[:, abi.S_POS + 2] = 1.0
+  st[0, abi.S_ANGVEL:abi.S_ANGVEL + 3] = [300.0, 0.0, 0.0]
+  st[1, abi.S_ANGVEL:abi.S_ANGVEL + 3] = [0.0, 700.0, 0.0]
+  st[2, abi.S_ANGVEL:abi.S_ANGVEL + 3] = [400.0, -300.0, 500.0]
+  eng.state.copy_(torch.as_tensor(st, device='cuda', dtype=torch.float32))
+  a = np.zeros((4, 12))
+  ph.step(st, a)
+  eng.step(torch.zeros(4, 12, device='cuda'), abi.STEP_PHYSICS)
+  got = eng.state.cpu().numpy().astype(np.float64)
+  np.testing.assert_allclose(got[:, abi.S_QUAT:abi.S_QUAT + 4], st[:, abi.S_QUAT:abi.S_QUAT + 4], rtol=0, atol=2e-5)
+  np.testing.assert_allclose(np.linalg.norm(got[:, abi.S_QUAT:abi.S_QUAT + 4], axis=1), 1.0, atol=1e-6)
+  eng.close()
