@@ -14,23 +14,28 @@
 //  * The floating base couples the legs only through a 6x6 block, so the joint-space inverse
 //    inertia is applied in factored form: Cholesky of the four 2x2 leg blocks P_l and of the
 //    6x6 base Schur complement S = M_bb - sum_l M_bl P_l^-1 M_lb (the base's articulated-body
-//    inertia).  Every constraint row r (8 motor rows + 3 per touching sphere) is owned by ONE
-//    LANE, which whitens its Jacobian against those factors (ghat_r in R^6, hhat_r in R^2), so
-//    that the Delassus matrix is  A_sr = ghat_s.ghat_r + [same leg] hhat_s.hhat_r.
-//  * The matrix is never stored.  Projected Gauss-Seidel keeps, per lane, the row's candidate,
-//    impulse and bounds; the rows that still move are found for all lanes at once (clamp,
-//    subtract, compare: the compare's lane mask is the set) and only those are visited, in solver
-//    order, each one rebuilding its Delassus column from the whitened row vectors in LDS (see
+//    inertia).  Every constraint row r (8 motor rows, 8 joint-limit rows, 3 per touching sphere) is
+//    owned by ONE LANE, which whitens its Jacobian against those factors (ghat_r in R^6, hhat_r in
+//    R^2), so that the Delassus matrix is  A_sr = ghat_s.ghat_r + [same leg] hhat_s.hhat_r.
+//  * f32: the scaled columns of that matrix for the rows that can move are built once per step into
+//    two 32-wide register tuples (ColumnBank, solo_wave_ops.h); f64 evaluates them from the whitened
+//    row vectors in LDS.  Projected Gauss-Seidel keeps, per lane, the row's candidate, impulse and
+//    bounds; the rows that still move are found for all lanes at once (clamp, subtract, compare:
+//    the compare's lane mask is the set) and only those are visited, in solver order (non-contact
+//    rows, normal rows, friction rows), each with one register-indexed move for its column (see
 //    physics_solve).  All branching is wave-uniform: the whole wave belongs to one robot.
+//  * The ~50 scalars a step reads, the per-leg and per-row tables live in LDS for the launch; the
+//    rarely used kernel arguments are re-read from the kernarg segment where they are used.
 //  * Termination (TimeBased counters) and the auto-reset stay in the robot's wave; observations,
 //    rewards and episodic returns do NOT: a fused launch leaves one 128-B record per robot-step
 //    and the output kernels at the end of this file evaluate them with one THREAD per robot-step
 //    (solo_outputs.h).  Only a single-step launch - the closed-loop step() - evaluates its outputs
 //    in place, with the same per-item functions.
-// No MFMA: there is no dense contraction here (14 dofs, <= 56 rows per robot).
+// No MFMA: there is no dense contraction here (14 dofs, <= 64 rows per robot).
 //
 // The including translation unit must provide solo::lane_id/block_id/wave_sync/wave_readlane/
-// wave_sum_group16/wave_sum_all/wave_ballot/RowDot<T>/Real<T>/stats_add (solo_wave_ops.h on the GPU).
+// wave_sum_group16/wave_sum_all/wave_reduce_rows/wave_lane_below/wave_ballot/wave_cold_args/RowDot<T>/
+// ColumnBank<T>/Real<T>/stats_add (solo_wave_ops.h on the GPU, tests/emu/wave_emu.h on the CPU emulator).
 #pragma once
 
 #include "solo_kernel_params.h"
