@@ -10,14 +10,19 @@
  * contact/friction rows -> semi-implicit Euler), in double precision, scalar, generic over
  * the kinematic tree, using textbook 6-D spatial algebra (Featherstone, RBDA ch. 5, 6, 9).
  * It is pinned only by (a) physics known-answer tests in tests/test_oracle_physics.py,
- * (b) the getJointInfo model fixture gym_solo/core/test_obs_observations.py:123-162 and
- * (c) the determinism/rest properties of gym_solo/envs/test_solo8v2vanilla.py:77-194.
+ * (b) the getJointInfo model fixture gym_solo/core/test_obs_observations.py:123-162,
+ * (c) the determinism/rest properties of gym_solo/envs/test_solo8v2vanilla.py:77-194 and
+ * (d) the one pybullet-extracted rest state the reference holds (test_obs_observations.py:256-275),
+ *     which calibrates two collision parameters of the model (gym_solo_amd/model.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  *
  * Step semantics restated (reference call sites):
  *   setJointMotorControlArray(POSITION_CONTROL, targetPositions, forces)
  *       solo8v2vanilla.py:87-90 -> 8 velocity-level motor rows, impulse clamp force*dt
+ *   URDF joint limits (-10 / +10 rad, fixture columns 8-9) -> unilateral rows near a limit
+ *   one solver iteration: non-contact rows (leg by leg), all normal rows, all friction rows
+ *       ([recalled] btMultiBodyConstraintSolver::solveSingleIteration)
  *   stepSimulation()  solo8v2vanilla.py:91, fixedTimeStep=dt, numSubSteps=1
  *       solo8_base_env.py:39-41
  *   gravity configs.py:17, link damping configs.py:21-22 via changeDynamics
