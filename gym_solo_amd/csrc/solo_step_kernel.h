@@ -692,6 +692,9 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   // workgroup -> robot: the identity, or the cost-balanced launch order (solo_engine_set_order)
   const int slot = block_id() + B.env_base;
   if (slot >= B.num_envs) return;
+  // (wave_cold_args assumes the kernel's parameter layout - one pointer, then this block: checked on
+  // two fields, so that a changed signature traps instead of reading garbage)
+  if (wave_cold_args(Bin)->num_envs != B.num_envs || wave_cold_args(Bin)->steps != B.steps) __builtin_trap();
   const int32_t* order = wave_cold_args(Bin)->order;
   const int env = order != nullptr ? wave_uniform(order[slot]) : slot;
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
