@@ -25,3 +25,14 @@ def test_rewards_match_reference(name, dtype):
 @pytest.mark.parametrize('dtype', ['float64', 'float32'])
 def test_termination_sequences_match_reference(dtype):
   gc.case_terminations(make_env, dtype)
+
+
+def test_random_reward_trees_on_the_hip_engine():
+  """The randomized reward-tree check of tests/test_emu_golden.py on the HIP engine (f64)."""
+  import test_emu_golden as cpu
+  saved = cpu.make_env
+  cpu.make_env = make_env
+  try:
+    cpu.test_random_reward_trees_fused_vs_reference_semantics()
+  finally:
+    cpu.make_env = saved
