@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "solo_wave_ops.h"
+#include "solo_pgs_gfx950.h"  // (defines SOLO_PGS_GFX950: the f32 Gauss-Seidel loop of the step kernel in assembly)
 #include "solo_step_kernel.h"
 
 namespace {

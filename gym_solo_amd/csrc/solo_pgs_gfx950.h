@@ -1,0 +1,129 @@
+// solo_pgs_gfx950.h — the projected Gauss-Seidel loop of solo_step_kernel.h (f32, register-resident
+// Delassus columns) written directly in gfx950 assembly.  SAME rows, SAME order, SAME arithmetic as
+// the C++ loop in physics_solve (which stays the definition: the f64 instantiation and the CPU wave
+// emulator run it, and the GPU parity tests compare this file against the emulator bit for bit).
+//
+// Why assembly.  One wave issues one instruction every ~7 cycles whatever the instruction is and whether
+// or not it depends on the one before (tools/microbench/pgs_chain.hip: the row-update block costs
+// 7 cycles x its instruction count with the register indexing, the v_readlane and the compare -> SGPR
+// hop removed one by one, and just the same with the next row made independent of the scalar chain:
+// a speculative, software-pipelined walk was built, measured 6 % SLOWER for its three extra
+// instructions per row, and dropped).  So the time of this loop - half the time of the slowest robot
+// of a launch, the one that decides how long the launch takes - is its INSTRUCTION COUNT, and that is
+// what is minimised here:
+//  * ONE 64-slot column bank.  The two 32-register tuples of ColumnBank<float> are pinned to
+//    v[64:95] / v[96:127], so a column is `v64` indexed by the row number: three walks per sweep
+//    instead of the compiler's six (one per phase and 32-register tuple);
+//  * 16 instructions per updated row (compiler: 17) and 21 per sweep besides them (compiler: ~70:
+//    flag registers for "a normal row moved", mask halves moved about, 64-bit compares after
+//    instructions that had already set SCC, the friction-limit refresh in 12 instructions instead
+//    of 8 with the DPP shifts folded into the multiplies);
+//  * the manual wait states of gfx940-class hardware are respected by construction (>= 2 instructions
+//    between a VALU write of an SGPR / VCC and a VALU read of it, >= 2 between a VALU write and a DPP
+//    read, >= 1 before a v_readlane of a freshly written VGPR) - the assembler does not check them
+//    inside inline asm.
+#pragma once
+
+#include "solo_wave_ops.h"
+
+#define SOLO_PGS_GFX950 1
+
+namespace solo {
+
+#ifdef SOLO_STAMPS
+#define SOLO_PGS_COUNT_ROW "s_add_u32 %[nch], %[nch], 1\n\t"
+#else
+#define SOLO_PGS_COUNT_ROW
+#endif
+
+// the walk over the pending rows of window %[w] (entry: %[todo] = pend & w, non-zero): 16 instructions
+// per updated row.  Between a VALU write of an SGPR / VCC and the VALU read of it sit two other
+// instructions (the manual wait states of gfx940-class hardware; the assembler does not check inline asm).
+#define SOLO_PGS_WALK(P)                                                                           \
+  ".Lpgs_%=_" P "_row:\n\t"                                                                        \
+  "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
+  "s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n\t"                                                      \
+  "v_mov_b32_e32 %[col], v64\n\t"             /* its column: v[64 + row] */                        \
+  "s_set_gpr_idx_off\n\t"                                                                          \
+  "v_readlane_b32 %[sd], %[dl], %[rs]\n\t"    /* the change of its impulse */                      \
+  "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
+  "s_lshl_b64 %[t], -2, %[rs]\n\t"                                                                 \
+  "v_fma_f32 %[v], %[sd], %[col], %[v]\n\t"                                                        \
+  "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n\t"                                             \
+  "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n\t"                                                     \
+  "v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n\t"                                                     \
+  "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"                                                       \
+  "s_and_b64 %[w], %[w], %[t]\n\t"            /* the cursor moves past the row */                  \
+  "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"                                                  \
+  SOLO_PGS_COUNT_ROW                                                                               \
+  "s_and_b64 %[todo], %[pend], %[w]\n\t"                                                           \
+  "s_cbranch_scc1 .Lpgs_%=_" P "_row\n"                                                            \
+  ".Lpgs_%=_" P "_end:\n\t"
+
+// Runs the sweeps.  In: v (candidates at lam = 0), lam = 0, cand = clamp(v), dl = cand - lam, pend = rows
+// above the tolerance, lo / hi (friction rows: refreshed here from their normal row's impulse), the
+// resident columns.  Out: lam (the impulses), returns the number of sweeps.  21 instructions per sweep
+// besides the row updates.
+__device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, float& v, float& lam, float& cand, float& dl,
+                                                unsigned long long& pend, float& lo, float& hi, float tol, int lane, float mu,
+                                                unsigned long long tan1_lanes, unsigned long long tangent_lanes,
+                                                unsigned long long phase0, unsigned long long phase1, unsigned long long phase2,
+                                                int iters, int& n_changed) {
+  float thr, col, x1, x2;
+  unsigned long long w, t, todo;
+  int rs, sd, it;
+  asm volatile(
+      "s_sub_u32 %[it], 0, %[iters]\n\t"       // counts up to zero: the carry of the increment is "cap reached"
+      "s_cbranch_scc0 .Lpgs_%=_done\n\t"        // (no sweeps allowed)
+      "s_cmp_lg_u64 %[pend], 0\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_done\n"          // nothing pending at the start of a sweep: converged
+      ".Lpgs_%=_sweep:\n\t"
+      // ---- the non-contact rows (joint motors, joint limits), leg by leg
+      "s_and_b64 %[todo], %[pend], %[ph0]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_p0_end\n\t"
+      "s_mov_b64 %[w], %[ph0]\n"
+      SOLO_PGS_WALK("p0")
+      // ---- all normal rows
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_limits_done\n\t"  // no normal row moves in this sweep: the friction limits stand
+      "s_mov_b64 %[w], %[ph1]\n"
+      SOLO_PGS_WALK("p1")
+      // ---- friction limits = mu x the normal impulse their contact holds NOW (the normal row sits one
+      //      lane below its first friction row, two below the second: DPP row shifts folded into the
+      //      multiply; %[thr] is the threshold of the current impulses - the last row update left it)
+      "v_mul_f32_dpp %[x1], %[lam], %[mu] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %[x2], %[lam], %[mu] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_e64 %[x1], %[x2], %[x1], %[tan1]\n\t"
+      "v_cndmask_b32_e64 %[lo], %[lo], -%[x1], %[tang]\n\t"
+      "v_cndmask_b32_e64 %[hi], %[hi], %[x1], %[tang]\n\t"
+      "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n\t"
+      "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"
+      "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n"
+      ".Lpgs_%=_limits_done:\n\t"
+      // ---- all friction rows
+      "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_p2_end\n\t"
+      "s_mov_b64 %[w], %[ph2]\n"
+      SOLO_PGS_WALK("p2")
+      "s_add_u32 %[it], %[it], 1\n\t"
+      "s_cbranch_scc1 .Lpgs_%=_done\n\t"        // the sweep cap
+      "s_cmp_lg_u64 %[pend], 0\n\t"
+      "s_cbranch_scc1 .Lpgs_%=_sweep\n"
+      ".Lpgs_%=_done:\n\t"
+      : [v] "+v"(v), [lam] "+v"(lam), [cand] "+v"(cand), [dl] "+v"(dl), [lo] "+v"(lo), [hi] "+v"(hi), [pend] "+s"(pend),
+        [thr] "=&v"(thr), [col] "=&v"(col), [x1] "=&v"(x1), [x2] "=&v"(x2),
+        [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [sd] "=&s"(sd), [it] "=&s"(it)
+#ifdef SOLO_STAMPS
+        , [nch] "+s"(n_changed)
+#endif
+      : [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
+        [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes), "{v[64:95]}"(A.a0), "{v[96:127]}"(A.a1)
+      : "vcc", "scc");
+  (void)n_changed;
+  return it + iters;
+}
+
+#undef SOLO_PGS_WALK
+#undef SOLO_PGS_COUNT_ROW
+
+}  // namespace solo

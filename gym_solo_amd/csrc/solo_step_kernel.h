@@ -523,6 +523,20 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   int n_changed = 0;
 #endif
   int it = 0;
+#ifdef SOLO_PGS_GFX950
+  // f32 on the GPU: the loop below, hand-scheduled in assembly (solo_pgs_gfx950.h) - same rows, same
+  // order, same arithmetic; this C++ form stays the definition (f64, and the CPU emulator the GPU
+  // results are compared against bit for bit)
+  if constexpr (sizeof(T) == 4) {
+    int rows_updated = 0;
+    it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu,
+                          wave_ballot(type == ROW_TAN1), wave_ballot(is_tangent), kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2],
+                          iters, rows_updated);
+#ifdef SOLO_STAMPS
+    n_changed = rows_updated;
+#endif
+  } else
+#endif
 #pragma unroll 1
   for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
     // (the register banks of the matrix are walked one after the other - static bank per loop - which
