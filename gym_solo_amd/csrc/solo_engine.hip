@@ -266,7 +266,8 @@ struct Engine final : EngineBase {
       constexpr int kT = sizeof(T) == 4 ? 128 : 64;  // threads per block: ~50 KB of LDS staging either way
       const int gx = (count + kT - 1) / kT, gy = steps < 1024 / gx + 1 ? steps : 1024 / gx + 1;  // ~1000 blocks, each walking steps / gy steps
       hipLaunchKernelGGL((solo::solo_outputs_kernel<T, kT>), dim3(gx, gy), dim3(kT), 0, s, dparams, traj, steps, n, lo,
-                         count, o, o_stride, o_from, r, r_stride);
+                         count, o, o_stride, o_from, r, r_stride, events, (flags & SOLO_STEP_DONE) ? b.done : (uint8_t*)nullptr,
+                         (long long)b.done_stride);
       HIP_TRY(hipGetLastError());
       if (bookkeeping) {
         hipLaunchKernelGGL(solo::solo_returns_kernel<T>, dim3((count + solo::kOutputThreads - 1) / solo::kOutputThreads),

@@ -695,7 +695,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ T s_hext[64][8];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][20];
-  __shared__ int s_cnt[SOLO_MAX_TERMS];     // TimeBased step counters (termination.py:72-83)
+  // termination (termination.py:38-83), one lane per termination (lanes >= SOLO_MAX_TERMS: never fire):
+  // s_cnt = TimeBased step counters, s_termlim = the count above which lane t fires (-1: always - a
+  // Constant(True) -, INT_MAX: never), s_termtick = 1 for the lanes whose counter ticks (TimeBased)
+  __shared__ int s_cnt[64];
+  __shared__ int s_termlim[64];
+  __shared__ int s_termtick[64];
   // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
   // read them from LDS instead of paying a global-load latency each
   __shared__ LegConst<T> s_legc[4];
@@ -738,13 +743,34 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     int32_t* cdst = reinterpret_cast<int32_t*>(&s_const);
     for (int i = lane0; i < kConstWords; i += 64) cdst[i] = csrc[i];
   }
+  // issue priority (see physics_solve): a closed-loop step() is a launch of ONE step - it has no history
+  // of its own, and its slowest robot, one that runs all the sweeps, decides how long the step takes.  A
+  // robot's Gauss-Seidel cost is persistent, so such a launch starts from the sweep count of the robot's
+  // previous step (fused launches build their own history: seeded the same way they were 4 % slower)
   int prio_sweeps = 0, prio_steps = 0;
+  if (B.steps == 1) {
+    const int32_t* cost = wave_cold_args(Bin)->cost;
+    if ((B.flags & SOLO_STEP_PHYSICS) && cost != nullptr) { prio_sweeps = wave_uniform(cost[env]); prio_steps = 1; }
+  }
+  const int hist_sweeps = prio_sweeps;
+  if (prio_steps > 0) wave_set_priority_level(prio_sweeps > 8 ? 3 : wave_slot_id() % 3);  // (thresholds 4 / 8 / 20 / 40 measured: 1.063 / 1.060 / 1.027 / 1.021e8 env-steps/s)
   if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = wave_cold_args(Bin)->state[rec + lane0];
   const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
   const T mass_scale = wave_cold_args(Bin)->params[(size_t)env * 4 + 1];
   // TimeBased counters of this robot live in LDS across the launch's steps (kept in scalar
   // registers next to the termination program they cost 25 SGPR spills in the fused step loop)
-  if (lane0 < SOLO_MAX_TERMS) s_cnt[lane0] = wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane0];
+  s_cnt[lane0] = lane0 < SOLO_MAX_TERMS ? wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane0] : 0;
+  {
+    const int tl = lane0 & (SOLO_MAX_TERMS - 1);
+    const int kind = P0->c.term_kind[tl], param = P0->c.term_param[tl];
+    const bool mine = lane0 < P0->c.num_terms;  // (num_terms <= SOLO_MAX_TERMS)
+    s_termlim[lane0] = (mine && kind == SOLO_T_TIME) ? param : ((mine && kind == SOLO_T_CONST && param != 0) ? -1 : 0x7fffffff);
+    s_termtick[lane0] = (mine && kind == SOLO_T_TIME) ? 1 : 0;
+  }
+  // The auto-reset belongs to a step that advanced the simulation (or asks for it explicitly): a
+  // query-only launch - TerminationFactory.is_terminated() outside step(), termination.py:38-50 - never
+  // mutates the physics state.
+  const bool may_restart = (B.flags & SOLO_STEP_DONE) && (B.flags & (SOLO_STEP_PHYSICS | SOLO_STEP_AUTO_RESET)) && P0->c.auto_reset != 0;
 
   // B.steps consecutive env steps of THIS robot in one launch: the state record stays in LDS,
   // only actions come in and the step records / done flags go out per step.  Robots are independent, so
@@ -791,31 +817,26 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     }
 
     SOLO_STAMP(B, 10);
-    // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83)
+    // ---- termination: OR with short-circuit, per-env TimeBased counters (termination.py:38-83).
+    //      Lane t evaluates termination t on its own counter; once an earlier termination fires, the
+    //      later ones are not ticked (termination.py:46-48).  Branch-free: ~14 instructions.
     bool done = false;
     if (B.flags & SOLO_STEP_DONE) {
-      // lane t evaluates termination t on its own counter (LDS); the OR short-circuits: once an
-      // earlier termination fires, the later ones are not ticked (termination.py:46-48)
-      const int tl = lane & (SOLO_MAX_TERMS - 1);
-      const int kind = C.term_kind[tl], param = C.term_param[tl], cnt = s_cnt[tl] + 1;
-      const bool mine = lane < wave_uniform(C.num_terms);  // (num_terms <= SOLO_MAX_TERMS)
-      const bool fire = mine && ((kind == SOLO_T_TIME && cnt > param) || (kind == SOLO_T_CONST && param != 0));
-      const unsigned long long fired = wave_ballot(fire);
+      const int old = s_cnt[lane];
+      const unsigned long long fired = wave_ballot(old + 1 > s_termlim[lane]);
       done = fired != 0ull;
-      const int first = done ? __builtin_ctzll(fired) : SOLO_MAX_TERMS;  // wave-uniform
-      if (mine && kind == SOLO_T_TIME && lane <= first) s_cnt[lane] = cnt;
+      const int first = done ? __builtin_ctzll(fired) : 63;  // wave-uniform
+      s_cnt[lane] = old + ((s_termtick[lane] != 0 && lane <= first) ? 1 : 0);
     }
-    // The auto-reset belongs to a step that advanced the simulation (or asks for it explicitly):
-    // a query-only launch - TerminationFactory.is_terminated() outside step(), termination.py:38-50
-    // - never mutates the physics state.
-    const bool restart = (B.flags & SOLO_STEP_DONE) && (B.flags & (SOLO_STEP_PHYSICS | SOLO_STEP_AUTO_RESET)) &&
-                         (done || diverged) && wave_uniform(C.auto_reset) != 0;
-    // ---- the step's record for the output kernels (solo_outputs.h): the state after the step,
-    //      before an auto-reset (one coalesced 32-real store), and the step's event bits
+    const bool restart = may_restart && (done || diverged);
+    // ---- the step's record for the output kernels (solo_outputs.h): the state after the step, before
+    //      an auto-reset, as ONE coalesced 32-real store; slot 31 carries the step's event bits (the
+    //      outputs kernel turns them into the events / done arrays: no byte stores from this wave)
     if (B.traj != nullptr) {
+      const T ev = T((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
+      const T word = s_state[lane & (SOLO_STATE_STRIDE - 1)];
       if (lane < SOLO_STATE_STRIDE)
-        B.traj[((size_t)step * B.num_envs + env) * SOLO_STATE_STRIDE + lane] = lane < SOLO_S_RETURN ? s_state[lane] : T(0);
-      if (lane == 0) B.events[(size_t)step * B.num_envs + env] = (uint8_t)((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
+        B.traj[(unsigned)(step * B.num_envs + env) * (unsigned)SOLO_STATE_STRIDE + (unsigned)lane] = lane == SOLO_S_SPARE ? ev : word;
     }
     // closed-loop step() = a single-step launch: its outputs are evaluated right here with the
     // same per-item functions the output kernels use (no second launch on the critical path of a
@@ -861,11 +882,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
       if (restart) {
         wave_sync();  // the record above is read from the old state first
         if (lane < SOLO_S_RETURN) s_state[lane] = wave_cold_args(Bin)->snapshot[rec + lane];
-        if (lane < SOLO_MAX_TERMS) s_cnt[lane] = 0;
+        s_cnt[lane] = 0;
         // reset() leaves the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
         if (lane < SOLO_NUM_JOINTS) wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = C.settle_tgt[lane];
       }
-      if (lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
+      // (a launch that leaves records has its done flags written by the outputs kernel, from slot 31)
+      if (B.traj == nullptr && lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
     }
     SOLO_STAMP(B, 12);
     wave_sync();  // this step's LDS state is complete before the next step reads it
@@ -873,7 +895,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   SOLO_STAMP(B, 13);
   const int lane1 = wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
   if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
-  if ((B.flags & SOLO_STEP_PHYSICS) && lane1 == 0) { int32_t* cost = wave_cold_args(Bin)->cost; if (cost != nullptr) cost[env] = prio_sweeps; }
+  if ((B.flags & SOLO_STEP_PHYSICS) && lane1 == 0) { int32_t* cost = wave_cold_args(Bin)->cost; if (cost != nullptr) cost[env] = prio_sweeps - hist_sweeps; }
   // (slots SOLO_S_RETURN.. of the record are the returns kernel's after a fused launch; a single-step
   // launch that evaluated its reward in place keeps the accumulators itself)
   const bool own_returns = B.reward_inline != nullptr && (B.flags & SOLO_STEP_DONE);
@@ -889,7 +911,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
 constexpr int kOutputThreads = 256;   // returns kernel
 constexpr int kObsStageMax = 32;      // observations of up to this many elements leave through LDS, coalesced
 
-// Observations (steps >= obs_from_step only) and rewards of `steps` x `count` robot-steps.
+// Observations (steps >= obs_from_step only), rewards, event bytes and done flags of `steps` x `count` robot-steps.
 // grid = (ceil(count / kThreads), <= steps): a block owns kThreads consecutive robots of ONE step at a time,
 // whose records are contiguous in traj [steps][num_envs][32] and whose observation rows are
 // contiguous in obs - both move through LDS with fully coalesced accesses (a thread reading its
@@ -899,7 +921,8 @@ template <typename T, int kThreads>
 __global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>* __restrict__ P, const T* __restrict__ traj,
                                                                 int steps, int num_envs, int env_base, int count,
                                                                 T* __restrict__ obs, long long obs_stride, int obs_from_step,
-                                                                T* __restrict__ reward, long long reward_stride) {
+                                                                T* __restrict__ reward, long long reward_stride,
+                                                                uint8_t* __restrict__ events, uint8_t* __restrict__ done, long long done_stride) {
   __shared__ T s_rec[kThreads][SOLO_STATE_STRIDE + 1];        // (+1: conflict-free row access)
   __shared__ T s_val[SOLO_MAX_REWARD_OPS][kThreads];           // reward program values, one column per thread
   __shared__ T s_obs[kThreads][kObsStageMax + 1];
@@ -917,6 +940,11 @@ __global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>
     const bool want_obs = obs != nullptr && k >= obs_from_step;
     if (tid < nb) {
       const T* rec = s_rec[tid];
+      // the step's event bits travel in slot 31 of its record: the events array of the returns kernel and
+      // the caller's done flags ([K][N], or the engine's view: the last step's) are written here, coalesced
+      const int ev = (int)rec[SOLO_S_SPARE];
+      events[(size_t)k * num_envs + env] = (uint8_t)ev;
+      if (done != nullptr && (done_stride != 0 || k == steps - 1)) done[(size_t)k * done_stride + env] = (uint8_t)(ev & kEventDone);
       T roll, pitch, yaw;
       euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
       if (want_obs)

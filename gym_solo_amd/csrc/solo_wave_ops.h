@@ -72,6 +72,20 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
 }
 // the value of lane ^ 8: the other half of the caller's 16-lane row (DPP row_ror:8)
 template <typename T> __device__ __forceinline__ T wave_other_half16(T x) { return dpp_mov<0x128>(x); }
+// the LOWER half's (lanes 8..15 of the row) value in both halves of each 16-lane row, or the UPPER half's:
+// ONE bank-masked DPP move in place (row_ror:8 written only to the banks of the other half), instead of
+// a zeroed temporary, a DPP move and a select
+template <int BANKS> __device__ __forceinline__ float dpp_half_bcast(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x128, 0xf, BANKS, false));
+}
+template <int BANKS> __device__ __forceinline__ double dpp_half_bcast(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp((int)(b & 0xffffffffll), (int)(b & 0xffffffffll), 0x128, 0xf, BANKS, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), 0x128, 0xf, BANKS, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T> __device__ __forceinline__ T wave_from_lower_half16(T x) { return dpp_half_bcast<0x3>(x); }
+template <typename T> __device__ __forceinline__ T wave_from_upper_half16(T x) { return dpp_half_bcast<0xc>(x); }
 // the value of lane - N inside the caller's 16-lane row (DPP row_shr:N; the first N lanes of a row get 0)
 template <int N, typename T> __device__ __forceinline__ T wave_lane_below(T x) { return dpp_mov<0x110 + N>(x); }
 // sum over the 16 lanes of the caller's row, result in every lane (row_ror 8,4,2,1 all-reduce)
@@ -315,7 +329,9 @@ template <> struct Real<float> {
   static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
   static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
   static __device__ __forceinline__ float clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-  static __device__ __forceinline__ bool finite(float x) { return isfinite(x); }
+  // (a bit test, not isfinite(): the build may assume finite math for the arithmetic - see the Makefile -
+  // and this check must keep seeing the NaNs / infinities of a diverged robot)
+  static __device__ __forceinline__ bool finite(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
   static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
   static __device__ __forceinline__ float floor(float x) { return floorf(x); }
   static __device__ __forceinline__ float big() { return 3.0e38f; }
@@ -339,7 +355,7 @@ template <> struct Real<double> {
   static __device__ __forceinline__ double min(double a, double b) { return ::fmin(a, b); }
   static __device__ __forceinline__ double max(double a, double b) { return ::fmax(a, b); }
   static __device__ __forceinline__ double clamp(double x, double lo, double hi) { return ::fmin(::fmax(x, lo), hi); }
-  static __device__ __forceinline__ bool finite(double x) { return isfinite(x); }
+  static __device__ __forceinline__ bool finite(double x) { return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull; }
   static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
   static __device__ __forceinline__ double floor(double x) { return ::floor(x); }
   static __device__ __forceinline__ double big() { return 1.0e300; }

@@ -91,6 +91,10 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
     for (int k = 0; k < steps; ++k)
       for (int e = 0; e < n; ++e) {
         const T* rec = traj.data() + ((size_t)k * n + e) * SOLO_STATE_STRIDE;
+        // (as solo_outputs_kernel: the step's event bits travel in slot 31 of its record)
+        const int ev = (int)rec[SOLO_S_SPARE];
+        events[(size_t)k * n + e] = (uint8_t)ev;
+        if ((flags & SOLO_STEP_DONE) && done) done[(size_t)k * n + e] = (uint8_t)(ev & kEventDone);
         T roll, pitch, yaw, val[SOLO_MAX_REWARD_OPS];
         euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
         if (want_obs) eval_observations<T>(Pp, rec, roll, pitch, yaw, ob.data() + ((size_t)k * n + e) * D);
