@@ -172,9 +172,9 @@ def pmc_profile(dtype):
 
 
 def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
-  """The bound that actually binds (the path is dependent-issue-latency bound, not
-  HBM bound): share of the chip's VALU issue capacity the launches use, from the VALU instruction
-  count per env-step measured with rocprofv3 --pmc SQ_INSTS_VALU (profiles/)."""
+  """The bound that actually binds (the path is bound by the instruction issue rate of one
+  wave per robot, not by HBM): share of the chip's VALU issue capacity the launches use, from the VALU
+  instruction count per env-step measured with rocprofv3 --pmc SQ_INSTS_VALU (profiles/)."""
   valu = pmc.get('valu_insts_per_env_step')
   if not valu:
     return 'dependent-issue-latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype'
@@ -185,9 +185,11 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
   return ('latency bound, not HBM bound: %.0f VALU instructions per env-step (rocprofv3 --pmc SQ_INSTS_VALU, '
           'profiles/pmc_traffic.json) x %d cycles (wave64 on a SIMD-32 shared by %.0f waves, MI355X_MICROARCH.md) x %d '
           'env-steps x %d concurrent launch chains = %.2f of the %d SIMDs\' VALU issue capacity over the measured launch '
-          'duration at %.1f GHz; the rest is dependent-instruction latency of one wave per robot (a Gauss-Seidel row '
-          'update is a ~20-instruction serial chain) and the launch waiting for its slowest robot (profiles/README.md)'
-          % (valu, cyc, waves_per_simd, env_steps_per_launch, chains, util, NUM_SIMDS, clock / 1e9))
+          'duration at %.1f GHz; what binds is the issue rate of ONE wave per robot - one instruction of any kind every ~7 '
+          'cycles (tools/microbench), %s instructions per env-step - and the launch waiting for its slowest robot '
+          '(profiles/README.md)'
+          % (valu, cyc, waves_per_simd, env_steps_per_launch, chains, util, NUM_SIMDS, clock / 1e9,
+             ('%.0f' % pmc['insts_per_env_step']) if pmc.get('insts_per_env_step') else '~2300'))
 
 
 def free_port():

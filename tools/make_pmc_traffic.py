@@ -36,6 +36,8 @@ out = {'float32': {
   'per_kernel': per,
   'algorithmic_bytes_per_env_step': BYTES_PER_ENV_STEP,
   'valu_insts_per_env_step': s['SQ_INSTS_VALU'] / n,
+  'insts_per_env_step': (s['SQ_INSTS'] / n) if 'SQ_INSTS' in s else None,
+  'branch_insts_per_env_step': (s['SQ_INSTS_BRANCH'] / n) if 'SQ_INSTS_BRANCH' in s else None,
   'salu_insts_per_env_step': s['SQ_INSTS_SALU'] / n,
   'lds_insts_per_env_step': s['SQ_INSTS_LDS'] / n,
   'smem_insts_per_env_step': s.get('SQ_INSTS_SMEM', 0.0) / n,
