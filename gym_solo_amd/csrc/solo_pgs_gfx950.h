@@ -1,7 +1,8 @@
 // solo_pgs_gfx950.h — the projected Gauss-Seidel loop of solo_step_kernel.h (f32, register-resident
 // Delassus columns) written directly in gfx950 assembly.  SAME rows, SAME order, SAME arithmetic as
-// the C++ loop in physics_solve (which stays the definition: the f64 instantiation and the CPU wave
-// emulator run it, and the GPU parity tests compare this file against the emulator bit for bit).
+// the C++ loop in physics_solve, which stays the definition: the f64 instantiation and the CPU wave
+// emulator run it, and tests/test_gpu_pgs_asm.py compares this file against it BIT FOR BIT on the GPU
+// (libsolo_hip_pgs_cpp.so: the same translation unit with -DSOLO_PGS_NO_ASM), sweep counts included.
 //
 // Why assembly.  One wave issues one instruction every ~7 cycles whatever the instruction is and whether
 // or not it depends on the one before (tools/microbench/pgs_chain.hip: the row-update block costs
@@ -26,7 +27,9 @@
 
 #include "solo_wave_ops.h"
 
+#ifndef SOLO_PGS_NO_ASM  // (-DSOLO_PGS_NO_ASM: the test build that runs the C++ definition of the loop instead)
 #define SOLO_PGS_GFX950 1
+#endif
 
 namespace solo {
 

@@ -524,9 +524,9 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #endif
   int it = 0;
 #ifdef SOLO_PGS_GFX950
-  // f32 on the GPU: the loop below, hand-scheduled in assembly (solo_pgs_gfx950.h) - same rows, same
-  // order, same arithmetic; this C++ form stays the definition (f64, and the CPU emulator the GPU
-  // results are compared against bit for bit)
+  // f32 on the GPU: the loop below, written in assembly (solo_pgs_gfx950.h) - same rows, same order, same
+  // arithmetic; this C++ form stays the definition (f64, the CPU emulator, and the -DSOLO_PGS_NO_ASM test
+  // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py)
   if constexpr (sizeof(T) == 4) {
     int rows_updated = 0;
     it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu,
