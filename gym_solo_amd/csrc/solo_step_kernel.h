@@ -23,7 +23,9 @@
 //    bounds; the rows that still move are found for all lanes at once (clamp, subtract, compare:
 //    the compare's lane mask is the set) and only those are visited, in solver order (non-contact
 //    rows, normal rows, friction rows), each with one register-indexed move for its column (see
-//    physics_solve).  All branching is wave-uniform: the whole wave belongs to one robot.
+//    physics_solve; the f32 loop itself is written in assembly: solo_pgs_gfx950.h - a wave issues one
+//    instruction every ~7 cycles whatever it is, so the loop's time is its instruction count).  All
+//    branching is wave-uniform: the whole wave belongs to one robot.
 //  * The ~50 scalars a step reads, the per-leg and per-row tables live in LDS for the launch; the
 //    rarely used kernel arguments are re-read from the kernarg segment where they are used.
 //  * Termination (TimeBased counters) and the auto-reset stay in the robot's wave; observations,
