@@ -7,17 +7,19 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from gym_solo_amd import abi
 from bench import build_env
-names = ['loads+sync', 'kinematics', 'crba', 'rne bias', 'schur+sum', 'chol+solve', 'rows', 'A build', 'PGS', 'gather+finish', 'euler+obs', 'reward', 'done', 'store']
+names = ['loads+sync', 'kinematics', 'crba', 'rne bias', 'schur+sum', 'chol+solve', 'rows', 'A build', 'PGS', 'finish+nan check', 'term+record', 'restart+done', 'loop exit', 'epilogue']
+DTYPE = os.environ.get('DTYPE', 'float32')
+TD = torch.float32 if DTYPE == 'float32' else torch.float64
 for n in [int(a) for a in sys.argv[1:]] or (1024, 4096):
-  env = build_env(n, 0, 'float32')
+  env = build_env(n, 0, DTYPE)
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(1234)
-  acts = (torch.rand(64, n, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
+  acts = (torch.rand(64, n, 12, device='cuda', dtype=TD, generator=g) * 2 - 1) * (2 * np.pi)
   eng.rollout(acts, abi.STEP_ALL)
   eng.step(acts[0], abi.STEP_ALL)
   buf = np.zeros((n, 32), dtype=np.uint64)
   eng.lib.solo_engine_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
+  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1 if DTYPE == 'float32' else 0) == 0
   d = np.diff(buf[:, :15].astype(np.int64), axis=1)
   med = np.median(d, axis=0)
   tot = np.median(buf[:, 14].astype(np.int64) - buf[:, 0].astype(np.int64))
@@ -37,15 +39,15 @@ for n in [int(a) for a in sys.argv[1:]] or (1024, 4096):
 
 # ---- fused launches (the bench configuration): how unequal are the robots' 100-step totals? ----
 for n, spl in ((1024, 100), (4096, 100)):
-  env = build_env(n, 0, 'float32', steps_per_launch=spl, rollout_streams=1)
+  env = build_env(n, 0, DTYPE, steps_per_launch=spl, rollout_streams=1)
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(99)
-  acts = (torch.rand(500, n, 12, device='cuda', dtype=torch.float32, generator=g) * 2 - 1) * (2 * np.pi)
+  acts = (torch.rand(500, n, 12, device='cuda', dtype=TD, generator=g) * 2 - 1) * (2 * np.pi)
   eng.rollout(acts, abi.STEP_ALL)                      # into the flailing steady state
   eng.rollout(acts[:spl], abi.STEP_ALL)                # ONE fused launch: its stamps are read back
   buf = np.zeros((n, 32), dtype=np.uint64)
   eng.lib.solo_engine_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
+  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1 if DTYPE == 'float32' else 0) == 0
   t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 14].astype(np.int64)
   per_step = (t1 - t0) / spl
   acc = buf[:, 16:32].astype(np.int64)   # acc[:, i] = ticks before stamp i, summed over the launch; acc[:, 15] = sweeps
@@ -61,6 +63,7 @@ for n, spl in ((1024, 100), (4096, 100)):
     n, spl, np.percentile(per_step, [1, 50, 90, 99, 100]).astype(int).tolist(), (t1.max() - t0.min()) / spl, per_step.mean()))
   env._close()
 
+if DTYPE != 'float32': sys.exit(0)
 # ---- is a robot's cost persistent from one fused launch to the next? (would cost-sorted slices pay?)
 n, spl = 4096, 100
 env = build_env(n, 0, 'float32', steps_per_launch=spl, rollout_streams=1)
@@ -72,7 +75,7 @@ tot = []
 for j in range(4):
   eng.rollout(acts[j * spl:(j + 1) * spl], abi.STEP_ALL)
   buf = np.zeros((n, 32), dtype=np.uint64)
-  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1) == 0
+  assert eng.lib.solo_engine_debug_stamps(eng._h, buf.ctypes.data, 1 if DTYPE == 'float32' else 0) == 0
   tot.append((buf[:, 14].astype(np.int64) - buf[:, 0].astype(np.int64)) / spl)
   hw = (buf[:, 15] >> 28).astype(np.int64); xcc = ((buf[:, 15] >> 24) & 0xf).astype(np.int64)
   simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7

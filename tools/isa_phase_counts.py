@@ -16,7 +16,7 @@ lines = open(path).read().split('\n')
 start = [i for i, l in enumerate(lines) if l.startswith('_ZN4solo16solo_step_kernelI%sLb1EE' % t)][0]
 fe = [i for i, l in enumerate(lines[start:]) if l.startswith('.Lfunc_end')][0] + start
 names = ['prologue', 'loads+sync', 'kinematics', 'crba', 'rne bias', 'schur+sum', 'chol+solve', 'rows', 'A build',
-         'PGS', 'gather+finish', 'euler+obs', 'reward', 'done', 'store', 'tail']
+         'PGS', 'finish+nan check', 'term+record', 'restart+done', 'loop exit', 'epilogue', 'tail']
 new = lambda: {'valu': 0, 'salu': 0, 'lds': 0, 'vmem': 0, 'trans': 0, 'mov': 0, 'rdlane': 0, 'wrlane': 0, 'cnd': 0}
 counts, cur = [], new()
 for l in lines[start:fe]:
