@@ -217,7 +217,13 @@ struct Engine final : EngineBase {
     return launch((const T*)a, flags, s);
   }
 
-  int spl() const { return cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1; }
+  // steps per fused launch: the configured number, capped so that the records of one launch stay below
+  // 2^32 elements (the step kernel addresses them with 32-bit offsets; at 4096 robots that is 32768 steps)
+  int spl() const {
+    const long long cap = ((1ll << 32) - 1) / ((long long)n * SOLO_STATE_STRIDE);
+    const long long want = cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1;
+    return (int)(want < cap ? want : (cap > 1 ? cap : 1));
+  }
 
   // one chain of launches covering steps [0, k) for robots [lo, lo+count): per launch the step
   // kernel (one wave per robot, S fused steps), then - on the same stream - the output kernels
