@@ -26,11 +26,11 @@ case, out = sys.argv[1], sys.argv[2]
 res = {}
 if case == 'flail':      # the bench workload: random targets, robots tumbling over the plane, auto-reset
   from bench import build_env
-  env = build_env(512, 0, 'float32', steps_per_launch=50, rollout_streams=2)
+  env = build_env(4096, 0, 'float32', steps_per_launch=250, rollout_streams=2)   # the bench geometry
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(77)
-  acts = (torch.rand(300, 512, 12, device='cuda', generator=g) * 2 - 1) * (2 * np.pi)
-  o = eng.rollout_buffers(300)
+  acts = (torch.rand(500, 4096, 12, device='cuda', generator=g) * 2 - 1) * (2 * np.pi)
+  o = eng.rollout_buffers(500)
   eng.rollout(acts, abi.STEP_ALL, out=o)
   torch.cuda.synchronize()
   res = dict(state=eng.state.cpu().numpy(), cost=eng.cost.cpu().numpy(),
