@@ -39,82 +39,96 @@ namespace solo {
 #define SOLO_PGS_COUNT_ROW
 #endif
 
-// the walk over the pending rows of window %[w] (entry: %[todo] = pend & w, non-zero): 16 instructions
-// per updated row.  Between a VALU write of an SGPR / VCC and the VALU read of it sit two other
-// instructions (the manual wait states of gfx940-class hardware; the assembler does not check inline asm).
-#define SOLO_PGS_WALK(P)                                                                           \
+// the walk over the pending rows of one phase (lanes PH; entry: %[todo] = pend & PH, non-zero): 15
+// instructions per updated row (the column is not fetched: the FMA reads it register-indexed).  Rows are visited in ascending order, so the rows still to visit after
+// row r are PH & (bits above r) - no window register to initialise per phase.  Between a VALU write of an
+// SGPR / VCC and the VALU read of it sit two other instructions (the manual wait states of gfx940-class
+// hardware; the assembler does not check inline asm).
+#define SOLO_PGS_WALK(P, PH)                                                                       \
   ".Lpgs_%=_" P "_row:\n\t"                                                                        \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
-  "s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n\t"                                                      \
-  "v_mov_b32_e32 %[col], v64\n\t"             /* its column: v[64 + row] */                        \
-  "s_set_gpr_idx_off\n\t"                                                                          \
-  "v_readlane_b32 %[sd], %[dl], %[rs]\n\t"    /* the change of its impulse */                      \
   "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
+  "v_readlane_b32 %[sd], %[dl], %[rs]\n\t"    /* the change of its impulse */                      \
   "s_lshl_b64 %[t], -2, %[rs]\n\t"                                                                 \
-  "v_fma_f32 %[v], %[sd], %[col], %[v]\n\t"                                                        \
+  "s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n\t"                                                      \
+  "v_fma_f32 %[v], v64, %[sd], %[v]\n\t"      /* v += column * change; the column is v[64 + row]: source 0, register-indexed */ \
+  "s_set_gpr_idx_off\n\t"                                                                          \
   "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n\t"                                             \
   "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n\t"                                                     \
   "v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n\t"                                                     \
   "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"                                                       \
-  "s_and_b64 %[w], %[w], %[t]\n\t"            /* the cursor moves past the row */                  \
+  "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor */             \
   "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"                                                  \
   SOLO_PGS_COUNT_ROW                                                                               \
   "s_and_b64 %[todo], %[pend], %[w]\n\t"                                                           \
-  "s_cbranch_scc1 .Lpgs_%=_" P "_row\n"                                                            \
-  ".Lpgs_%=_" P "_end:\n\t"
+  "s_cbranch_scc1 .Lpgs_%=_" P "_row\n\t"
+
+// friction limits = mu x the normal impulse their contact holds NOW (the normal row sits one lane below its
+// first friction row, two below the second: DPP row shifts folded into the multiply; %[thr] is the
+// threshold of the current impulses - the last row update left it), only after a walk over normal rows
+#define SOLO_PGS_LIMITS                                                                            \
+  "v_mul_f32_dpp %[x1], %[lam], %[mu] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                    \
+  "v_mul_f32_dpp %[x2], %[lam], %[mu] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                    \
+  "v_cndmask_b32_e64 %[x1], %[x2], %[x1], %[tan1]\n\t"                                             \
+  "v_cndmask_b32_e64 %[lo], %[lo], -%[x1], %[tang]\n\t"                                            \
+  "v_cndmask_b32_e64 %[hi], %[hi], %[x1], %[tang]\n\t"                                             \
+  "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n\t"                                                     \
+  "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"                                                       \
+  "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"
 
 // Runs the sweeps.  In: v (candidates at lam = 0), lam = 0, cand = clamp(v), dl = cand - lam, pend = rows
 // above the tolerance, lo / hi (friction rows: refreshed here from their normal row's impulse), the
-// resident columns.  Out: lam (the impulses), returns the number of sweeps.  21 instructions per sweep
-// besides the row updates.
+// resident columns.  Out: lam (the impulses), returns the number of sweeps.
+// A sweep costs 8 scalar instructions besides its row updates and the limit refresh (8): one `and` + one
+// branch per phase and the sweep counter with the branch back.  There is no "anything
+// pending?" test in the loop: a sweep starts on the NO-WORK path (labels a1, a2), whose phase tests lead
+// to `done` when all three fail - a sweep that finds work in a phase continues on the other path (b1, b2),
+// which ends in the counter.  One instruction per sweep is one per cent of a closed-loop step: the
+// slowest robot of a step runs all 50 sweeps with three rows moving in each.
 __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, float& v, float& lam, float& cand, float& dl,
                                                 unsigned long long& pend, float& lo, float& hi, float tol, int lane, float mu,
                                                 unsigned long long tan1_lanes, unsigned long long tangent_lanes,
                                                 unsigned long long phase0, unsigned long long phase1, unsigned long long phase2,
                                                 int iters, int& n_changed) {
-  float thr, col, x1, x2;
+  float thr, x1, x2;
   unsigned long long w, t, todo;
   int rs, sd, it;
   asm volatile(
       "s_sub_u32 %[it], 0, %[iters]\n\t"       // counts up to zero: the carry of the increment is "cap reached"
-      "s_cbranch_scc0 .Lpgs_%=_done\n\t"        // (no sweeps allowed)
-      "s_cmp_lg_u64 %[pend], 0\n\t"
-      "s_cbranch_scc0 .Lpgs_%=_done\n"          // nothing pending at the start of a sweep: converged
+      "s_cbranch_scc0 .Lpgs_%=_done\n"          // (no sweeps allowed)
       ".Lpgs_%=_sweep:\n\t"
       // ---- the non-contact rows (joint motors, joint limits), leg by leg
       "s_and_b64 %[todo], %[pend], %[ph0]\n\t"
-      "s_cbranch_scc0 .Lpgs_%=_p0_end\n\t"
-      "s_mov_b64 %[w], %[ph0]\n"
-      SOLO_PGS_WALK("p0")
-      // ---- all normal rows
+      "s_cbranch_scc0 .Lpgs_%=_a1\n"
+      SOLO_PGS_WALK("p0", "%[ph0]")
+      // ---- all normal rows, then the friction limits
       "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
-      "s_cbranch_scc0 .Lpgs_%=_limits_done\n\t"  // no normal row moves in this sweep: the friction limits stand
-      "s_mov_b64 %[w], %[ph1]\n"
-      SOLO_PGS_WALK("p1")
-      // ---- friction limits = mu x the normal impulse their contact holds NOW (the normal row sits one
-      //      lane below its first friction row, two below the second: DPP row shifts folded into the
-      //      multiply; %[thr] is the threshold of the current impulses - the last row update left it)
-      "v_mul_f32_dpp %[x1], %[lam], %[mu] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_mul_f32_dpp %[x2], %[lam], %[mu] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_cndmask_b32_e64 %[x1], %[x2], %[x1], %[tan1]\n\t"
-      "v_cndmask_b32_e64 %[lo], %[lo], -%[x1], %[tang]\n\t"
-      "v_cndmask_b32_e64 %[hi], %[hi], %[x1], %[tang]\n\t"
-      "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n\t"
-      "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"
-      "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n"
-      ".Lpgs_%=_limits_done:\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_b2\n"            // no normal row moves in this sweep: the friction limits stand
+      SOLO_PGS_WALK("p1", "%[ph1]")
+      SOLO_PGS_LIMITS
+      "s_branch .Lpgs_%=_b2\n"
+      // (the same phase for a sweep that has found no work so far)
+      ".Lpgs_%=_a1:\n\t"
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_a2\n"
+      SOLO_PGS_WALK("q1", "%[ph1]")
+      SOLO_PGS_LIMITS
       // ---- all friction rows
+      ".Lpgs_%=_b2:\n\t"
       "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
-      "s_cbranch_scc0 .Lpgs_%=_p2_end\n\t"
-      "s_mov_b64 %[w], %[ph2]\n"
-      SOLO_PGS_WALK("p2")
+      "s_cbranch_scc0 .Lpgs_%=_next\n"
+      ".Lpgs_%=_p2:\n"
+      SOLO_PGS_WALK("p2", "%[ph2]")
+      ".Lpgs_%=_next:\n\t"
       "s_add_u32 %[it], %[it], 1\n\t"
-      "s_cbranch_scc1 .Lpgs_%=_done\n\t"        // the sweep cap
-      "s_cmp_lg_u64 %[pend], 0\n\t"
-      "s_cbranch_scc1 .Lpgs_%=_sweep\n"
+      "s_cbranch_scc0 .Lpgs_%=_sweep\n\t"       // (no carry: below the sweep cap)
+      "s_branch .Lpgs_%=_done\n"
+      ".Lpgs_%=_a2:\n\t"                        // (no work in the first two phases)
+      "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
+      "s_cbranch_scc1 .Lpgs_%=_p2\n"            // (else: nothing pending at the start of a sweep - converged)
       ".Lpgs_%=_done:\n\t"
       : [v] "+v"(v), [lam] "+v"(lam), [cand] "+v"(cand), [dl] "+v"(dl), [lo] "+v"(lo), [hi] "+v"(hi), [pend] "+s"(pend),
-        [thr] "=&v"(thr), [col] "=&v"(col), [x1] "=&v"(x1), [x2] "=&v"(x2),
+        [thr] "=&v"(thr), [x1] "=&v"(x1), [x2] "=&v"(x2),
         [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [sd] "=&s"(sd), [it] "=&s"(it)
 #ifdef SOLO_STAMPS
         , [nch] "+s"(n_changed)
@@ -126,6 +140,7 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
   return it + iters;
 }
 
+#undef SOLO_PGS_LIMITS
 #undef SOLO_PGS_WALK
 #undef SOLO_PGS_COUNT_ROW
 
