@@ -15,10 +15,15 @@
 //  * ONE 64-slot column bank.  The two 32-register tuples of ColumnBank<float> are pinned to
 //    v[64:95] / v[96:127], so a column is `v64` indexed by the row number: three walks per sweep
 //    instead of the compiler's six (one per phase and 32-register tuple);
-//  * 16 instructions per updated row (compiler: 17) and 21 per sweep besides them (compiler: ~70:
-//    flag registers for "a normal row moved", mask halves moved about, 64-bit compares after
-//    instructions that had already set SCC, the friction-limit refresh in 12 instructions instead
-//    of 8 with the DPP shifts folded into the multiplies);
+//  * 15 instructions per updated row (compiler: 17): the column is not fetched into a register - the
+//    FMA reads it register-indexed as its source 0 - and the rows beyond the cursor are the phase's
+//    lanes above it (no window register to carry);
+//  * 16 instructions per sweep besides them (compiler: ~70: flag registers for "a normal row moved",
+//    mask halves moved about, 64-bit compares after instructions that had already set SCC, the
+//    friction-limit refresh in 12 instructions instead of 8 with the DPP shifts folded into the
+//    multiplies), with no "anything pending?" test in the loop.  The slowest robot of a closed-loop
+//    step or a short launch runs all 50 sweeps with ~3 rows moving in each: one instruction per sweep
+//    is 1 % of such a step, one per row 1.5 % (measured);
 //  * the manual wait states of gfx940-class hardware are respected by construction (>= 2 instructions
 //    between a VALU write of an SGPR / VCC and a VALU read of it, >= 2 between a VALU write and a DPP
 //    read, >= 1 before a v_readlane of a freshly written VGPR) - the assembler does not check them
