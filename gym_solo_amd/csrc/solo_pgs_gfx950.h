@@ -99,6 +99,14 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
   unsigned long long w, t, todo;
   int rs, sd, it;
   asm volatile(
+      // The loops below sit at a FIXED position relative to the 64-byte instruction lines (the padding is
+      // jumped over): where a row loop starts within a line moves a closed-loop step by +-2 % (sixteen
+      // positions measured: 1.10 ... 1.15e8 env-steps/s; 12 dwords past a line start is the best), and without
+      // this the position - and with it every timing - changed with any edit of the code in front of the loop
+      "s_branch .Lpgs_%=_entry\n\t"
+      ".p2align 6\n\t"
+      ".fill 12, 4, 0xbf800000\n"              // (s_nop 0)
+      ".Lpgs_%=_entry:\n\t"
       "s_sub_u32 %[it], 0, %[iters]\n\t"       // counts up to zero: the carry of the increment is "cap reached"
       "s_cbranch_scc0 .Lpgs_%=_done\n"          // (no sweeps allowed)
       ".Lpgs_%=_sweep:\n\t"
