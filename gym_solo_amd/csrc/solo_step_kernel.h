@@ -107,8 +107,8 @@ template <typename T> __device__ __forceinline__ V3<T> select(bool p, V3<T> a, V
 // the two halves (k < 8 / k >= 8) of a 16-lane row: sum of both, or the lower half's value in both
 template <typename T> __device__ __forceinline__ T both_halves(T x) { return x + wave_other_half16(x); }
 template <typename T> __device__ __forceinline__ V3<T> both_halves(V3<T> v) { return {both_halves(v.x), both_halves(v.y), both_halves(v.z)}; }
-template <typename T> __device__ __forceinline__ T from_lower(bool lower, T x) { const T o = wave_other_half16(x); return lower ? x : o; }
-template <typename T> __device__ __forceinline__ V3<T> from_lower(bool lower, V3<T> v) { return {from_lower(lower, v.x), from_lower(lower, v.y), from_lower(lower, v.z)}; }
+template <typename T> __device__ __forceinline__ T from_lower(T x) { return wave_from_lower_half16(x); }
+template <typename T> __device__ __forceinline__ V3<T> from_lower(V3<T> v) { return {from_lower(v.x), from_lower(v.y), from_lower(v.z)}; }
 
 
 // ------------------------------------------------------------------------------------------
@@ -118,7 +118,7 @@ template <typename T> __device__ __forceinline__ V3<T> from_lower(bool lower, V3
 template <typename T>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
                                            const RowConst<T>& rc, const T* s_state, T my_target, T (*s_rowvec)[8], T (*s_hext)[8],
-                                           T* s_keep, T (*s_leg)[20], T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps) {
+                                           T* s_keep, T (*s_leg)[20], T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps, int& prio_rot) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = C.dt;
@@ -146,12 +146,11 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   const T q1 = s_state[SOLO_S_Q + 2 * leg], q2 = s_state[SOLO_S_Q + 2 * leg + 1];
   const T qd1 = s_state[SOLO_S_QD + 2 * leg], qd2 = s_state[SOLO_S_QD + 2 * leg + 1];
   // ONE sincos per lane - of its own link's absolute angle (q1 on the upper half, q1 + q2 on the lower) -
-  // and the other link's pair from the other half of the 16-lane row (two DPP moves)
+  // and each link's pair broadcast over both halves of the 16-lane row (bank-masked DPP moves)
   T sinb, cosb;  // this half's link orientation
   R::sincos(lower ? q1 + q2 : q1, &sinb, &cosb);
-  const T sino = wave_other_half16(sinb), coso = wave_other_half16(cosb);
-  const T s1 = lower ? sino : sinb, c1 = lower ? coso : cosb;
-  const T s12 = lower ? sinb : sino, c12 = lower ? cosb : coso;
+  const T s1 = wave_from_upper_half16(sinb), c1 = wave_from_upper_half16(cosb);
+  const T s12 = wave_from_lower_half16(sinb), c12 = wave_from_lower_half16(cosb);
   const V3<T> o1 = {L.hip[0], L.hip[1], L.hip[2]};
   const V3<T> o2 = o1 + roty(c1, s1, V3<T>{L.knee[0], L.knee[1], L.knee[2]});
   const V3<T> ob = select(lower, o2, o1);                // ... and joint origin
@@ -170,10 +169,10 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   const V3<T> f1 = both_halves(mB * t1);
   const V3<T> n1 = both_halves(Iy + mB * cross(c, t1));
   const T P11 = both_halves(mB * dot(t1, t1) + I[1]);
-  const V3<T> f2 = from_lower(lower, mB * t2);
-  const V3<T> n2 = from_lower(lower, Iy + mB * cross(c, t2));
-  const T P12 = from_lower(lower, mB * dot(t1, t2) + I[1]);
-  const T P22 = from_lower(lower, mB * dot(t2, t2) + I[1]);
+  const V3<T> f2 = from_lower(mB * t2);
+  const V3<T> n2 = from_lower(Iy + mB * cross(c, t2));
+  const T P12 = from_lower(mB * dot(t1, t2) + I[1]);
+  const T P22 = from_lower(mB * dot(t2, t2) + I[1]);
   // Cholesky of the 2x2 leg block, W = Lp^-1 [F1;F2], K = P^-1 M_lb = Lp^-T W
   const T iL11 = R::rsqrt(P11);
   const T L21 = P12 * iL11;
@@ -211,7 +210,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   const V3<T> N = symmul(I, a) + cross(wB, Iw) + eB * Iw;
   // joint torques y . (N + r x F): both links load joint 1, the lower one joint 2
   const T h1 = both_halves(N.y + (r1.z * F.x - r1.x * F.z));
-  const T h2 = from_lower(lower, N.y + (r2.z * F.x - r2.x * F.z));
+  const T h2 = from_lower(N.y + (r2.z * F.x - r2.x * F.z));
   const V3<T> Fleg = both_halves(F);
   const V3<T> Nleg = both_halves(N + cross(c, F));
   // e = Lp^-1 h ; y = Lp^-T e = P^-1 h
@@ -475,6 +474,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) A.build(16 * l2 + kk);
     }
+    const unsigned touching_lo = (unsigned)touching, touching_hi = (unsigned)(touching >> 32);
     if (limited != 0ull) {  // (a joint within reach of a limit is rare: one test for all eight rows)
 #pragma unroll
       for (int l2 = 0; l2 < 4; ++l2) {
@@ -488,7 +488,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r0 = 16 * l2 + 2 + 3 * j;
-        if ((touching >> r0) & 1ull) {
+        if (((r0 < 32 ? touching_lo : touching_hi) >> (r0 & 31)) & 1u) {  // (32-bit halves: s_bitcmp1_b32 + branch)
 #pragma unroll
           for (int q = 0; q < 3; ++q) A.build(r0 + q);
         }
@@ -604,7 +604,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // +4 % on the 250-step fused rollout, +2 % at 20 steps; no effect on results.
   prio_sweeps += it;
   prio_steps += 1;
-  wave_set_priority_level(prio_sweeps > 8 * prio_steps ? 3 : (prio_steps + wave_slot_id()) % 3);
+  prio_rot = prio_rot == 2 ? 0 : prio_rot + 1;  // = (prio_steps + wave slot) % 3, without the division
+  wave_set_priority_level(prio_sweeps > 8 * prio_steps ? 3 : prio_rot);
   SOLO_STAMP(B, 9);
   return lamv;
 }
@@ -755,6 +756,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     if ((B.flags & SOLO_STEP_PHYSICS) && cost != nullptr) { prio_sweeps = wave_uniform(cost[env]); prio_steps = 1; }
   }
   const int hist_sweeps = prio_sweeps;
+  int prio_rot = (prio_steps + wave_slot_id()) % 3;  // the rotation's phase (advanced once per step)
   if (prio_steps > 0) wave_set_priority_level(prio_sweeps > 8 ? 3 : wave_slot_id() % 3);  // (thresholds 4 / 8 / 20 / 40 measured: 1.063 / 1.060 / 1.027 / 1.021e8 env-steps/s)
   if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = wave_cold_args(Bin)->state[rec + lane0];
   const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
       const T my_target = raw_target * target_scale;
-      const T lam = physics_solve<T>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, mu, mass_scale, lane, prio_sweeps, prio_steps);
+      const T lam = physics_solve<T>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, mu, mass_scale, lane, prio_sweeps, prio_steps, prio_rot);
       physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, lam, lane);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted

@@ -62,7 +62,8 @@ __device__ __forceinline__ double wave_sum_legs(double x) {
          __longlong_as_double(((long long)c[1] & 0xffffffffll) | ((long long)d[1] << 32));
 }
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+  // (bound_ctrl: lanes without a source read 0 - what `old` = 0 gave - without a zeroed register per move)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
   const long long b = __double_as_longlong(x);

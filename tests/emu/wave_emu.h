@@ -176,6 +176,8 @@ template <typename T> inline T wave_sum_legs(T x) {
   return x;
 }
 template <typename T> inline T wave_other_half16(T x) { return emu_shfl_xor(x, 8); }
+template <typename T> inline T wave_from_lower_half16(T x) { const T o = emu_shfl_xor(x, 8); return (lane_id() & 8) ? x : o; }
+template <typename T> inline T wave_from_upper_half16(T x) { const T o = emu_shfl_xor(x, 8); return (lane_id() & 8) ? o : x; }
 template <int N, typename T> inline T wave_lane_below(T x) {
   const int l = lane_id();
   const T y = wave_readlane(x, (l & 15) >= N ? l - N : l);
