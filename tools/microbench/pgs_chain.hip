@@ -29,7 +29,7 @@ template <int MODE> __global__ __launch_bounds__(64, 4) void k(const float* in, 
                : [v] "+v"(v), [lam] "+v"(lam), [cand] "+v"(cand), [dl] "+v"(dl), [pend] "+s"(pend), [thr] "=&v"(thr), [col] "=&v"(col), \
                  [t] "=&s"(t), [todo] "=&s"(todo), [rs] "+s"(rs), [rn] "=&s"(rn), [sd] "=&s"(sd), [cnt] "+s"(cnt)                \
                : [lane] "v"(lane), [tol] "v"(tol), [lo] "v"(lo), [hi] "v"(hi), [w] "s"(w), "{v[64:95]}"(a0), "{v[96:127]}"(a1)   \
-               : "vcc", "scc")
+               : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63")
   if (MODE == 0) RUN(FETCH READLANE BODY_A CMP TAIL);                 // the real block (row index walks 0..63 via ff1 of all-ones & w -> always 0 here)
   if (MODE == 1) RUN(NOFETCH READLANE BODY_A CMP TAIL);               // no register indexing
   if (MODE == 2) RUN(FETCH "s_mov_b32 %[sd], 0x3a000000\n" BODY_A CMP TAIL);  // no v_readlane
@@ -38,6 +38,9 @@ template <int MODE> __global__ __launch_bounds__(64, 4) void k(const float* in, 
   if (MODE == 5) RUN(FETCH READLANE BODY_A CMP TAIL_CONST_RS);        // the next row index does not depend on this update's scalar chain
   if (MODE == 6) RUN("s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n s_set_gpr_idx_off\n");  // just the mode switches
   if (MODE == 7) RUN(READLANE "s_nop 0\n s_nop 0\n v_fma_f32 %[v], %[sd], %[v], %[v]\n v_sub_f32_e32 %[dl], %[v], %[lam]\n s_nop 0\n");  // readlane -> fma -> (sub) -> readlane round trip
+  if (MODE == 9) RUN("s_ff1_i32_b64 %[rn], %[todo]\n v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n v_readlane_b32 %[sd], %[dl], %[rs]\n s_lshl_b64 %[t], -2, %[rs]\n s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n v_fma_f32 %[v], v64, %[sd], %[v]\n s_set_gpr_idx_off\n v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n v_med3_f32 %[cand], %[v], %[lo], %[hi]\n v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n v_sub_f32_e32 %[dl], %[cand], %[lam]\n s_and_b64 %[t], %[w], %[t]\n v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n s_and_b64 %[todo], %[pend], %[t]\n s_cbranch_scc0 9f\n");  // the 15-instruction row update
+  if (MODE == 10) RUN("s_ff1_i32_b64 %[rn], %[todo]\n v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n v_readlane_b32 %[sd], %[dl], %[rs]\n s_lshl_b64 %[t], -2, %[rs]\n s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n v_fma_f32 %[v], v64, %[sd], %[v]\n s_set_gpr_idx_off\n v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n v_med3_f32 %[cand], %[v], %[lo], %[hi]\n v_pk_fma_f32 v[60:61], v[56:57], v[58:59], v[62:63]\n s_and_b64 %[t], %[w], %[t]\n v_cmp_gt_f32_e64 %[pend], |v60|, |v61|\n s_and_b64 %[todo], %[pend], %[t]\n s_cbranch_scc0 9f\n");  // ... with one packed FMA for thr and dl (14)
+  if (MODE == 12) RUN("s_ff1_i32_b64 %[rn], %[todo]\n v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n v_readlane_b32 %[sd], %[dl], %[rs]\n s_lshl_b64 %[t], -2, %[rs]\n s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n v_fma_f32 %[v], v64, %[sd], %[v]\n s_set_gpr_idx_off\n v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n v_med3_f32 %[cand], %[v], %[lo], %[hi]\n v_mul_f32_e32 %[thr], %[tol], %[lam]\n v_sub_f32_e32 %[dl], %[cand], %[lam]\n s_and_b64 %[t], %[w], %[t]\n v_cmp_gt_f32_e64 %[pend], |%[dl]|, |%[thr]|\n s_and_b64 %[todo], %[pend], %[t]\n s_cbranch_scc0 9f\n");  // thr = tol * lam (4-byte encoding), |thr| in the compare
   if (MODE == 8) RUN(CMP "s_and_b64 %[todo], %[pend], %[w]\n s_ff1_i32_b64 %[rn], %[todo]\n v_add_u32_e32 %[dl], %[rn], %[dl]\n");  // v_cmp -> SALU -> VALU round trip
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * 64 + threadIdx.x] = v + lam + cand + dl + (float)pend + (float)rs;
@@ -66,6 +69,9 @@ int main() {
     run<6>("s_set_gpr_idx_on + off only (+3 loop)", blocks, in);
     run<7>("readlane, 2 nop, fma, sub, nop (+3 loop)", blocks, in);
     run<8>("v_cmp->s_and->s_ff1->v_add (+3 loop)", blocks, in);
+    run<9>("15-instruction row update (+3 loop)", blocks, in);
+    run<12>("  thr = tol * lam, |thr| in the compare", blocks, in);
+    run<10>("14 with v_pk_fma for thr + dl (+3 loop)", blocks, in);
   }
   return 0;
 }
