@@ -735,46 +735,63 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   const KParams<T>* __restrict__ const P0 = Pin;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s_hext[lane0][i] = T(0);
-  {
-    constexpr int kLegWords = (int)(sizeof(LegConst<T>) * 4 / sizeof(T));
-    const T* src = reinterpret_cast<const T*>(P0->leg);
-    T* dst = reinterpret_cast<T*>(s_legc);
-    for (int i = lane0; i < kLegWords; i += 64) dst[i] = src[i];
-    s_rowc[lane0] = P0->row[lane0];
-    constexpr int kConstWords = (int)(sizeof(StepConst<T>) / sizeof(int32_t));
-    const int32_t* csrc = reinterpret_cast<const int32_t*>(&P0->c);
-    int32_t* cdst = reinterpret_cast<int32_t*>(&s_const);
-    for (int i = lane0; i < kConstWords; i += 64) cdst[i] = csrc[i];
-  }
+  // ---- the prologue's global loads, ALL ISSUED BEFORE THE FIRST ONE IS WAITED FOR (written as copy loops
+  //      and load-then-store pairs they were eight exposed round trips to memory, one after the other:
+  //      nothing in a fused launch, 17 % of a closed-loop step, which is a launch of its own)
+  constexpr int kLegWords = (int)(sizeof(LegConst<T>) * 4 / sizeof(T)), kLegLoads = (kLegWords + 63) / 64;
+  constexpr int kConstWords = (int)(sizeof(StepConst<T>) / sizeof(int32_t)), kConstLoads = (kConstWords + 63) / 64;
+  const T* leg_src = reinterpret_cast<const T*>(P0->leg);
+  const int32_t* const_src = reinterpret_cast<const int32_t*>(&P0->c);
+  T leg_w[kLegLoads];
+  int32_t const_w[kConstLoads];
+#pragma unroll
+  for (int j = 0; j < kLegLoads; ++j) leg_w[j] = (lane0 + 64 * j < kLegWords) ? leg_src[lane0 + 64 * j] : T(0);
+  const RowConst<T> row_w = P0->row[lane0];
+#pragma unroll
+  for (int j = 0; j < kConstLoads; ++j) const_w[j] = (lane0 + 64 * j < kConstWords) ? const_src[lane0 + 64 * j] : 0;
+  const T state_w = lane0 < SOLO_STATE_STRIDE ? wave_cold_args(Bin)->state[rec + lane0] : T(0);
+  const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
+  const T mass_scale = wave_cold_args(Bin)->params[(size_t)env * 4 + 1];
+  const int count_w = lane0 < SOLO_MAX_TERMS ? wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane0] : 0;
   // issue priority (see physics_solve): a closed-loop step() is a launch of ONE step - it has no history
   // of its own, and its slowest robot, one that runs all the sweeps, decides how long the step takes.  A
   // robot's Gauss-Seidel cost is persistent, so such a launch starts from the sweep count of the robot's
   // previous step (fused launches build their own history: seeded the same way they were 4 % slower)
-  int prio_sweeps = 0, prio_steps = 0;
+  int hist_w = 0, prio_steps = 0;
   if (B.steps == 1) {
     const int32_t* cost = wave_cold_args(Bin)->cost;
-    if ((B.flags & SOLO_STEP_PHYSICS) && cost != nullptr) { prio_sweeps = wave_uniform(cost[env]); prio_steps = 1; }
+    if ((B.flags & SOLO_STEP_PHYSICS) && cost != nullptr) { hist_w = cost[env]; prio_steps = 1; }
   }
+  // ---- ... and into LDS: the per-leg / per-row / per-step tables, the state record, the TimeBased counters
+  //      (kept in scalar registers next to the termination program they cost 25 SGPR spills in the step loop)
+  {
+    T* leg_dst = reinterpret_cast<T*>(s_legc);
+    int32_t* const_dst = reinterpret_cast<int32_t*>(&s_const);
+#pragma unroll
+    for (int j = 0; j < kLegLoads; ++j) if (lane0 + 64 * j < kLegWords) leg_dst[lane0 + 64 * j] = leg_w[j];
+    s_rowc[lane0] = row_w;
+#pragma unroll
+    for (int j = 0; j < kConstLoads; ++j) if (lane0 + 64 * j < kConstWords) const_dst[lane0 + 64 * j] = const_w[j];
+    if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = state_w;
+    s_cnt[lane0] = count_w;
+  }
+  int prio_sweeps = wave_uniform(hist_w);
   const int hist_sweeps = prio_sweeps;
   int prio_rot = (prio_steps + wave_slot_id()) % 3;  // the rotation's phase (advanced once per step)
   if (prio_steps > 0) wave_set_priority_level(prio_sweeps > 8 ? 3 : wave_slot_id() % 3);  // (thresholds 4 / 8 / 20 / 40 measured: 1.063 / 1.060 / 1.027 / 1.021e8 env-steps/s)
-  if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = wave_cold_args(Bin)->state[rec + lane0];
-  const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
-  const T mass_scale = wave_cold_args(Bin)->params[(size_t)env * 4 + 1];
-  // TimeBased counters of this robot live in LDS across the launch's steps (kept in scalar
-  // registers next to the termination program they cost 25 SGPR spills in the fused step loop)
-  s_cnt[lane0] = lane0 < SOLO_MAX_TERMS ? wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane0] : 0;
-  {
+  wave_sync();
+  {  // the termination tables, from the staged constants
     const int tl = lane0 & (SOLO_MAX_TERMS - 1);
-    const int kind = P0->c.term_kind[tl], param = P0->c.term_param[tl];
-    const bool mine = lane0 < P0->c.num_terms;  // (num_terms <= SOLO_MAX_TERMS)
+    const int kind = s_const.term_kind[tl], param = s_const.term_param[tl];
+    const bool mine = lane0 < s_const.num_terms;  // (num_terms <= SOLO_MAX_TERMS)
     s_termlim[lane0] = (mine && kind == SOLO_T_TIME) ? param : ((mine && kind == SOLO_T_CONST && param != 0) ? -1 : 0x7fffffff);
     s_termtick[lane0] = (mine && kind == SOLO_T_TIME) ? 1 : 0;
   }
   // The auto-reset belongs to a step that advanced the simulation (or asks for it explicitly): a
   // query-only launch - TerminationFactory.is_terminated() outside step(), termination.py:38-50 - never
   // mutates the physics state.
-  const bool may_restart = (B.flags & SOLO_STEP_DONE) && (B.flags & (SOLO_STEP_PHYSICS | SOLO_STEP_AUTO_RESET)) && P0->c.auto_reset != 0;
+  const bool may_restart = (B.flags & SOLO_STEP_DONE) && (B.flags & (SOLO_STEP_PHYSICS | SOLO_STEP_AUTO_RESET)) &&
+                           wave_uniform(s_const.auto_reset) != 0;
 
   // B.steps consecutive env steps of THIS robot in one launch: the state record stays in LDS,
   // only actions come in and the step records / done flags go out per step.  Robots are independent, so
