@@ -863,19 +863,23 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     // same per-item functions the output kernels use (no second launch on the critical path of a
     // policy loop) - lane i takes observation element i / reward leaf i, lane 0 folds the reward
     if (B.obs_inline != nullptr || B.reward_inline != nullptr) {
+      // lane i's observation element / reward instruction come from the parameter block in global memory:
+      // loaded HERE so that the loads fly while the Euler angles are computed
+      // (loaded where they are used they were three exposed round trips at the end of every closed-loop step)
+      const int n_obs = wave_uniform(C.num_obs), n_rops = wave_uniform(C.num_reward_ops);
+      // (lanes beyond a program load its entry 0 - one more address in an already issued load - and never use it)
+      const ObsElemK<T> prog_obs = P0->obs[lane < n_obs ? lane : 0];
+      const RewardInstrK<T> prog_reward = P0->reward[lane < n_rops ? lane : 0];
       T roll, pitch, yaw;
       euler_from_quat<T>(s_state[SOLO_S_QUAT], s_state[SOLO_S_QUAT + 1], s_state[SOLO_S_QUAT + 2], s_state[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
-      const int n_obs = wave_uniform(C.num_obs), n_rops = wave_uniform(C.num_reward_ops);
       if (B.obs_inline != nullptr && lane < n_obs)
-        B.obs_inline[(size_t)env * n_obs + lane] = observation_value<T>(P0->obs[lane], s_state, roll, pitch, yaw);
+        B.obs_inline[(size_t)env * n_obs + lane] = observation_value<T>(prog_obs, s_state, roll, pitch, yaw);
       if (B.reward_inline != nullptr) {
         // lane i holds instruction i and its value: the leaves are evaluated lane-parallel, the
         // combining instructions (SCALE / ADD / MUL over earlier values, three-address form) in
         // program order with wave-uniform v_readlane broadcasts - no LDS, and no chain of dependent
         // scalar loads of the program on lane 0 (~14 x 250 cycles at the end of every closed-loop step)
-        RewardInstrK<T> ri;
-        ri.op = SOLO_R_CONST; ri.src = 0; ri.a = ri.b = ri.c = ri.d = T(0);
-        if (lane < n_rops) ri = P0->reward[lane];
+        const RewardInstrK<T>& ri = prog_reward;  // (lanes >= n_rops hold a copy of instruction 0: evaluated, never read)
         T myval = reward_is_leaf(ri.op) ? reward_leaf<T>(ri, s_state, roll, pitch) : T(0);
         for (int i = 0; i < n_rops; ++i) {
           const int op = wave_readlane_int(ri.op, i);
