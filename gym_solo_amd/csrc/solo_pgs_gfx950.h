@@ -45,10 +45,11 @@ namespace solo {
 #endif
 
 // the walk over the pending rows of one phase (lanes PH; entry: %[todo] = pend & PH, non-zero): 15
-// instructions per updated row (the column is not fetched: the FMA reads it register-indexed).  Rows are visited in ascending order, so the rows still to visit after
-// row r are PH & (bits above r) - no window register to initialise per phase.  Between a VALU write of an
-// SGPR / VCC and the VALU read of it sit two other instructions (the manual wait states of gfx940-class
-// hardware; the assembler does not check inline asm).
+// instructions per updated row (the column is not fetched: the FMA reads it register-indexed).  Rows are
+// visited in ascending order, so the rows still to visit after row r are PH & (bits above r) - no window
+// register to initialise per phase.  Between a VALU write of an SGPR / VCC and the VALU read of it sit two
+// other instructions (the manual wait states of gfx940-class hardware; the assembler does not check
+// inline asm).
 #define SOLO_PGS_WALK(P, PH)                                                                       \
   ".Lpgs_%=_" P "_row:\n\t"                                                                        \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
