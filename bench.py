@@ -59,6 +59,19 @@ def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollo
   return env
 
 
+def desynchronise_episodes(eng, generator, max_steps=1000):
+  """Episode phases are DESYNCHRONISED before anything is timed: all robots start their 1000-step episodes
+  together, so a 20-step window would never see a termination, an auto-reset or a real number in the
+  statistics all-reduce.  The TimeBased counter (and the episode-length accumulator with it) of every
+  robot is seeded uniformly in [0, max_steps): ~K/1000 of the robots finish an episode in a K-step window
+  (the first episode of a robot is the remainder of one: its return covers the steps actually run)."""
+  import torch
+  from gym_solo_amd import abi
+  phase = torch.randint(0, max_steps, (eng.num_envs,), device=eng.state.device, generator=generator, dtype=torch.int32)
+  eng.term_count[:, 0] = phase
+  eng.state[:, abi.S_EPLEN] = phase.to(eng.tdtype)
+
+
 def host_cores():
   """Cores this process may actually use: the GPU box exposes 256 logical CPUs but gives a
   1-GPU job a 16-CPU share (cgroup quota), and oversubscribed OpenMP threads crawl."""
@@ -161,14 +174,24 @@ def pybullet_baseline(seconds_target=5.0):
     return {'available': False, 'note': 'pybullet importable but the run failed: %r' % (e,)}
 
 
-def pmc_profile(dtype):
-  """Per-env-step figures from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
-  written by tools/make_pmc_traffic.py), or {}."""
+def pmc_profile(dtype, spl, slices):
+  """Per-env-step figures from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by
+  tools/make_pmc_traffic.py), or {}.  The file holds one entry per dtype and launch geometry
+  ("float32", "float32_k20", "float64", "float64_k20": fused launches of 250 steps on two stream slices, or
+  the driver's single 20-step launch); the entry measured on THIS run's geometry is used when there is one,
+  else the dtype's other entry - `geometry_match` says which."""
   try:
     with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-      return json.load(f).get(dtype, {})
+      table = json.load(f)
   except Exception:  # noqa: BLE001
     return {}
+  for key, e in table.items():
+    if key.startswith(dtype) and e.get('steps_per_launch') == spl and e.get('launch_chains') == slices:
+      return dict(e, geometry_match=True, profile_key=key)
+  for key in (dtype + '_k20' if spl <= 20 else dtype, dtype, dtype + '_k20'):
+    if key in table:
+      return dict(table[key], geometry_match=False, profile_key=key)
+  return {}
 
 
 def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
@@ -198,24 +221,48 @@ def free_port():
     return s.getsockname()[1]
 
 
-def launch_ranks(n_ranks):
+def launch_ranks(n_ranks, child_cmd=None):
   """N > 1 without a torch.distributed environment: start one child per GPU (this process has not
-  touched the GPU and never will), forward rank 0's stdout, exit with the worst child status."""
+  touched the GPU and never will), forward rank 0's stdout, exit with the worst child status.
+  (child_cmd: the command every rank runs - this script with its own arguments unless a test passes another.)"""
   port = os.environ.get('MASTER_PORT') or str(free_port())
   procs = []
   for r in range(n_ranks):
     env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR='127.0.0.1',
                MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
                SOLO_BENCH_CHILD='1')
-    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+    procs.append(subprocess.Popen(child_cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                   stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-  out, _ = procs[0].communicate()
-  if procs[0].returncode != 0:  # rank 0 failed: do not leave the others waiting in a collective
-    for p in procs[1:]:
+  # rank 0's stdout is drained by a thread while ALL children are polled: the first rank that exits
+  # non-zero (GPU unavailable, import error) takes the others down at once instead of leaving them - and
+  # this parent - waiting in init_process_group / a barrier until the store or RCCL timeout
+  import threading
+  chunks = []
+  reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+  reader.start()
+  failed = None
+  while failed is None and any(p.poll() is None for p in procs):
+    for r, p in enumerate(procs):
+      if p.poll() not in (None, 0):
+        failed = r
+        break
+    time.sleep(0.2)
+  if failed is None:
+    failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+  if failed is not None:
+    print('[bench launcher] rank %d exited with status %d: stopping the other ranks' % (failed, procs[failed].returncode),
+          file=sys.stderr, flush=True)
+    for p in procs:
       if p.poll() is None:
         p.terminate()
-  rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-  sys.stdout.write(out.decode())
+    for p in procs:
+      try:
+        p.wait(timeout=20)
+      except subprocess.TimeoutExpired:
+        p.kill()
+  rcs = [p.wait() for p in procs]
+  reader.join(timeout=10)
+  sys.stdout.write(b''.join(c for c in chunks if c).decode())
   sys.stdout.flush()
   raise SystemExit(max(abs(rc) for rc in rcs))
 
@@ -312,9 +359,14 @@ def main():
       else:
         eng.rollout(acts, abi.STEP_ALL, out=out)
 
+    desynchronise_episodes(eng, gen)
     out = None if closed_loop else eng.rollout_buffers(k)  # every step's obs / reward / done goes to HBM
     if w > 0:
       run(action_pool(w), None if closed_loop else eng.rollout_buffers(w))
+    # ... and ONE untimed repeat of exactly the timed call (same K, same output buffers): first-use costs
+    # (code objects of this launch shape, page faults of the output buffers) stay out of the timed repeats
+    run(action_pool(k), out)
+    barrier()
     times, total = [], None
     while True:
       acts = action_pool(k)
@@ -331,25 +383,47 @@ def main():
         break
     return times, total, eng, env, action_pool, spl, streams
 
+  def roofline(dtype, eng, action_pool, k, spl, streams):
+    """The dominant kernel of a rollout, measured live: HIP events on the streams its launches are issued on
+    (mean over the slices' chains), same rollout path and workload (fresh actions every step); one launch =
+    (n / slices) robots x spl steps; algorithmic bytes per env-step from SURVEY.md 8d."""
+    reps = max(1, min(k, 1000) // spl)
+    kern_ms = statistics.median(eng.time_step(action_pool(reps * spl), abi.STEP_ALL) for _ in range(5 if k <= 100 else 3))
+    slices = streams if (streams > 1 and n >= 2 * streams) else 1
+    env_steps_per_launch = (n // slices) * spl
+    bytes_per_launch = BYTES_PER_ENV_STEP[dtype] * env_steps_per_launch
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    pmc = pmc_profile(dtype, spl, slices)
+    traffic = pmc['hbm_bytes_per_env_step'] * env_steps_per_launch if pmc.get('hbm_bytes_per_env_step') else None
+    return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+            'traffic_note': pmc.get('traffic_note'),
+            'traffic_profile': None if not pmc else {'entry': pmc.get('profile_key'), 'measured_on_this_launch_geometry': pmc.get('geometry_match')},
+            'kernel': eng.kernel_name, 'kernel_ms': kern_ms,
+            'kernel_ms_note': 'HIP events around the launch chain of every slice, on the stream it is launched on; mean per '
+                              'launch over slices and launches; the step kernel alone (the output kernels are separate, short launches)',
+            'bytes_per_env_step': BYTES_PER_ENV_STEP[dtype],
+            'algorithmic_bytes_per_launch': bytes_per_launch, 'env_steps_per_launch': env_steps_per_launch,
+            'concurrent_launch_chains': slices, 'achieved_all_chains': achieved * slices,
+            'note': secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, n / NUM_SIMDS)}, slices
+
   times, stats, eng, env, action_pool, spl, streams = timed(args.dtype, k, False, args.min_seconds, args.max_repeats)
   log('timed region done: %d repeats, stats all-reduce ok (episodes %.0f)' % (len(times), float(stats[2])))
   elapsed = statistics.median(times)
-
-  # dominant kernel: HIP events on the streams its launches are issued on (mean over the slices' chains),
-  # same rollout path and workload (fresh actions every step); one launch = (n / slices) robots x spl steps
-  reps = max(1, min(k, 1000) // spl)
-  kern_ms = statistics.median(eng.time_step(action_pool(reps * spl), abi.STEP_ALL) for _ in range(5 if k <= 100 else 3))
-  kernel_name = eng.kernel_name
+  roof, slices = roofline(args.dtype, eng, action_pool, k, spl, streams)
   env._close()
 
   extra = {}
   if not args.no_extra:
     ke = min(k, 500)  # (bounded intervals: f64 is ~3x, single-step launches ~4x slower per step)
     if args.dtype == 'float32':
-      t64, _, _, e64, _, _, _ = timed('float64', ke, False, 0.3, 10)
+      t64, s64, g64, e64, pool64, spl64, streams64 = timed('float64', ke, False, 0.3, 10)
       extra['value_f64'] = world * n * ke / statistics.median(t64)
       extra['value_f64_note'] = ('same workload and rollout path in float64 (the reference\'s precision, SURVEY.md §8; the '
                                  'parity instantiation of the kernel), median of %d repeats of %d steps' % (len(t64), ke))
+      # the reference-precision kernel's own roofline block: 765 algorithmic bytes per env-step
+      extra['roofline_f64'] = roofline('float64', g64, pool64, ke, spl64, streams64)[0]
+      extra['episodes_f64'] = summarize(s64.cpu().numpy())
       e64._close()
     tcl, _, _, ecl, _, _, _ = timed(args.dtype, ke, True, 0.3, 10)
     extra['value_closed_loop'] = world * n * ke / statistics.median(tcl)
@@ -360,15 +434,6 @@ def main():
 
   if rank == 0:
     value = world * n * k / elapsed
-    slices = streams if (streams > 1 and n >= 2 * streams) else 1
-    robots_per_launch = n // slices
-    env_steps_per_launch = robots_per_launch * spl
-    bytes_per_launch = BYTES_PER_ENV_STEP[args.dtype] * env_steps_per_launch
-    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    pmc = pmc_profile(args.dtype)
-    traffic = None
-    if pmc.get('hbm_bytes_per_env_step'):
-      traffic = pmc['hbm_bytes_per_env_step'] * env_steps_per_launch
     line = {
       'metric': METRIC, 'value': value, 'unit': 'env-steps/s',
       'n_gpus': world, 'steps': k, 'warmup': w, 'ms_per_step': elapsed / k * 1e3,
@@ -376,23 +441,16 @@ def main():
       'dtype': 'f32' if args.dtype == 'float32' else 'f64', 'data': 'synthetic',
       'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
                              'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
-                             'TimeBasedTermination(1000)+auto-reset, dt=1e-3, 50 PGS iterations' % n,
+                             'TimeBasedTermination(1000)+auto-reset (episode phases desynchronised), dt=1e-3, 50 PGS iterations' % n,
                  'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': slices,
                  'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'timing': {'repeats': len(times), 'statistic': 'median', 'min_ms_per_step': min(times) / k * 1e3,
                  'max_ms_per_step': max(times) / k * 1e3, 'value_best_repeat': world * n * k / min(times),
                  'value_worst_repeat': world * n * k / max(times),
-                 'note': 'each repeat = exactly K steps between barrier + device sync on both sides (max over ranks), '
-                         'fresh actions, the simulation continues from repeat to repeat'},
-      'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                   'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                   'traffic_note': pmc.get('traffic_note'),
-                   'kernel': kernel_name, 'kernel_ms': kern_ms,
-                   'kernel_ms_note': 'HIP events around the launch chain of every slice, on the stream it is launched on; mean per '
-                                     'launch over slices and launches; the step kernel alone (the output kernels are separate, short launches)',
-                   'algorithmic_bytes_per_launch': bytes_per_launch, 'env_steps_per_launch': env_steps_per_launch,
-                   'concurrent_launch_chains': slices, 'achieved_all_chains': achieved * slices,
-                   'note': secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, n / NUM_SIMDS)},
+                 'note': 'W warm-up steps and one untimed repeat of the timed call first; then each repeat = exactly K steps '
+                         'between barrier + device sync on both sides (max over ranks), fresh actions, the simulation '
+                         'continues from repeat to repeat; the statistics all-reduce is inside every repeat'},
+      'roofline': roof,
       'episodes': summarize(stats.cpu().numpy()),
     }
     line.update(extra)

@@ -123,7 +123,9 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
   if starting_joint_pos is not None:
     for j, name in enumerate(joint_ordering):
       c.settle_targets[j] = float(starting_joint_pos[name])
-  c.action_scale = float(config.max_motor_rotation) if normalize_actions else 1.0
+  # solo8v2vanilla.py:84-85 multiplies by `self._action_space.high`, the float32 bound of the Box built
+  # at :170-172: 2 pi reaches the motors as 6.2831854820251465 (float64 arithmetic on a float32 value)
+  c.action_scale = float(np.float32(config.max_motor_rotation)) if normalize_actions else 1.0
   c.auto_reset = 1 if config.auto_reset else 0
   c.steps_per_launch = max(1, int(getattr(config, 'steps_per_launch', 1)))
   c.rollout_streams = max(1, int(getattr(config, 'rollout_streams', 1)))

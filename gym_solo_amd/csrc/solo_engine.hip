@@ -418,7 +418,27 @@ struct Engine final : EngineBase {
   int set_order(const int32_t* o, hipStream_t s) override {
     HIP_TRY(hipSetDevice(device));
     if (o == nullptr) { use_order = false; return SOLO_OK; }
-    HIP_TRY(hipMemcpyAsync(order, o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    // The step kernel uses order[slot] as the robot index of every buffer it addresses, and the output kernels
+    // of a rollout slice read the records of that slice's robots: the table is validated here, once per upload
+    // (a rare call; blocking) - a permutation of [0, N) that maps every rollout slice onto itself.
+    std::vector<int32_t> h((size_t)n);
+    HIP_TRY(hipMemcpyAsync(h.data(), o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint8_t> seen((size_t)n, 0);
+    const int groups = slices();
+    for (int g = 0; g < groups; ++g) {
+      const int lo = (int)((long long)n * g / groups), hi = (int)((long long)n * (g + 1) / groups);
+      for (int i = lo; i < hi; ++i) {
+        const int32_t e = h[(size_t)i];
+        if (e < lo || e >= hi || seen[(size_t)e]) {
+          err = "launch order must be a permutation of [0, num_envs) that keeps every rollout slice's robots in that slice";
+          return SOLO_ERR_INVALID_ARG;
+        }
+        seen[(size_t)e] = 1;
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(order, h.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (h goes out of scope)
     use_order = true;
     return SOLO_OK;
   }

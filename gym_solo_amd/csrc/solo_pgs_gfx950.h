@@ -152,7 +152,7 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 #endif
       : [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
         [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes), "{v[64:95]}"(A.a0), "{v[96:127]}"(A.a1)
-      : "vcc", "scc");
+      : "vcc", "scc", "m0");  // (s_set_gpr_idx_on writes M0)
   (void)n_changed;
   return it + iters;
 }

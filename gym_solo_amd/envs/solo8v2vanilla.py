@@ -141,6 +141,12 @@ class Solo8VanillaEnv(Solo8BaseEnv):
         self.client.state_version += 1  # (the launch above restored the finished robots)
       elif done is True or (hasattr(done, 'any') and bool(done.any())):
         self.reset_where(done)
+        if done is True:
+          # host-side terminations are per-object, not per-robot: a scalar True ended the episode of the
+          # whole batch, so their per-episode state restarts with it (reset(), solo8v2vanilla.py:110-143;
+          # left alone, a TimeBasedTermination stays past its limit and the batch is reset every step).
+          # A per-robot flag tensor comes from a custom termination that keeps per-robot state itself.
+          self.termination_factory.reset()
     return obs_values, reward, done, {'labels': obs_labels}
 
   def reset_where(self, done):

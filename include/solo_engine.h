@@ -296,7 +296,9 @@ int solo_engine_set_terrain(SoloEngine* eng, const SoloTerrain* terrain, void* s
  * the positions [N g / G, N (g+1) / G) must hold a permutation of the same robot range (every slice
  * keeps its robots).  Results do not depend on the order (robots are independent); it matters when
  * N exceeds the 4096 resident waves of the chip: dispatching the costliest robots first (view.cost,
- * descending) keeps the tail of a launch short.  Copied into an engine-owned buffer. */
+ * descending) keeps the tail of a launch short.  Copied into an engine-owned buffer.  The table is
+ * VALIDATED on upload (one device-to-host copy, synchronises `stream`): anything but such a permutation
+ * returns SOLO_ERR_INVALID_ARG and leaves the previous order in force. */
 int solo_engine_set_order(SoloEngine* eng, const int32_t* order_dev, void* stream);
 /* name of the dominant kernel (for rocprof cross-checks) and its last launch geometry */
 const char* solo_engine_kernel_name(SoloEngine* eng);

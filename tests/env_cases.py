@@ -100,6 +100,22 @@ def case_action_normalization(make_env):
     np.testing.assert_array_equal(np_(env.engine.targets), np.full((env.num_envs, 12), expect))
 
 
+def case_action_normalization_float32_bound(make_env):
+  # solo8v2vanilla.py:84-85 scales by `self._action_space.high`: the FLOAT32 bound of the Box built at
+  # :170-172, in float64 arithmetic.  Known answer for the default 2 pi: a normalised 1.0 reaches the
+  # motors as 6.2831854820251465, not as the double 2 pi (6.283185307179586)
+  config = Solo8VanillaConfig()
+  config.dtype = 'float64'
+  env = make_env(config=config, normalize_actions=True)
+  env.obs_factory.register_observation(CompliantObs(None))
+  env.termination_factory.register_termination(DummyTermination(0, True))
+  env.reward_factory.register_reward(1, SimpleReward())
+  assert float(np.float32(2 * np.pi)) == 6.2831854820251465
+  for a in (1., -1., 0.5):
+    env.step([a] * 12)
+    np.testing.assert_array_equal(np_(env.engine.targets), np.full((env.num_envs, 12), a * 6.2831854820251465))
+
+
 def case_reset(make_env):
   # test_solo8v2vanilla.py:141-163
   env = make_env()
@@ -241,3 +257,41 @@ def case_reset_restores_motor_targets(make_env, dtype='float64'):
   env.client.stepSimulation()
   fresh.client.stepSimulation()
   np.testing.assert_array_equal(np_(env.engine.state)[:, :29], np_(fresh.engine.state)[:, :29])
+
+
+class _PythonOnlyTimeLimit(terms.Termination):
+  """A host-side time limit without program(): forces every termination onto the host."""
+
+  def __init__(self, limit):
+    self.limit = limit
+    self.reset()
+
+  def reset(self):
+    self.ticks = 0
+
+  def is_terminated(self):
+    self.ticks += 1
+    return self.ticks > self.limit
+
+
+def case_host_termination_auto_reset(make_env, dtype='float64'):
+  """auto_reset with a Python-only termination: the scalar True of the host evaluation restores the
+  robots AND restarts the host-side terminations' episode state (a TimeBasedTermination next to it
+  included), so the next episode runs its full length instead of ending every step."""
+  cfg = Solo8VanillaConfig()
+  cfg.dtype, cfg._dtype_pinned, cfg.auto_reset = dtype, True, True
+  env = make_env(config=cfg)
+  env.obs_factory.register_observation(solo_obs.TorsoIMU(env.robot))
+  env.reward_factory.register_reward(1, SimpleReward())
+  env.termination_factory.register_termination(_PythonOnlyTimeLimit(2), terms.TimeBasedTermination(5))
+  env._ensure_program()
+  assert env._fused['done'] is False
+  home = np_(env.engine.snapshot)[:, :29].copy()
+  flags = []
+  for k in range(9):
+    _, _, d, _ = env.step(np.full(12, 0.3))
+    flags.append(bool(d is True or (hasattr(d, 'all') and np_(d).all())))
+    if flags[-1]:
+      np.testing.assert_array_equal(np_(env.engine.state)[:, :29], home)  # restored ...
+  # ... and three-step episodes keep coming: done on the third step of each, False in between
+  assert flags == [False, False, True] * 3

@@ -24,7 +24,9 @@ def test_self_launch_fails_loudly_without_gpu():
     pytest.skip('CPU-side check (a GPU box runs the real thing)')
   r = _run(['--gpus', '2', '--steps', '20', '--warmup', '5'])
   assert r.returncode != 0
-  assert r.stderr.count('needs an MI355X') == 2 and 'torch.distributed.run' not in r.stderr
+  # (both ranks fail at once; the launcher stops the rest as soon as it sees the first failure)
+  assert 1 <= r.stderr.count('needs an MI355X') <= 2 and 'torch.distributed.run' not in r.stderr
+  assert '[bench launcher] rank' in r.stderr
   r = _run(['--gpus', '1', '--steps', '20'])
   assert r.returncode != 0 and 'needs an MI355X' in r.stderr
 
@@ -32,3 +34,23 @@ def test_self_launch_fails_loudly_without_gpu():
 def test_world_size_mismatch_is_reported():
   r = _run(['--gpus', '2'], env={'RANK': '0', 'WORLD_SIZE': '3'})
   assert r.returncode != 0 and 'WORLD_SIZE=3' in r.stderr
+
+
+def test_a_dying_peer_rank_stops_rank_zero_at_once():
+  """A rank > 0 that exits non-zero (no GPU, import error) must not leave rank 0 - and the parent -
+  waiting in a rendezvous until some timeout: the launcher polls every child and stops the rest."""
+  import time
+  import pytest
+  sys.path.insert(0, ROOT)
+  import bench
+  child = [sys.executable, '-c',
+           'import os, sys, time\n'
+           'if os.environ["RANK"] == "0":\n'
+           '  print("rank0 alive", flush=True); time.sleep(300)\n'
+           'else:\n'
+           '  time.sleep(1); sys.exit(3)\n']
+  t0 = time.time()
+  with pytest.raises(SystemExit) as e:
+    bench.launch_ranks(2, child_cmd=child)
+  assert time.time() - t0 < 60
+  assert e.value.code not in (0, None)

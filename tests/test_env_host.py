@@ -43,6 +43,10 @@ def test_action_normalization():
   cases.case_action_normalization(make_env)
 
 
+def test_action_normalization_float32_bound():
+  cases.case_action_normalization_float32_bound(make_env)
+
+
 def test_reset():
   cases.case_reset(make_env)
 
@@ -119,3 +123,7 @@ def test_make_and_vector_adapter(monkeypatch):
   cfg2.dtype, cfg2.num_envs = 'float64', 2
   with pytest.raises(ValueError):
     Solo8VectorEnv(make_env(config=cfg2))
+
+
+def test_host_termination_with_auto_reset_restarts_the_episode():
+  cases.case_host_termination_auto_reset(make_env)

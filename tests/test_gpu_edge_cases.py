@@ -242,6 +242,31 @@ def test_launch_order_does_not_change_results(torch, streams):
       np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('streams', [1, 2])
+def test_invalid_launch_order_is_rejected(torch, streams):
+  """solo_engine_set_order validates its table on upload: out-of-range entries, duplicates and - with
+  rollout slices - robots that leave their slice are SOLO_ERR_INVALID_ARG (ValueError), and the engine
+  keeps stepping with the previous order."""
+  eng, ca, ma = _engine(8, 'float32', rollout_streams=streams)
+  ident = torch.arange(8, dtype=torch.int32, device='cuda')
+  bad = [ident.clone() for _ in range(3)]
+  bad[0][3] = 8            # out of range
+  bad[1][3] = -1
+  bad[2][5] = bad[2][4]    # duplicate
+  if streams == 2:
+    swapped = ident.clone()
+    swapped[0], swapped[7] = 7, 0   # a permutation, but robots cross the slice boundary
+    bad.append(swapped)
+  for o in bad:
+    with pytest.raises(ValueError):
+      eng.set_order(o)
+  eng.set_order(ident.flip(0) if streams == 1 else torch.cat([ident[:4].flip(0), ident[4:].flip(0)]))
+  eng.step(torch.zeros(8, 12, device='cuda'), abi.STEP_PHYSICS)
+  eng.synchronize()
+  assert bool(torch.isfinite(eng.state).all())
+  eng.close()
+
+
 def test_fast_spin_takes_the_library_rotation_path(torch):
   """The f32 rotation update uses even Taylor polynomials in (|w| dt / 2)^2 and falls back to the
   library sincos above 1/16 (|w| > 500 rad/s): a base spinning at 300 / 700 rad/s in the air, one

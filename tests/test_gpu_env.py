@@ -37,6 +37,10 @@ def test_action_normalization():
   cases.case_action_normalization(make_env)
 
 
+def test_action_normalization_float32_bound():
+  cases.case_action_normalization_float32_bound(make_env)
+
+
 def test_reset():
   cases.case_reset(make_env)
 
@@ -319,3 +323,7 @@ def test_full_size_properties_f32(n, terrain):
   eng.rollout(acts[:50], abi.STEP_ALL)
   assert torch.equal(a, eng.state)
   env._close()
+
+
+def test_host_termination_with_auto_reset_restarts_the_episode():
+  cases.case_host_termination_auto_reset(make_env)

@@ -59,7 +59,7 @@ def _run(lib, case, tmp_path):
 @pytest.mark.parametrize('case', ['flail', 'cap3', 'exact', 'one'])
 def test_assembly_loop_equals_cpp_loop_bit_for_bit(case, tmp_path):
   asm_lib, cpp_lib = os.path.join(CSRC, 'libsolo_hip.so'), os.path.join(CSRC, 'libsolo_hip_pgs_cpp.so')
-  assert os.path.isfile(cpp_lib), 'build it: make -C gym_solo_amd/csrc (or __graft_entry__.build())'
+  assert os.path.isfile(cpp_lib), 'build it: make -C gym_solo_amd/csrc test-libs (or __graft_entry__.build())'
   a, b = _run(asm_lib, case, tmp_path), _run(cpp_lib, case, tmp_path)
   assert set(a.files) == set(b.files)
   for k in a.files:

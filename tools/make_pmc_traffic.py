@@ -1,6 +1,8 @@
 """profiles/pmc_traffic.json from the PMC summaries of tools/refresh_profiles.sh.
 
-usage: python tools/make_pmc_traffic.py gpurun_out/<tag>   (reads pmc_hbm_f32.json, pmc_sq_f32.json)
+usage: python tools/make_pmc_traffic.py gpurun_out/<tag> <config>   (config = f32 | f32_k20 | f64 | f64_k20:
+reads pmc_hbm_<config>.json, pmc_sq_<config>.json, prof_driver_<config>.json; MERGES the entry
+"float32" / "float32_k20" / "float64" / "float64_k20" into profiles/pmc_traffic.json)
 
 Everything is normalised PER ENV-STEP, so that bench.py can scale it to the launch size of its own
 run (roofline.traffic = hbm_bytes_per_env_step x env_steps_per_launch of that run).  FETCH_SIZE /
@@ -11,13 +13,14 @@ step kernel loads one dword per lane (uncalibrated: raw value kept); the outputs
 records and rows coalesced (dword per lane as well).  The raw figures are reported, with the
 2x-on-reads upper bound next to them."""
 import json, os, sys
-src = sys.argv[1]
+src, cfg = sys.argv[1], (sys.argv[2:] or ['f32'])[0]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-hbm = json.load(open(os.path.join(src, 'pmc_hbm_f32.json')))
-sq = json.load(open(os.path.join(src, 'pmc_sq_f32.json')))
-meta = json.load(open(os.path.join(src, 'prof_driver.json')))   # robots per launch, steps per launch
+hbm = json.load(open(os.path.join(src, 'pmc_hbm_%s.json' % cfg)))
+sq = json.load(open(os.path.join(src, 'pmc_sq_%s.json' % cfg)))
+meta = json.load(open(os.path.join(src, 'prof_driver_%s.json' % cfg)))   # robots per launch, steps per launch
 n = meta['robots_per_launch'] * meta['steps_per_launch']       # env-steps one launch (of each kernel) covers
-BYTES_PER_ENV_STEP = 385                                         # bench.py / SURVEY.md §8d (f32)
+BYTES_PER_ENV_STEP = {'float32': 385, 'float64': 765}[meta['dtype']]   # bench.py / SURVEY.md §8d
+key = meta['dtype'] + ('_k20' if cfg.endswith('_k20') else '')
 per = {}
 for fam in ('step', 'outputs', 'returns'):
   h = hbm.get(fam, {})
@@ -27,8 +30,9 @@ rd = sum(p['read_bytes_per_env_step'] for p in per.values())
 wr = sum(p['write_bytes_per_env_step'] for p in per.values())
 s = sq['step']
 wave_cycles = s.get('SQ_WAVE_CYCLES')
-out = {'float32': {
+out = {key: {
   'env_steps_per_profiled_launch': n,
+  'steps_per_launch': meta['steps_per_launch'], 'robots_per_launch': meta['robots_per_launch'], 'launch_chains': meta.get('launch_chains', 1),
   'hbm_bytes_per_env_step': rd + wr,
   'hbm_read_bytes_per_env_step': rd,
   'hbm_write_bytes_per_env_step': wr,
@@ -55,10 +59,15 @@ out = {'float32': {
                   'KB x 1024, step + outputs + returns kernels of one fused launch of %d robots x %d steps) x this run\'s '
                   'env-steps per launch; raw FETCH_SIZE (dword-per-lane loads: uncalibrated width; with the guide\'s 2x '
                   'correction for wide reads the total would be %.0f B/env-step); algorithmic figure of the whole path: %d '
-                  'B/env-step (a fused launch neither re-reads nor re-writes the 116-B state per step, and the returns '
-                  'kernel reads 5 B/env-step)' % (meta['robots_per_launch'], meta['steps_per_launch'], 2 * rd + wr, BYTES_PER_ENV_STEP),
+                  'B/env-step (a fused launch neither re-reads nor re-writes the state record per step, and the returns '
+                  'kernel reads one reward + one event byte per env-step)' % (meta['robots_per_launch'], meta['steps_per_launch'], 2 * rd + wr, BYTES_PER_ENV_STEP),
   'how': 'tools/refresh_profiles.sh: tools/prof_driver.py (bench workload, every step recorded) under rocprofv3 --pmc, one '
          'pass per counter group; tools/pmc_summary.py averages the last 6 full-size dispatches per kernel'}}
 path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-json.dump(out, open(path, 'w'), indent=1)
+try:
+  table = json.load(open(path))
+except Exception:
+  table = {}
+table.update(out)
+json.dump(table, open(path, 'w'), indent=1)
 print(json.dumps(out, indent=1))
