@@ -363,12 +363,7 @@ def main():
     out = None if closed_loop else eng.rollout_buffers(k)  # every step's obs / reward / done goes to HBM
     if w > 0:
       run(action_pool(w), None if closed_loop else eng.rollout_buffers(w))
-    # ... and ONE untimed repeat of exactly the timed call (same K, same output buffers): first-use costs
-    # (code objects of this launch shape, page faults of the output buffers) stay out of the timed repeats
-    run(action_pool(k), out)
-    barrier()
-    times, total = [], None
-    while True:
+    def one_repeat():
       acts = action_pool(k)
       stats_before = eng.stats_shards.clone()
       barrier()
@@ -377,7 +372,16 @@ def main():
       # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI
       stats = all_reduce_stats((eng.stats_shards - stats_before).sum(dim=0))
       barrier()  # (all_reduce_stats is a no-op without an initialised process group)
-      times.append(max_over_ranks(time.perf_counter() - t0))
+      return max_over_ranks(time.perf_counter() - t0), stats
+
+    # ... and ONE untimed repeat of exactly the timed region (same K, same output buffers, the statistics
+    # reduction included): first-use costs - code objects of this launch shape and of torch's small kernels,
+    # page faults of the output buffers - stay out of the timed repeats
+    one_repeat()
+    times, total = [], None
+    while True:
+      t, stats = one_repeat()
+      times.append(t)
       total = stats if total is None else total + stats
       if sum(times) >= min_seconds or len(times) >= max_repeats:
         break
@@ -446,7 +450,7 @@ def main():
                  'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'timing': {'repeats': len(times), 'statistic': 'median', 'min_ms_per_step': min(times) / k * 1e3,
                  'max_ms_per_step': max(times) / k * 1e3, 'value_best_repeat': world * n * k / min(times),
-                 'value_worst_repeat': world * n * k / max(times),
+                 'value_worst_repeat': world * n * k / max(times), 'first_repeats_ms_per_step': [t / k * 1e3 for t in times[:6]],
                  'note': 'W warm-up steps and one untimed repeat of the timed call first; then each repeat = exactly K steps '
                          'between barrier + device sync on both sides (max over ranks), fresh actions, the simulation '
                          'continues from repeat to repeat; the statistics all-reduce is inside every repeat'},

@@ -241,7 +241,7 @@ struct Engine final : EngineBase {
       if (done_out) { b.done = done_out + (size_t)i * n; b.done_stride = n; }
       // a single-step launch (closed-loop step(), or a rollout with steps_per_launch = 1) evaluates
       // its outputs inside the step kernel; a fused launch leaves records for the output kernels
-      const bool inline_outputs = steps == 1 && (want_obs || want_reward);
+      const bool inline_outputs = steps == 1 && (want_obs || want_reward) && solo::kInlineOutputs<T, true>;
       if (inline_outputs) {
         if (want_obs) b.obs_inline = obs_out ? obs_out + (size_t)i * n * obs_dim : obs;
         if (want_reward) b.reward_inline = reward_out ? reward_out + (size_t)i * n : reward;

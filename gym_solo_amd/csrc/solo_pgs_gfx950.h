@@ -152,13 +152,131 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 #endif
       : [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
         [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes), "{v[64:95]}"(A.a0), "{v[96:127]}"(A.a1)
-      : "vcc", "scc", "m0");  // (s_set_gpr_idx_on writes M0)
+      : "vcc", "scc");
+  // (s_set_gpr_idx_on overwrites M0.  M0 is a RESERVED register for the AMDGPU backend - naming it in the clobber
+  // list draws "reserved registers on the clobber list may not be preserved ... undefined behaviour" from clang -
+  // and the backend never keeps a value live in it across statements: it (re)writes M0 immediately before each
+  // of its own uses - LDS-direct, s_movrel, sendmsg.  `make asm`: no m0 reference in the generated code.)
   (void)n_changed;
   return it + iters;
 }
 
 #undef SOLO_PGS_LIMITS
 #undef SOLO_PGS_WALK
+
+// ---- the same loop in f64 (round 3): the reference's precision, the parity path ---------------------------
+// Columns: 64 doubles per lane in v[128:255] (ColumnBank<double>: four 16-wide tuples), column r = v[128 + 2 r :
+// 129 + 2 r], read register-indexed as source 0 of the v_fma_f64 (index 2 r).  The 64-bit loop variables whose
+// HALVES are touched (v_cndmask_b32 / v_readlane_b32 / DPP moves work on dwords) sit in fixed registers - an
+// inline-asm operand cannot be sliced - : lam v[114:115], cand v[116:117], dl v[118:119], lo v[120:121],
+// hi v[122:123], x1 v[124:125], x2 v[126:127]; the impulse change of the updated row in s[94:95].
+// 19 instructions per updated row (the compiler's loop over LDS-evaluated columns: ~40), no v_med3 in f64:
+// v_max_f64 + v_min_f64, exactly Real<double>::clamp.  Same rows, same order, same arithmetic as the C++ loop
+// (tests/test_gpu_pgs_asm.py compares the two bit for bit in f64 too).
+#define SOLO_PGS_WALK64(P, PH)                                                                     \
+  ".Lpgs64_%=_" P "_row:\n\t"                                                                      \
+  "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
+  "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
+  "v_readlane_b32 s94, v118, %[rs]\n\t"       /* the change of its impulse */                      \
+  "v_readlane_b32 s95, v119, %[rs]\n\t"                                                            \
+  "s_lshl_b32 %[ri], %[rs], 1\n\t"            /* register index of the column: 2 x row */          \
+  "s_lshl_b64 %[t], -2, %[rs]\n\t"                                                                 \
+  "s_set_gpr_idx_on %[ri], gpr_idx(SRC0)\n\t"                                                      \
+  "v_fma_f64 %[v], v[128:129], s[94:95], %[v]\n\t"  /* v += column * change (source 0 register-indexed) */ \
+  "s_set_gpr_idx_off\n\t"                                                                          \
+  "v_cndmask_b32_e32 v114, v114, v116, vcc\n\t"   /* lam[row] = cand[row] */                       \
+  "v_cndmask_b32_e32 v115, v115, v117, vcc\n\t"                                                    \
+  "v_max_f64 v[116:117], %[v], v[120:121]\n\t"                                                     \
+  "v_min_f64 v[116:117], v[116:117], v[122:123]\n\t"                                               \
+  "v_mul_f64 %[thr], %[tol], |v[114:115]|\n\t"                                                     \
+  "v_add_f64 v[118:119], v[116:117], -v[114:115]\n\t"                                              \
+  "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor */             \
+  "v_cmp_gt_f64_e64 %[pend], |v[118:119]|, %[thr]\n\t"                                             \
+  SOLO_PGS_COUNT_ROW                                                                               \
+  "s_and_b64 %[todo], %[pend], %[w]\n\t"                                                           \
+  "s_cbranch_scc1 .Lpgs64_%=_" P "_row\n\t"
+
+// friction limits = mu x the normal impulse their contact holds now (DPP row shifts of the two dwords)
+#define SOLO_PGS_LIMITS64                                                                          \
+  "v_mov_b32_dpp v124, v114 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
+  "v_mov_b32_dpp v125, v115 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
+  "v_mov_b32_dpp v126, v114 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
+  "v_mov_b32_dpp v127, v115 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
+  "v_cndmask_b32_e64 v124, v126, v124, %[tan1]\n\t"                                                \
+  "v_cndmask_b32_e64 v125, v127, v125, %[tan1]\n\t"                                                \
+  "v_mul_f64 v[124:125], %[mu], v[124:125]\n\t"                                                    \
+  "v_cndmask_b32_e64 v120, v120, v124, %[tang]\n\t"    /* lo = -lim (the sign lives in the high dword) */ \
+  "v_cndmask_b32_e64 v121, v121, -v125, %[tang]\n\t"                                               \
+  "v_cndmask_b32_e64 v122, v122, v124, %[tang]\n\t"    /* hi = lim */                              \
+  "v_cndmask_b32_e64 v123, v123, v125, %[tang]\n\t"                                                \
+  "v_max_f64 v[116:117], %[v], v[120:121]\n\t"                                                     \
+  "v_min_f64 v[116:117], v[116:117], v[122:123]\n\t"                                               \
+  "v_add_f64 v[118:119], v[116:117], -v[114:115]\n\t"                                              \
+  "v_cmp_gt_f64_e64 %[pend], |v[118:119]|, %[thr]\n\t"
+
+__device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, double& v, double& lam, double& cand, double& dl,
+                                                unsigned long long& pend, double& lo, double& hi, double tol, int lane, double mu,
+                                                unsigned long long tan1_lanes, unsigned long long tangent_lanes,
+                                                unsigned long long phase0, unsigned long long phase1, unsigned long long phase2,
+                                                int iters, int& n_changed) {
+  double thr, lam_o, cand_o, dl_o, lo_o, hi_o, x1, x2;
+  unsigned long long w, t, todo;
+  int rs, ri, it;
+  asm volatile(
+      "s_branch .Lpgs64_%=_entry\n\t"
+      ".p2align 6\n\t"
+      ".fill 12, 4, 0xbf800000\n"              // (s_nop 0: the loops at a fixed position within the 64-byte instruction lines)
+      ".Lpgs64_%=_entry:\n\t"
+      "s_sub_u32 %[it], 0, %[iters]\n\t"       // counts up to zero: the carry of the increment is "cap reached"
+      "s_cbranch_scc0 .Lpgs64_%=_done\n"        // (no sweeps allowed)
+      ".Lpgs64_%=_sweep:\n\t"
+      // ---- the non-contact rows (joint motors, joint limits), leg by leg
+      "s_and_b64 %[todo], %[pend], %[ph0]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_a1\n"
+      SOLO_PGS_WALK64("p0", "%[ph0]")
+      // ---- all normal rows, then the friction limits
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_b2\n"          // no normal row moves in this sweep: the friction limits stand
+      SOLO_PGS_WALK64("p1", "%[ph1]")
+      SOLO_PGS_LIMITS64
+      "s_branch .Lpgs64_%=_b2\n"
+      ".Lpgs64_%=_a1:\n\t"                      // (the same phase for a sweep that has found no work so far)
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_a2\n"
+      SOLO_PGS_WALK64("q1", "%[ph1]")
+      SOLO_PGS_LIMITS64
+      // ---- all friction rows
+      ".Lpgs64_%=_b2:\n\t"
+      "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_next\n"
+      ".Lpgs64_%=_p2:\n"
+      SOLO_PGS_WALK64("p2", "%[ph2]")
+      ".Lpgs64_%=_next:\n\t"
+      "s_add_u32 %[it], %[it], 1\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_sweep\n\t"     // (no carry: below the sweep cap)
+      "s_branch .Lpgs64_%=_done\n"
+      ".Lpgs64_%=_a2:\n\t"                      // (no work in the first two phases)
+      "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
+      "s_cbranch_scc1 .Lpgs64_%=_p2\n"          // (else: nothing pending at the start of a sweep - converged)
+      ".Lpgs64_%=_done:\n\t"
+      : [v] "+v"(v), "={v[114:115]}"(lam_o), "={v[116:117]}"(cand_o), "={v[118:119]}"(dl_o), "={v[120:121]}"(lo_o), "={v[122:123]}"(hi_o),
+        "={v[124:125]}"(x1), "={v[126:127]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
+        [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [ri] "=&s"(ri), [it] "=&s"(it)
+#ifdef SOLO_STAMPS
+        , [nch] "+s"(n_changed)
+#endif
+      : "{v[114:115]}"(lam), "{v[116:117]}"(cand), "{v[118:119]}"(dl), "{v[120:121]}"(lo), "{v[122:123]}"(hi),
+        [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
+        [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes),
+        "{v[128:159]}"(A.a0), "{v[160:191]}"(A.a1), "{v[192:223]}"(A.a2), "{v[224:255]}"(A.a3)
+      : "vcc", "scc", "s94", "s95");
+  lam = lam_o; cand = cand_o; dl = dl_o; lo = lo_o; hi = hi_o;
+  (void)n_changed; (void)x1; (void)x2;
+  return it + iters;
+}
+
+#undef SOLO_PGS_LIMITS64
+#undef SOLO_PGS_WALK64
 #undef SOLO_PGS_COUNT_ROW
 
 }  // namespace solo

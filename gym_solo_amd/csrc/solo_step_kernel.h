@@ -118,7 +118,7 @@ template <typename T> __device__ __forceinline__ V3<T> from_lower(V3<T> v) { ret
 template <typename T>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
                                            const RowConst<T>& rc, const T* s_state, T my_target, T (*s_rowvec)[8], T (*s_hext)[8],
-                                           T* s_keep, T (*s_leg)[20], T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps, int& prio_rot) {
+                                           T* s_keep, T (*s_leg)[20], const T* s_math, T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps, int& prio_rot) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = C.dt;
@@ -148,7 +148,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // ONE sincos per lane - of its own link's absolute angle (q1 on the upper half, q1 + q2 on the lower) -
   // and each link's pair broadcast over both halves of the 16-lane row (bank-masked DPP moves)
   T sinb, cosb;  // this half's link orientation
-  R::sincos(lower ? q1 + q2 : q1, &sinb, &cosb);
+  R::sincos(lower ? q1 + q2 : q1, &sinb, &cosb, s_math);
   const T s1 = wave_from_upper_half16(sinb), c1 = wave_from_upper_half16(cosb);
   const T s12 = wave_from_lower_half16(sinb), c12 = wave_from_lower_half16(cosb);
   const V3<T> o1 = {L.hip[0], L.hip[1], L.hip[2]};
@@ -529,7 +529,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // f32 on the GPU: the loop below, written in assembly (solo_pgs_gfx950.h) - same rows, same order, same
   // arithmetic; this C++ form stays the definition (f64, the CPU emulator, and the -DSOLO_PGS_NO_ASM test
   // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py)
-  if constexpr (sizeof(T) == 4) {
+  {
     int rows_updated = 0;
     it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu,
                           wave_ballot(type == ROW_TAN1), wave_ballot(is_tangent), kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2],
@@ -537,8 +537,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #ifdef SOLO_STAMPS
     n_changed = rows_updated;
 #endif
-  } else
-#endif
+  }
+#else
 #pragma unroll 1
   for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
     // (the register banks of the matrix are walked one after the other - static bank per loop - which
@@ -583,6 +583,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     }
     SOLO_PGS_SWEEP_HOOK(it, pend, lamv, v);
   }
+#endif
 #ifdef SOLO_STAMPS
   if (lane == 0) {
     // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28
@@ -614,7 +615,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 // K du_b), go back to world-frame velocities and integrate.  Everything is re-read from LDS.
 template <typename T>
 __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, const T (*s_rowvec)[8],
-                                               const T* s_keep, const T (*s_leg)[20], T lam, int lane) {
+                                               const T* s_keep, const T (*s_leg)[20], const T* s_math, T lam, int lane) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = C.dt;
@@ -658,7 +659,7 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
   // q+ = exp(dt w / 2) (x) q, renormalised
   // exp(dt w / 2) = (w sin(x) / |w|, cos(x)) with x = |w| dt / 2: sin(x) / |w| = (dt / 2) sinc(x)
   T sinc_x, ch;
-  R::sinc_cos(T(0.25) * dt * dt * dot(wn, wn), &sinc_x, &ch);  // argument: x^2
+  R::sinc_cos(T(0.25) * dt * dt * dot(wn, wn), &sinc_x, &ch, s_math);  // argument: x^2
   const T sc = T(0.5) * dt * sinc_x;
   const T dx = wn.x * sc, dy = wn.y * sc, dz = wn.z * sc, dw = ch;
   T nx = dw * qx + dx * qw + dy * qz - dz * qy;
@@ -688,6 +689,9 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
 // __launch_bounds__(64, W): W waves per SIMD -> 512/W VGPRs.  f32: 4 (128 VGPRs, a whole 4096-robot
 // batch resident on the 1024 SIMDs); f64: 2 (the Delassus row alone is 112 VGPRs).
 // kFull = false: physics-only instantiation (flags are treated as SOLO_STEP_PHYSICS).
+// single-step launches evaluate their outputs in the step kernel itself (see the step loop): f32 only
+template <typename T, bool kFull> constexpr bool kInlineOutputs = kFull && sizeof(T) == 4;
+
 template <typename T, bool kFull>
 __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(const KParams<T>* __restrict__ Pin, KBuffers<T> Bin) {
   KBuffers<T> B = Bin;
@@ -709,6 +713,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ LegConst<T> s_legc[4];
   __shared__ RowConst<T> s_rowc[64];
   __shared__ StepConst<T> s_const;          // the scalars a step reads (see solo_kernel_params.h)
+  // coefficient table of Real<T>'s polynomials (f64 only: see Real<double>::sincos; f32 uses instruction literals)
+  __shared__ T s_math[Real<T>::kTabSize > 0 ? Real<T>::kTabSize : 1];
 
   const int lane0 = lane_id();
   // workgroup -> robot: the identity, or the cost-balanced launch order (solo_engine_set_order)
@@ -753,6 +759,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
   const T mass_scale = wave_cold_args(Bin)->params[(size_t)env * 4 + 1];
   const int count_w = lane0 < SOLO_MAX_TERMS ? wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane0] : 0;
+  T math_w = T(0);
+  if constexpr (Real<T>::kTabSize > 0) math_w = wave_math_table<T>(lane0 < Real<T>::kTabSize ? lane0 : 0);
   // issue priority (see physics_solve): a closed-loop step() is a launch of ONE step - it has no history
   // of its own, and its slowest robot, one that runs all the sweeps, decides how long the step takes.  A
   // robot's Gauss-Seidel cost is persistent, so such a launch starts from the sweep count of the robot's
@@ -774,6 +782,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     for (int j = 0; j < kConstLoads; ++j) if (lane0 + 64 * j < kConstWords) const_dst[lane0 + 64 * j] = const_w[j];
     if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = state_w;
     s_cnt[lane0] = count_w;
+    if constexpr (Real<T>::kTabSize > 0) { if (lane0 < Real<T>::kTabSize) s_math[lane0] = math_w; }
   }
   int prio_sweeps = wave_uniform(hist_w);
   const int hist_sweeps = prio_sweeps;
@@ -824,8 +833,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
       const T my_target = raw_target * target_scale;
-      const T lam = physics_solve<T>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, mu, mass_scale, lane, prio_sweeps, prio_steps, prio_rot);
-      physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, lam, lane);
+      const T lam = physics_solve<T>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, prio_sweeps, prio_steps, prio_rot);
+      physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, s_math, lam, lane);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted
       const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) || (motor_lane && !R::finite(my_target));
@@ -862,7 +871,11 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     // closed-loop step() = a single-step launch: its outputs are evaluated right here with the
     // same per-item functions the output kernels use (no second launch on the critical path of a
     // policy loop) - lane i takes observation element i / reward leaf i, lane 0 folds the reward
-    if (B.obs_inline != nullptr || B.reward_inline != nullptr) {
+    // (f32 only: in f64 - the parity path - every launch leaves records for the output kernels.  The library
+    // atan2 / asin / exp of the f64 outputs need ~40 f64 constants, which the compiler kept live across the whole
+    // step loop - and spilled: 36 scratch stores per lane at the top of every launch, 900 B of HBM writes per
+    // env-step of a 20-step launch - for a code path fused launches never take.)
+    if constexpr (kInlineOutputs<T, kFull>) if (B.obs_inline != nullptr || B.reward_inline != nullptr) {
       // lane i's observation element / reward instruction come from the parameter block in global memory:
       // loaded HERE so that the loads fly while the Euler angles are computed
       // (loaded where they are used they were three exposed round trips at the end of every closed-loop step)
@@ -923,7 +936,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   if ((B.flags & SOLO_STEP_PHYSICS) && lane1 == 0) { int32_t* cost = wave_cold_args(Bin)->cost; if (cost != nullptr) cost[env] = prio_sweeps - hist_sweeps; }
   // (slots SOLO_S_RETURN.. of the record are the returns kernel's after a fused launch; a single-step
   // launch that evaluated its reward in place keeps the accumulators itself)
-  const bool own_returns = B.reward_inline != nullptr && (B.flags & SOLO_STEP_DONE);
+  const bool own_returns = kInlineOutputs<T, kFull> && B.reward_inline != nullptr && (B.flags & SOLO_STEP_DONE);
   if (lane1 < (own_returns ? SOLO_S_SPARE : SOLO_S_RETURN)) wave_cold_args(Bin)->state[rec + lane1] = s_state[lane1];
   SOLO_STAMP(B, 14);
 #ifdef SOLO_STAMPS

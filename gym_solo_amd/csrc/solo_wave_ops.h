@@ -213,21 +213,31 @@ template <> struct ColumnBank<float> {
   __device__ __forceinline__ void build(int r) { const float x = column(r); if (r < 32) a0[r] = x; else a1[r - 32] = x; }
   __device__ __forceinline__ float get(int bank, int r) const { return bank == 0 ? a0[r & 31] : a1[r & 31]; }
 };
+// f64 (the reference's precision; round 3): resident as well - 64 doubles per lane in four 16-wide tuples = 128
+// VGPRs, half of the 256 a wave has at two waves per SIMD.  The rest of the step fits in the other half while
+// the columns are live (everything the post-solve phase needs is parked in LDS across the solver).
+typedef double solo_f64x16 __attribute__((ext_vector_type(16)));
 template <> struct ColumnBank<double> {
-  static constexpr bool kResident = false;
-  static constexpr int kBanks = 1;
-  static __device__ __forceinline__ constexpr unsigned long long bank_lanes(int) { return ~0ull; }
+  static constexpr bool kResident = true;
+  static constexpr int kBanks = 4;
+  static __device__ __forceinline__ constexpr unsigned long long bank_lanes(int b) { return 0xffffull << (16 * b); }
   RowDot<double> own;
   double nid;
   int lane;
   const double* rowvec;
   const double* hext;
+  solo_f64x16 a0, a1, a2, a3;
   __device__ __forceinline__ void init(const double* gh, const double* hh, double nid_, int lane_, const double* rowvec_, const double* hext_) {
     own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; hext = hext_;
   }
   __device__ __forceinline__ double column(int r) const { const double m = (lane == r) ? 0.0 : nid; return m * own.dot(rowvec + 8 * r, hext + 8 * r); }
-  __device__ __forceinline__ void build(int) {}
-  __device__ __forceinline__ double get(int, int r) const { return column(r); }
+  __device__ __forceinline__ void build(int r) {
+    const double x = column(r);
+    if (r < 16) a0[r] = x; else if (r < 32) a1[r - 16] = x; else if (r < 48) a2[r - 32] = x; else a3[r - 48] = x;
+  }
+  __device__ __forceinline__ double get(int bank, int r) const {
+    return bank == 0 ? a0[r & 15] : (bank == 1 ? a1[r & 15] : (bank == 2 ? a2[r & 15] : a3[r & 15]));
+  }
 };
 
 // The kernel's by-value buffer block, re-read from the kernarg segment (constant address space ->
@@ -265,7 +275,8 @@ template <> struct Real<float> {
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
   static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-  static __device__ __forceinline__ void sincos(float x, float* s, float* c) {
+  static constexpr int kTabSize = 0;  // (f32 coefficients are instruction literals)
+  static __device__ __forceinline__ void sincos(float x, float* s, float* c, const float* = nullptr) {
     const float k = __builtin_rintf(x * 0.63661977236758134f);          // nearest multiple of pi/2
     float r = __builtin_fmaf(k, -1.57079601287841796875f, x);           // pi/2 in three pieces
     r = __builtin_fmaf(k, -3.1391647326017846e-07f, r);
@@ -286,7 +297,7 @@ template <> struct Real<float> {
   // ~1e-2): even Taylor polynomials, exact to f32 round-off for x^2 < 1/16 (truncation < 5e-11 /
   // 3e-9 relative); beyond that (|w| > 500 rad/s at dt = 1e-3: never in a sane simulation) the
   // library path.  No sqrt, no range reduction: 8 fused multiply-adds instead of ~35 instructions.
-  static __device__ __forceinline__ void sinc_cos(float x2, float* sinc, float* c) {
+  static __device__ __forceinline__ void sinc_cos(float x2, float* sinc, float* c, const float* = nullptr) {
     if (__builtin_expect(__builtin_amdgcn_readfirstlane(__float_as_int(x2)) > 0x3d800000, 0)) {  // x2 > 1/16 (wave-uniform: one robot)
       const float x = __builtin_amdgcn_sqrtf(x2);
       float sn, cs;
@@ -338,16 +349,100 @@ template <> struct Real<float> {
   static __device__ __forceinline__ float big() { return 3.0e38f; }
   static __device__ __forceinline__ float half_ulp() { return 5.9604645e-8f; }  // 2^-24
 };
+// f64 (the reference's precision): hardware v_rsq_f64 / v_rcp_f64 seeds (~2^-26) refined by two fused
+// Newton steps instead of the IEEE library sequences (division ~12, square root ~18, 1 / sqrt ~30
+// instructions: ten of them per step), a Cody-Waite sincos with fdlibm's kernel polynomials (~35
+// instructions, <= 2 ulp for |x| < 1e5 rad) instead of the library's sincos, whose Payne-Hanek path was
+// the register peak of the whole kernel (52 of its 84 VGPR spills), and even Taylor polynomials in x^2 for the
+// rotation update.  All within a few ulp of the correctly rounded value: three orders of magnitude below
+// what the parity tests resolve (1e-13 per step against the oracle's different formulation).
 template <> struct Real<double> {
-  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-  static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
-  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
-  static __device__ __forceinline__ void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
-  static __device__ __forceinline__ void sinc_cos(double x2, double* sinc, double* c) {
-    const double x = ::sqrt(x2);
-    double sn;
-    ::sincos(x, &sn, c);
-    *sinc = x > 1e-12 ? sn / x : 1.0;
+  // 1 / sqrt(x): Goldschmidt iteration on g -> sqrt(x), h -> 1 / (2 sqrt(x)); returns 2 h
+  static __device__ __forceinline__ void sqrt_pair(double x, double* g_out, double* h_out) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    *g_out = __builtin_fma(g, r, g);
+    *h_out = __builtin_fma(h, r, h);
+  }
+  static __device__ __forceinline__ double sqrt(double x) {
+    double g, h;
+    sqrt_pair(x, &g, &h);
+    return x == 0.0 ? 0.0 : g;  // (rsq(0) = inf: 0 x inf)
+  }
+  static __device__ __forceinline__ double rsqrt(double x) {
+    double g, h;
+    sqrt_pair(x, &g, &h);
+    return h + h;  // (x <= 0 or non-finite: a non-finite result, which the diverged-robot guard sees)
+  }
+  static __device__ __forceinline__ double rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+  }
+  // The polynomial coefficients come from a TABLE IN LDS (kMathTable below, staged once per launch): a f64
+  // constant cannot be an instruction literal on gfx950 (VOP3 takes none), so each one is a register pair - written
+  // as literals the compiler hoisted all ~30 of them out of the fused step loop and then SPILLED them (a scratch load
+  // per coefficient per step); from LDS two coefficients arrive per ds_read_b128 broadcast.
+  static constexpr int kTabSincos = 0, kTabSinc = 16, kTabSize = 32;
+  static __device__ __forceinline__ void sincos(double x, double* s, double* c, const double* tab) {
+    // r = x - k pi/2 with pi/2 in two pieces: the first fused step is exact for |k| < 2^20 (the difference
+    // is a multiple of 2^-52 below 1), the second rounds once
+    const double* t = tab + kTabSincos;
+    const double k = __builtin_rint(x * t[0]);
+    double r = __builtin_fma(k, t[1], x);
+    r = __builtin_fma(k, t[2], r);
+    const double z = r * r;
+    // fdlibm __kernel_sin / __kernel_cos on [-pi/4, pi/4]
+    double sp = __builtin_fma(z, t[4], t[5]);
+    sp = __builtin_fma(z, sp, t[6]);
+    sp = __builtin_fma(z, sp, t[7]);
+    sp = __builtin_fma(z, sp, t[8]);
+    sp = __builtin_fma(z, sp, t[9]);
+    const double sn = __builtin_fma(z * r, sp, r);
+    double cp = __builtin_fma(z, t[10], t[11]);
+    cp = __builtin_fma(z, cp, t[12]);
+    cp = __builtin_fma(z, cp, t[13]);
+    cp = __builtin_fma(z, cp, t[14]);
+    cp = __builtin_fma(z, cp, t[15]);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + z * z * cp);  // (fdlibm's compensated 1 - z/2 + z^2 C(z))
+    const int q = (int)k;
+    const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    *s = (q & 2) ? -a : a;
+    *c = ((q + 1) & 2) ? -b : b;
+  }
+  // sinc(x) = sin(x) / x and cos(x) from x^2 (x = |w| dt / 2, ~1e-2): even Taylor polynomials, truncation
+  // < 3e-21 / 4e-20 for x^2 < 1/16; beyond that (|w| > 500 rad/s at dt = 1e-3) the general path
+  static __device__ __forceinline__ void sinc_cos(double x2, double* sinc, double* c, const double* tab) {
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(x2) >> 32)) > 0x3fb00000, 0)) {  // x2 > 1/16 (wave-uniform: one robot)
+      const double x = sqrt(x2);
+      double sn;
+      sincos(x, &sn, c, tab);
+      *sinc = sn * rcp(x);
+      return;
+    }
+    const double* t = tab + kTabSinc;
+    double sp = __builtin_fma(x2, t[0], t[1]);   // -1/15!, 1/13!
+    sp = __builtin_fma(x2, sp, t[2]);            // -1/11!
+    sp = __builtin_fma(x2, sp, t[3]);            // 1/9!
+    sp = __builtin_fma(x2, sp, t[4]);            // -1/7!
+    sp = __builtin_fma(x2, sp, t[5]);            // 1/5!
+    sp = __builtin_fma(x2, sp, t[6]);            // -1/3!
+    *sinc = __builtin_fma(x2, sp, 1.0);
+    double cp = __builtin_fma(x2, t[8], t[9]);   // -1/14!, 1/12!
+    cp = __builtin_fma(x2, cp, t[10]);           // -1/10!
+    cp = __builtin_fma(x2, cp, t[11]);           // 1/8!
+    cp = __builtin_fma(x2, cp, t[12]);           // -1/6!
+    cp = __builtin_fma(x2, cp, t[13]);           // 1/4!
+    cp = __builtin_fma(x2, cp, -0.5);
+    *c = __builtin_fma(x2, cp, 1.0);
   }
   static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
   static __device__ __forceinline__ double asin(double x) { return ::asin(x); }
@@ -362,6 +457,22 @@ template <> struct Real<double> {
   static __device__ __forceinline__ double big() { return 1.0e300; }
   static __device__ __forceinline__ double half_ulp() { return 1.1102230246251565e-16; }  // 2^-53
 };
+
+// coefficients of Real<double>::sincos / sinc_cos (see there), copied into LDS by the step kernel's prologue
+__device__ const double kMathTable[Real<double>::kTabSize] = {
+    // [0] 2/pi, [1..2] -pi/2 in two pieces, [3] unused, [4..9] fdlibm S6..S1, [10..15] C6..C1
+    6.36619772367581382433e-01, -1.57079632679489655800e+00, -6.12323399573676603587e-17, 0.0,
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04,
+    8.33333333332248946124e-03, -1.66666666666666324348e-01,
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07, 2.48015872894767294178e-05,
+    -1.38888888888741095749e-03, 4.16666666666666019037e-02,
+    // [16..22] sinc: -1/15!, 1/13!, -1/11!, 1/9!, -1/7!, 1/5!, -1/3!; [23] unused; [24..29] cos: -1/14!, 1/12!, -1/10!, 1/8!, -1/6!, 1/4!
+    -7.6471637318198164759e-13, 1.6059043836821614599e-10, -2.5052108385441718775e-08, 2.7557319223985890653e-06,
+    -1.9841269841269841270e-04, 8.3333333333333333333e-03, -1.6666666666666666667e-01, 0.0,
+    -1.1470745597729724714e-11, 2.0876756987868098979e-09, -2.7557319223985890653e-07, 2.4801587301587301587e-05,
+    -1.3888888888888888889e-03, 4.1666666666666666667e-02, 0.0, 0.0};
+
+template <typename T> __device__ __forceinline__ T wave_math_table(int i) { return T(kMathTable[i]); }
 
 __device__ __forceinline__ void stats_add(double* p, double v) { atomicAdd(p, v); }
 

@@ -74,7 +74,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   B.state = st.data(); B.snapshot = snap.data(); B.targets = tg.data();
   B.actions = actions ? act.data() : nullptr; B.params = par.data();
   // as Engine::launch_chain: a single-step launch evaluates its outputs inside the step kernel
-  const bool inline_outputs = steps == 1 && (want_obs || want_reward);
+  const bool inline_outputs = steps == 1 && (want_obs || want_reward) && kInlineOutputs<T, true>;
   B.traj = (!inline_outputs && (want_obs || want_reward)) ? traj.data() : nullptr;
   B.events = events.data();
   B.obs_inline = (inline_outputs && want_obs) ? ob.data() : nullptr;

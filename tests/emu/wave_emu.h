@@ -206,13 +206,15 @@ inline unsigned long long wave_ballot(bool p) {
   return m;
 }
 
+template <typename T> inline T wave_math_table(int) { return T(0); }
 template <typename T> struct Real;
 template <> struct Real<float> {
   static float sqrt(float x) { return std::sqrt(x); }
   static float rsqrt(float x) { return 1.0f / std::sqrt(x); }
   static float rcp(float x) { return 1.0f / x; }
-  static void sincos(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
-  static void sinc_cos(float x2, float* sinc, float* c) { const float x = std::sqrt(x2); *c = std::cos(x); *sinc = x > 1e-12f ? std::sin(x) / x : 1.0f; }
+  static constexpr int kTabSize = 0;
+  static void sincos(float x, float* s, float* c, const float* = nullptr) { *s = std::sin(x); *c = std::cos(x); }
+  static void sinc_cos(float x2, float* sinc, float* c, const float* = nullptr) { const float x = std::sqrt(x2); *c = std::cos(x); *sinc = x > 1e-12f ? std::sin(x) / x : 1.0f; }
   static float atan2(float y, float x) { return std::atan2(y, x); }
   static float asin(float x) { return std::asin(x); }
   static float exp(float x) { return std::exp(x); }
@@ -230,8 +232,9 @@ template <> struct Real<double> {
   static double sqrt(double x) { return std::sqrt(x); }
   static double rsqrt(double x) { return 1.0 / std::sqrt(x); }
   static double rcp(double x) { return 1.0 / x; }
-  static void sincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
-  static void sinc_cos(double x2, double* sinc, double* c) { const double x = std::sqrt(x2); *c = std::cos(x); *sinc = x > 1e-12 ? std::sin(x) / x : 1.0; }
+  static constexpr int kTabSize = 0;
+  static void sincos(double x, double* s, double* c, const double* = nullptr) { *s = std::sin(x); *c = std::cos(x); }
+  static void sinc_cos(double x2, double* sinc, double* c, const double* = nullptr) { const double x = std::sqrt(x2); *c = std::cos(x); *sinc = x > 1e-12 ? std::sin(x) / x : 1.0; }
   static double atan2(double y, double x) { return std::atan2(y, x); }
   static double asin(double x) { return std::asin(x); }
   static double exp(double x) { return std::exp(x); }

@@ -1,8 +1,8 @@
-"""The assembly Gauss-Seidel loop (gym_solo_amd/csrc/solo_pgs_gfx950.h) against its C++ definition, ON THE
-GPU and BIT FOR BIT: the product library and libsolo_hip_pgs_cpp.so (the same translation unit built with
--DSOLO_PGS_NO_ASM) run the same contact-rich f32 rollouts in two processes; states, rewards, done flags
-and per-robot sweep counts must be identical - the assembly takes the same rows in the same order with
-the same arithmetic, and stops after the same number of sweeps."""
+"""The assembly Gauss-Seidel loops (gym_solo_amd/csrc/solo_pgs_gfx950.h: f32 and, since round 3, f64) against
+their C++ definition, ON THE GPU and BIT FOR BIT: the product library and libsolo_hip_pgs_cpp.so (the same
+translation unit built with -DSOLO_PGS_NO_ASM) run the same contact-rich rollouts in two processes; states,
+rewards, done flags and per-robot sweep counts must be identical - the assembly takes the same rows in the
+same order with the same arithmetic, and stops after the same number of sweeps."""
 import os
 import subprocess
 import sys
@@ -22,14 +22,15 @@ import numpy as np, torch
 from gym_solo_amd import abi
 from gym_solo_amd.engine import Engine
 from helpers import make_abi
-case, out = sys.argv[1], sys.argv[2]
+case, out, dtype = sys.argv[1], sys.argv[2], sys.argv[3]
+tdt = torch.float32 if dtype == 'float32' else torch.float64
 res = {}
 if case == 'flail':      # the bench workload: random targets, robots tumbling over the plane, auto-reset
   from bench import build_env
-  env = build_env(4096, 0, 'float32', steps_per_launch=250, rollout_streams=2)   # the bench geometry
+  env = build_env(4096, 0, dtype, steps_per_launch=250, rollout_streams=2)   # the bench geometry
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(77)
-  acts = (torch.rand(500, 4096, 12, device='cuda', generator=g) * 2 - 1) * (2 * np.pi)
+  acts = (torch.rand(500, 4096, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
   o = eng.rollout_buffers(500)
   eng.rollout(acts, abi.STEP_ALL, out=o)
   torch.cuda.synchronize()
@@ -37,10 +38,10 @@ if case == 'flail':      # the bench workload: random targets, robots tumbling o
              reward=o[1].cpu().numpy(), done=o[2].cpu().numpy(), obs=o[0].cpu().numpy())
 else:                     # few sweeps allowed / exact tolerance / one sweep: the loop's exits
   iters, tol = {'cap3': (3, 2), 'exact': (50, 0), 'one': (1, 2)}[case]
-  ca, ma = make_abi('float32', solver_iterations=iters, solver_ulp_tolerance=tol, settle_steps=100)
+  ca, ma = make_abi(dtype, solver_iterations=iters, solver_ulp_tolerance=tol, settle_steps=100)
   eng = Engine(ca, ma, 256)
   rng = np.random.default_rng(5)
-  acts = torch.as_tensor(rng.uniform(-6, 6, (120, 256, 12)), device='cuda', dtype=torch.float32)
+  acts = torch.as_tensor(rng.uniform(-6, 6, (120, 256, 12)), device='cuda', dtype=tdt)
   for i in range(120):
     eng.step(acts[i], abi.STEP_PHYSICS)
   torch.cuda.synchronize()
@@ -49,18 +50,19 @@ np.savez(out, **res)
 '''
 
 
-def _run(lib, case, tmp_path):
-  out = str(tmp_path / ('%s_%s.npz' % (case, os.path.basename(lib))))
+def _run(lib, case, dtype, tmp_path):
+  out = str(tmp_path / ('%s_%s_%s.npz' % (case, dtype, os.path.basename(lib))))
   env = dict(os.environ, SOLO_HIP_LIB=lib)
-  subprocess.run([sys.executable, '-c', _WORKER % {'root': ROOT}, case, out], check=True, env=env, timeout=600)
+  subprocess.run([sys.executable, '-c', _WORKER % {'root': ROOT}, case, out, dtype], check=True, env=env, timeout=600)
   return np.load(out)
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
 @pytest.mark.parametrize('case', ['flail', 'cap3', 'exact', 'one'])
-def test_assembly_loop_equals_cpp_loop_bit_for_bit(case, tmp_path):
+def test_assembly_loop_equals_cpp_loop_bit_for_bit(case, dtype, tmp_path):
   asm_lib, cpp_lib = os.path.join(CSRC, 'libsolo_hip.so'), os.path.join(CSRC, 'libsolo_hip_pgs_cpp.so')
   assert os.path.isfile(cpp_lib), 'build it: make -C gym_solo_amd/csrc test-libs (or __graft_entry__.build())'
-  a, b = _run(asm_lib, case, tmp_path), _run(cpp_lib, case, tmp_path)
+  a, b = _run(asm_lib, case, dtype, tmp_path), _run(cpp_lib, case, dtype, tmp_path)
   assert set(a.files) == set(b.files)
   for k in a.files:
     assert a[k].shape == b[k].shape

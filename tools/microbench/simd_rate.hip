@@ -1,63 +1,200 @@
-// MICROBENCH (not product): VALU issue throughput of ONE SIMD vs the number of waves resident on it.
-// Every wave runs the same stream of independent v_fma_f32 (inline asm: the compiler cannot pack or
-// fold them) or a VALU / SALU mix; wave 0 reports s_memtime ticks per instruction.  The launch uses
-// 64-thread workgroups: 1024 of them put one wave on every SIMD of the chip, 2048 two, ...
+// MICROBENCH (not product): what ONE wave issues per cycle on a SIMD of MI355X, alone and next to others.
+//
+// Round 3 rewrite.  The round-2 version timed loops of 8 instructions and divided by 8: the loop's own
+// s_add / s_cmp / taken s_cbranch (a taken branch restarts the instruction fetch: ~20 cycles) were counted
+// as if they were the measured instructions, which turned 4 cycles per independent v_fma into "7.5".  Now:
+//  * every body is 256 instructions (.rept 32 x 8), the loop runs ITERS times, and the SAME loop with an
+//    empty body is timed and subtracted - the figure printed is (t_body - t_empty) / (256 ITERS);
+//  * expected from MI355X_MICROARCH.md (constants table): independent v_fma_f32 / s_nop 0: 4 cycles for a
+//    wave alone on its SIMD, 2 with several waves sharing it; a dependent v_fma_f32 chain ~6.6;
+//  * ROLES: with 4 waves per SIMD (4096 workgroups of 64 threads, the step kernel's residency) the wave
+//    that arrives FIRST on each SIMD (an atomic ticket per SIMD, keyed by XCC_ID / HW_ID) measures, at
+//    s_setprio 3 or 0, while its three neighbours (a) exit at once (the SIMD is the measuring wave's alone:
+//    the tail of a launch whose other robots have finished), (b) run the same stream at priority 0, or
+//    (c) sleep.  That is the situation of the slowest robot of a launch: pinned to priority 3, neighbours
+//    finishing one after the other.
+//
+// build: hipcc -O3 --offload-arch=gfx950 -o simd_rate simd_rate.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-template <int MODE> __global__ __launch_bounds__(64) void k(float* out, unsigned long long* t, int iters) {
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+#define REPT32(BODY) ".rept 32\n" BODY ".endr\n"
+
+enum Mode { kEmpty, kFmaIndep, kFmaDep, kFmaDep2, kFmaSadd, kSadd, kSnop, kDppChain, kRowUpdate, kRowUpdate2, kModes };
+static const char* kModeName[kModes] = {
+    "empty loop", "v_fma_f32 x8 independent", "v_fma_f32 one dependent chain", "v_fma_f32 two interleaved chains",
+    "v_fma_f32 / s_add_u32 alternating", "s_add_u32 4 chains", "s_nop 0", "v_add_f32_dpp chain + s_nop 1",
+    "PGS row update (16 instr, dependent)", "PGS row update x2 interleaved (32 instr, 2 independent rows)"};
+static const int kBodyInstr[kModes] = {0, 256, 256, 256, 256, 256, 256, 256, 256, 256};
+
+template <int MODE>
+__device__ __forceinline__ void body(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5, float& x6, float& x7,
+                                     int& s0, int& s1, int& s2, int& s3, float b, float c) {
+  if (MODE == kFmaIndep) {
+    asm volatile(REPT32("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                        "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n")
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b), "v"(c));
+  } else if (MODE == kFmaDep) {
+    asm volatile(REPT32("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                        "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n")
+                 : "+v"(x0) : "v"(b), "v"(c));
+  } else if (MODE == kFmaDep2) {
+    asm volatile(REPT32("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
+                        "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n")
+                 : "+v"(x0), "+v"(x1) : "v"(b), "v"(c));
+  } else if (MODE == kFmaSadd) {
+    asm volatile(REPT32("v_fma_f32 %0, %0, %8, %9\n s_add_u32 %4, %4, 1\n v_fma_f32 %1, %1, %8, %9\n s_add_u32 %5, %5, 1\n"
+                        "v_fma_f32 %2, %2, %8, %9\n s_add_u32 %6, %6, 1\n v_fma_f32 %3, %3, %8, %9\n s_add_u32 %7, %7, 1\n")
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(b), "v"(c) : "scc");
+  } else if (MODE == kSadd) {
+    asm volatile(REPT32("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
+                        "s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n")
+                 : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+  } else if (MODE == kSnop) {
+    asm volatile(REPT32("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"));
+  } else if (MODE == kDppChain) {
+    asm volatile(REPT32("v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n")
+                 : "+v"(x0));
+  } else if (MODE == kRowUpdate || MODE == kRowUpdate2) {
+    // The Gauss-Seidel row update of gym_solo_amd/csrc/solo_pgs_gfx950.h, with the branch replaced by straight-line
+    // repetition (16 instructions incl. one s_nop standing in for the branch's issue slot; the register-indexed
+    // column read is a plain register here).  kRowUpdate2: TWO such updates on disjoint registers, interleaved
+    // instruction by instruction - what a software-pipelined walk over two independent rows would issue.
+    unsigned long long pend, w, t, todo = 0x0924092409240924ull, pend2, w2, t2, todo2 = 0x36d836d836d836d8ull;
+    int rs, sd, rs2, sd2;
+    float thr, thr2;
+    const int lane = threadIdx.x;
+    if (MODE == kRowUpdate) {
+      asm volatile(".rept 16\n"
+                   "s_ff1_i32_b64 %[rs], %[todo]\n v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n v_readlane_b32 %[sd], %[dl], %[rs]\n"
+                   "s_lshl_b64 %[t], -2, %[rs]\n s_nop 0\n v_fma_f32 %[v], %[col], %[sd], %[v]\n s_nop 0\n"
+                   "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n v_med3_f32 %[cand], %[v], %[lo], %[hi]\n"
+                   "v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n v_sub_f32_e32 %[dl], %[cand], %[lam]\n s_and_b64 %[w], %[ph], %[t]\n"
+                   "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n s_nop 0\n s_and_b64 %[todo], %[pend], %[w]\n s_or_b64 %[todo], %[todo], %[ph]\n"
+                   ".endr\n"
+                   : [v] "+v"(x0), [lam] "+v"(x1), [cand] "+v"(x2), [dl] "+v"(x3), [thr] "=&v"(thr), [pend] "=&s"(pend), [w] "=&s"(w),
+                     [t] "=&s"(t), [todo] "+s"(todo), [rs] "=&s"(rs), [sd] "=&s"(sd)
+                   : [lane] "v"(lane), [tol] "v"(c), [lo] "v"(-b), [hi] "v"(b), [col] "v"(x4), [ph] "s"(0x0924092409240924ull)
+                   : "vcc", "scc");
+    } else {
+      asm volatile(".rept 8\n"
+                   "s_ff1_i32_b64 %[rs], %[todo]\n s_ff1_i32_b64 %[rs2], %[todo2]\n"
+                   "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n v_cmp_eq_u32_e64 %[pend2], %[rs2], %[lane]\n"
+                   "v_readlane_b32 %[sd], %[dl], %[rs]\n v_readlane_b32 %[sd2], %[dl2], %[rs2]\n"
+                   "s_lshl_b64 %[t], -2, %[rs]\n s_lshl_b64 %[t2], -2, %[rs2]\n s_nop 0\n s_nop 0\n"
+                   "v_fma_f32 %[v], %[col], %[sd], %[v]\n v_fma_f32 %[v2], %[col], %[sd2], %[v2]\n s_nop 0\n s_nop 0\n"
+                   "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n v_cndmask_b32_e64 %[lam2], %[lam2], %[cand2], %[pend2]\n"
+                   "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n v_med3_f32 %[cand2], %[v2], %[lo], %[hi]\n"
+                   "v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n v_mul_f32_e64 %[thr2], %[tol], |%[lam2]|\n"
+                   "v_sub_f32_e32 %[dl], %[cand], %[lam]\n v_sub_f32_e32 %[dl2], %[cand2], %[lam2]\n"
+                   "s_and_b64 %[w], %[ph], %[t]\n s_and_b64 %[w2], %[ph], %[t2]\n"
+                   "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n v_cmp_gt_f32_e64 %[pend2], |%[dl2]|, %[thr2]\n s_nop 0\n s_nop 0\n"
+                   "s_and_b64 %[todo], %[pend], %[w]\n s_and_b64 %[todo2], %[pend2], %[w2]\n"
+                   "s_or_b64 %[todo], %[todo], %[ph]\n s_or_b64 %[todo2], %[todo2], %[ph]\n"
+                   ".endr\n"
+                   : [v] "+v"(x0), [lam] "+v"(x1), [cand] "+v"(x2), [dl] "+v"(x3), [thr] "=&v"(thr), [pend] "=&s"(pend), [w] "=&s"(w),
+                     [t] "=&s"(t), [todo] "+s"(todo), [rs] "=&s"(rs), [sd] "=&s"(sd),
+                     [v2] "+v"(x5), [lam2] "+v"(x6), [cand2] "+v"(x7), [dl2] "+v"(x4), [thr2] "=&v"(thr2), [pend2] "=&s"(pend2), [w2] "=&s"(w2),
+                     [t2] "=&s"(t2), [todo2] "+s"(todo2), [rs2] "=&s"(rs2), [sd2] "=&s"(sd2)
+                   : [lane] "v"(lane), [tol] "v"(c), [lo] "v"(-b), [hi] "v"(b), [col] "v"(b), [ph] "s"(0x0924092409240924ull)
+                   : "vcc", "scc");
+    }
+    s0 += (int)todo + (int)todo2;
+  }
+}
+
+// neighbours: 0 = exit at once, 1 = run the same stream at priority 0, 2 = sleep until the measuring wave is done
+template <int MODE>
+__global__ __launch_bounds__(64, 4) void k(float* out, unsigned long long* ticks, int* ticket, int* done_flag, int iters,
+                                           int neighbours, int prio) {
+  // which SIMD am I on?  XCC_ID (hwreg 20) and HW_ID (hwreg 4): simd [5:4], cu [11:8], sh [12], se [15:13]
+  const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4), xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xf;
+  const unsigned simd = (xcc << 10) | (((hw >> 13) & 7) << 7) | (((hw >> 12) & 1) << 6) | (((hw >> 8) & 0xf) << 2) | ((hw >> 4) & 3);
+  int first = 0;
+  if (threadIdx.x == 0) first = atomicAdd(&ticket[simd], 1) == 0;
+  first = __builtin_amdgcn_readfirstlane(first);
   float x0 = threadIdx.x, x1 = 1, x2 = 2, x3 = 3, x4 = 4, x5 = 5, x6 = 6, x7 = 7;
   const float b = 1.0001f, c = 1e-4f;
   int s0 = iters, s1 = 1, s2 = 2, s3 = 3;
-  unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  for (int i = 0; i < iters; ++i) {
-    if (MODE == 0) {  // 8 independent v_fma
-      asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
-                   "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
-                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b), "v"(c));
-    } else if (MODE == 1) {  // one dependent chain of 8
-      asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
-                   "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
-                   : "+v"(x0) : "v"(b), "v"(c));
-    } else if (MODE == 2) {  // 4 v_fma + 4 s_add interleaved (8 instructions)
-      asm volatile("v_fma_f32 %0, %0, %8, %9\n s_add_u32 %4, %4, 1\n v_fma_f32 %1, %1, %8, %9\n s_add_u32 %5, %5, 1\n"
-                   "v_fma_f32 %2, %2, %8, %9\n s_add_u32 %6, %6, 1\n v_fma_f32 %3, %3, %8, %9\n s_add_u32 %7, %7, 1\n"
-                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(b), "v"(c) : "scc");
-    } else if (MODE == 3) {  // 8 independent s_add
-      asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
-                   "s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
-                   : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
-    } else if (MODE == 4) {  // 8 dependent v_add with DPP row_ror (the reductions' shape)
-      asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-                   "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-                   : "+v"(x0));
+  if (!first) {
+    if (neighbours == 0) { ticks[blockIdx.x] = 0; return; }
+    if (neighbours == 2) {
+      // (bounded: ~0.2 s at most, whatever the dispatcher did with the placement - every wave reaches its exit)
+      for (int spin = 0; spin < 100000 && __hip_atomic_load(done_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x / 4; ++spin)
+        __builtin_amdgcn_s_sleep(64);
+      ticks[blockIdx.x] = 0;
+      return;
     }
+  } else {
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
   }
-  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int i = 0; i < iters; ++i) body<MODE>(x0, x1, x2, x3, x4, x5, x6, x7, s0, s1, s2, s3, b, c);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * 64 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + s0 + s1 + s2 + s3;
-  if (threadIdx.x == 0) t[blockIdx.x] = t1 - t0;
+  if (threadIdx.x == 0) {
+    ticks[blockIdx.x] = first ? (t1 - t0) : 0;
+    if (first) atomicAdd(done_flag, 1);
+  }
 }
-template <int MODE> void run(const char* name, int blocks) {
-  float* out; unsigned long long* t; hipMalloc(&out, blocks * 64 * 4); hipMalloc(&t, blocks * 8);
-  const int iters = 20000;
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, out, t, iters); hipDeviceSynchronize();
-  hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, out, t, iters);
-  hipEventRecord(e1, 0); hipDeviceSynchronize();
-  float ms; hipEventElapsedTime(&ms, e0, e1);
-  unsigned long long* h = new unsigned long long[blocks]; hipMemcpy(h, t, blocks * 8, hipMemcpyDeviceToHost);
-  double mean = 0, mx = 0; for (int i = 0; i < blocks; ++i) { mean += h[i]; if (h[i] > mx) mx = h[i]; } mean /= blocks;
-  printf("%-28s waves/SIMD %4.1f: %6.2f ticks per instruction per wave (mean; slowest wave %6.2f) ; launch %.3f ms -> %.2f ns per instr per wave, tick = %.3f ns\n",
-         name, blocks / 1024.0, mean / (iters * 8.0), mx / (iters * 8.0), ms, ms * 1e6 / (iters * 8.0), ms * 1e6 / mx);
-  delete[] h; hipFree(out); hipFree(t);
+
+struct Result { double mean, p50, mx; int n; };
+
+template <int MODE> Result run(int blocks, int neighbours, int prio, int iters) {
+  float* out; unsigned long long* t; int *ticket, *flag;
+  hipMalloc(&out, blocks * 64 * 4); hipMalloc(&t, blocks * 8); hipMalloc(&ticket, 16384 * 4); hipMalloc(&flag, 4);
+  Result r{};
+  for (int rep = 0; rep < 2; ++rep) {  // (the second launch is measured)
+    hipMemset(ticket, 0, 16384 * 4); hipMemset(flag, 0, 4); hipMemset(t, 0, blocks * 8);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, out, t, ticket, flag, iters, neighbours, prio);
+    hipDeviceSynchronize();
+  }
+  std::vector<unsigned long long> h(blocks); hipMemcpy(h.data(), t, blocks * 8, hipMemcpyDeviceToHost);
+  std::vector<double> v;
+  for (auto x : h) if (x) v.push_back((double)x);
+  std::sort(v.begin(), v.end());
+  r.n = (int)v.size();
+  if (r.n) { for (double x : v) r.mean += x; r.mean /= r.n; r.p50 = v[r.n / 2]; r.mx = v.back(); }
+  hipFree(out); hipFree(t); hipFree(ticket); hipFree(flag);
+  return r;
 }
+
+template <int MODE> void report(int blocks, int neighbours, int prio, const Result& empty) {
+  const int iters = 400;
+  const Result r = run<MODE>(blocks, neighbours, prio, iters);
+  const double n = (double)iters * kBodyInstr[MODE];
+  printf("  %-58s %6.2f cycles per instruction (median wave; mean %6.2f, slowest %6.2f; %d measuring waves)\n", kModeName[MODE],
+         (r.p50 - empty.p50) / n, (r.mean - empty.mean) / n, (r.mx - empty.p50) / n, r.n);
+}
+
 int main() {
-  for (int blocks : {256, 1024, 2048, 4096, 8192}) {
-    run<0>("v_fma 8 independent", blocks);
-    run<1>("v_fma dependent chain", blocks);
-    run<2>("v_fma / s_add interleaved", blocks);
-    run<3>("s_add 4 chains", blocks);
-    run<4>("v_add_dpp chain + s_nop 1", blocks);
+  struct Scn { const char* name; int blocks, neighbours, prio; };
+  const Scn scn[] = {
+      {"ONE wave per SIMD (1024 workgroups), priority 0", 1024, 1, 0},
+      {"4 waves per SIMD: the first measures at priority 3, its three neighbours EXIT at once (the tail of a launch)", 4096, 0, 3},
+      {"4 waves per SIMD: the first measures at priority 3, its three neighbours SLEEP", 4096, 2, 3},
+      {"4 waves per SIMD: the first measures at priority 3, its three neighbours run the same stream at priority 0", 4096, 1, 3},
+      {"4 waves per SIMD: the first measures at priority 0, its three (younger) neighbours run the same stream at priority 0", 4096, 1, 0},
+  };
+  printf("(guide, MI355X_MICROARCH.md: v_fma_f32 / s_nop 0 issue 4 cycles for one wave alone, 2 shared; dependent v_fma_f32 ~6.6)\n");
+  for (const Scn& s : scn) {
+    printf("%s\n", s.name);
+    const Result e = run<kEmpty>(s.blocks, s.neighbours, s.prio, 400);
+    printf("  %-58s %6.1f cycles per ITERATION (s_add + s_cmp + taken s_cbranch), subtracted below\n", kModeName[kEmpty], e.p50 / 400);
+    report<kFmaIndep>(s.blocks, s.neighbours, s.prio, e);
+    report<kFmaDep>(s.blocks, s.neighbours, s.prio, e);
+    report<kFmaDep2>(s.blocks, s.neighbours, s.prio, e);
+    report<kFmaSadd>(s.blocks, s.neighbours, s.prio, e);
+    report<kSadd>(s.blocks, s.neighbours, s.prio, e);
+    report<kSnop>(s.blocks, s.neighbours, s.prio, e);
+    report<kDppChain>(s.blocks, s.neighbours, s.prio, e);
+    report<kRowUpdate>(s.blocks, s.neighbours, s.prio, e);
+    report<kRowUpdate2>(s.blocks, s.neighbours, s.prio, e);
   }
   return 0;
 }
