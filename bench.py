@@ -59,17 +59,29 @@ def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollo
   return env
 
 
-def desynchronise_episodes(eng, generator, max_steps=1000):
-  """Episode phases are DESYNCHRONISED before anything is timed: all robots start their 1000-step episodes
-  together, so a 20-step window would never see a termination, an auto-reset or a real number in the
-  statistics all-reduce.  The TimeBased counter (and the episode-length accumulator with it) of every
-  robot is seeded uniformly in [0, max_steps): ~K/1000 of the robots finish an episode in a K-step window
-  (the first episode of a robot is the remainder of one: its return covers the steps actually run)."""
+def desynchronise_episodes(eng, generator, max_steps=1000, advance=True):
+  """Brings the batch into the STEADY STATE of the workload before anything is timed.  All robots are created
+  in the same post-reset pose with their 1000-step episodes in phase: a 20-step window right after that would
+  never see a termination, an auto-reset or a real number in the statistics all-reduce, and would time 4096
+  copies of the first steps of an episode (folded on the ground, every knee and foot in contact) instead of
+  the mix of episode phases an RL run is in.  So every robot's TimeBased counter is seeded uniformly in
+  [0, max_steps) and the simulation is advanced by max_steps untimed steps of the same random-action workload
+  with the in-kernel auto-reset: each robot ends its (shortened) first episode at its own time and is
+  afterwards `phase` steps into a regular episode - counters AND physical states spread uniformly over the
+  episode.  ~K/1000 of the robots then finish an episode inside any K-step window."""
   import torch
   from gym_solo_amd import abi
-  phase = torch.randint(0, max_steps, (eng.num_envs,), device=eng.state.device, generator=generator, dtype=torch.int32)
+  n, dev = eng.num_envs, eng.state.device
+  phase = torch.randint(0, max_steps, (n,), device=dev, generator=generator, dtype=torch.int32)
   eng.term_count[:, 0] = phase
   eng.state[:, abi.S_EPLEN] = phase.to(eng.tdtype)
+  if not advance:
+    return
+  chunk = 100
+  for _ in range(0, max_steps, chunk):
+    a = (torch.rand(chunk, n, abi.NUM_JOINTS, device=dev, dtype=eng.tdtype, generator=generator) * 2 - 1) * (2 * 3.141592653589793)
+    eng.rollout(a, abi.STEP_ALL)
+  torch.cuda.synchronize(dev)
 
 
 def host_cores():
@@ -365,14 +377,16 @@ def main():
       run(action_pool(w), None if closed_loop else eng.rollout_buffers(w))
     def one_repeat():
       acts = action_pool(k)
-      stats_before = eng.stats_shards.clone()
+      # (the interval's statistics = totals after - totals before; the totals before are reduced over the ranks here,
+      # outside the timed region, the totals after inside it)
+      before = all_reduce_stats(eng.stats_shards.sum(dim=0))
       barrier()
       t0 = time.perf_counter()
       run(acts, out)
       # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI
-      stats = all_reduce_stats((eng.stats_shards - stats_before).sum(dim=0))
+      after = all_reduce_stats(eng.stats_shards.sum(dim=0), in_place=True)
       barrier()  # (all_reduce_stats is a no-op without an initialised process group)
-      return max_over_ranks(time.perf_counter() - t0), stats
+      return max_over_ranks(time.perf_counter() - t0), after - before
 
     # ... and ONE untimed repeat of exactly the timed region (same K, same output buffers, the statistics
     # reduction included): first-use costs - code objects of this launch shape and of torch's small kernels,
@@ -445,7 +459,7 @@ def main():
       'dtype': 'f32' if args.dtype == 'float32' else 'f64', 'data': 'synthetic',
       'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
                              'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
-                             'TimeBasedTermination(1000)+auto-reset (episode phases desynchronised), dt=1e-3, 50 PGS iterations' % n,
+                             'TimeBasedTermination(1000)+auto-reset, steady state (episode phases spread uniformly by 1000 untimed steps), dt=1e-3, 50 PGS iterations' % n,
                  'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': slices,
                  'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'timing': {'repeats': len(times), 'statistic': 'median', 'min_ms_per_step': min(times) / k * 1e3,

@@ -228,8 +228,11 @@ struct Engine final : EngineBase {
   // one chain of launches covering steps [0, k) for robots [lo, lo+count): per launch the step
   // kernel (one wave per robot, S fused steps), then - on the same stream - the output kernels
   // over the S x count step records it left behind (one thread per robot-step / per robot)
+  // final_chunk: this chain ends the caller's rollout - a RECORDING rollout then has its last launch's output
+  // kernel also leave the last step's observation / reward / done in the engine's view (what three
+  // device-to-device copies after the chain used to do: ~15 us of a 0.4 ms 20-step rollout)
   int launch_chain(const T* act, long long act_stride, int k, uint32_t flags, T* obs_out, T* reward_out,
-                   uint8_t* done_out, hipStream_t s, int lo, int count) {
+                   uint8_t* done_out, hipStream_t s, int lo, int count, bool final_chunk = true) {
     const int S = spl();
     const bool want_obs = (flags & SOLO_STEP_OBS) != 0, want_reward = (flags & SOLO_STEP_REWARD) != 0;
     for (int i = 0; i < k; i += S) {
@@ -271,9 +274,12 @@ struct Engine final : EngineBase {
       const bool bookkeeping = want_reward && (flags & SOLO_STEP_DONE);
       constexpr int kT = sizeof(T) == 4 ? 128 : 64;  // threads per block: ~50 KB of LDS staging either way
       const int gx = (count + kT - 1) / kT, gy = steps < 1024 / gx + 1 ? steps : 1024 / gx + 1;  // ~1000 blocks, each walking steps / gy steps
+      const bool tail_to_view = final_chunk && i + S >= k;  // (the view's copy of a recorded rollout's last step)
       hipLaunchKernelGGL((solo::solo_outputs_kernel<T, kT>), dim3(gx, gy), dim3(kT), 0, s, dparams, traj, steps, n, lo,
                          count, o, o_stride, o_from, r, r_stride, events, (flags & SOLO_STEP_DONE) ? b.done : (uint8_t*)nullptr,
-                         (long long)b.done_stride);
+                         (long long)b.done_stride, (tail_to_view && obs_out) ? obs : (T*)nullptr,
+                         (tail_to_view && reward_out) ? reward : (T*)nullptr,
+                         (tail_to_view && done_out && (flags & SOLO_STEP_DONE)) ? done : (uint8_t*)nullptr);
       HIP_TRY(hipGetLastError());
       if (bookkeeping) {
         hipLaunchKernelGGL(solo::solo_returns_kernel<T>, dim3((count + solo::kOutputThreads - 1) / solo::kOutputThreads),
@@ -293,7 +299,12 @@ struct Engine final : EngineBase {
     if (k == 0) return SOLO_OK;  // an empty rollout is a no-op
     if (!a || k < 0) { err = "rollout needs actions [K][N][12]"; return SOLO_ERR_INVALID_ARG; }
     if (int rc = rollout_impl((const T*)a, k, flags, obs_out, reward_out, done_out, s, nullptr, nullptr)) return rc;
-    // the engine's view always ends up with the LAST step's outputs, also when every step was recorded
+    // the engine's view always ends up with the LAST step's outputs, also when every step was recorded: the last
+    // launch's output kernel writes them (launch_chain); only rollouts whose last launch is a single-step launch with
+    // in-place outputs (steps_per_launch = 1 in f32, or a one-step remainder) copy
+    const int S = spl();
+    const int last_steps = (k % S == 0) ? S : k % S;
+    if (!(last_steps == 1 && solo::kInlineOutputs<T, true>)) return SOLO_OK;
     if (obs_out && (flags & SOLO_STEP_OBS))
       HIP_TRY(hipMemcpyAsync(obs, (const T*)obs_out + (size_t)(k - 1) * n * obs_dim, (size_t)n * obs_dim * sizeof(T), hipMemcpyDeviceToDevice, s));
     if (reward_out && (flags & SOLO_STEP_REWARD))
@@ -336,7 +347,7 @@ struct Engine final : EngineBase {
         const int kk = (k - i < S) ? (k - i) : S;
         if (int rc = launch_chain(act ? act + (size_t)i * stride : nullptr, stride, kk, flags,
                                   oo ? oo + (size_t)i * n * obs_dim : nullptr, ro ? ro + (size_t)i * n : nullptr,
-                                  dn ? dn + (size_t)i * n : nullptr, sub[g], lo, hi - lo))
+                                  dn ? dn + (size_t)i * n : nullptr, sub[g], lo, hi - lo, i + S >= k))
           return rc;
       }
     for (int g = 0; g < groups; ++g) {

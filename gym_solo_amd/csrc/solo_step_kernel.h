@@ -960,7 +960,8 @@ __global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>
                                                                 int steps, int num_envs, int env_base, int count,
                                                                 T* __restrict__ obs, long long obs_stride, int obs_from_step,
                                                                 T* __restrict__ reward, long long reward_stride,
-                                                                uint8_t* __restrict__ events, uint8_t* __restrict__ done, long long done_stride) {
+                                                                uint8_t* __restrict__ events, uint8_t* __restrict__ done, long long done_stride,
+                                                                T* __restrict__ view_obs, T* __restrict__ view_reward, uint8_t* __restrict__ view_done) {
   __shared__ T s_rec[kThreads][SOLO_STATE_STRIDE + 1];        // (+1: conflict-free row access)
   __shared__ T s_val[SOLO_MAX_REWARD_OPS][kThreads];           // reward program values, one column per thread
   __shared__ T s_obs[kThreads][kObsStageMax + 1];
@@ -983,20 +984,29 @@ __global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>
       const int ev = (int)rec[SOLO_S_SPARE];
       events[(size_t)k * num_envs + env] = (uint8_t)ev;
       if (done != nullptr && (done_stride != 0 || k == steps - 1)) done[(size_t)k * done_stride + env] = (uint8_t)(ev & kEventDone);
+      if (view_done != nullptr && k == steps - 1) view_done[env] = (uint8_t)(ev & kEventDone);
       T roll, pitch, yaw;
       euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
       if (want_obs)
         eval_observations<T>(P, rec, roll, pitch, yaw, staged ? &s_obs[tid][0] : obs + (size_t)k * obs_stride + (size_t)env * n_obs);
-      if (reward != nullptr)
-        reward[(size_t)k * reward_stride + env] = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kThreads);
+      if (want_obs && !staged && view_obs != nullptr && k == steps - 1)   // (wide observations: the thread's own row, just written)
+        for (int j = 0; j < n_obs; ++j) view_obs[(size_t)env * n_obs + j] = obs[(size_t)k * obs_stride + (size_t)env * n_obs + j];
+      if (reward != nullptr) {
+        const T rv = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kThreads);
+        reward[(size_t)k * reward_stride + env] = rv;
+        if (view_reward != nullptr && k == steps - 1) view_reward[env] = rv;  // (a recorded rollout's last step: also the engine's view)
+      }
     }
     block_sync();
     if (want_obs && staged) {
       T* dst = obs + (size_t)k * obs_stride + (size_t)(env_base + e0) * n_obs;  // nb rows of n_obs, contiguous
       int row = tid / n_obs, col = tid % n_obs;
       const int drow = kThreads / n_obs, dcol = kThreads % n_obs;
+      T* vdst = (view_obs != nullptr && k == steps - 1) ? view_obs + (size_t)(env_base + e0) * n_obs : nullptr;
       for (int w = tid; w < nb * n_obs; w += kThreads) {
-        dst[w] = s_obs[row][col];
+        const T x = s_obs[row][col];
+        dst[w] = x;
+        if (vdst != nullptr) vdst[w] = x;
         row += drow; col += dcol;
         if (col >= n_obs) { col -= n_obs; row += 1; }
       }

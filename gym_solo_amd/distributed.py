@@ -26,11 +26,12 @@ def shard_sizes(total_envs: int, world: int):
   return [base + (1 if r < rem else 0) for r in range(world)]
 
 
-def all_reduce_stats(stats, group=None):
+def all_reduce_stats(stats, group=None, in_place=False):
   """Sum the per-rank statistics [sum return, sum return^2, episodes, sum length, -, diverged, -, -]
-  over all ranks.  Returns a new tensor; a no-op without an initialised process group."""
+  over all ranks.  Returns a new tensor (or `stats` itself with in_place=True); a no-op without an
+  initialised process group."""
   import torch.distributed as dist
-  out = stats.clone()
+  out = stats if in_place else stats.clone()
   if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
   return out

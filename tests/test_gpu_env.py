@@ -157,6 +157,37 @@ def test_fused_rollout_equals_single_steps(dtype):
   assert out[1][2].sum() == 2 * 64  # two episode ends (steps 12 and 24) per robot
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+@pytest.mark.parametrize('spl,streams,k', [(1, 1, 5), (7, 1, 30), (7, 1, 21), (7, 2, 30), (20, 1, 20), (6, 2, 13)])
+def test_view_holds_the_last_step_of_a_recorded_rollout(dtype, spl, streams, k):
+  """After solo_engine_rollout_record the engine's view (obs / reward / done) holds the LAST step's outputs,
+  whatever the launch geometry: the last launch's output kernel writes them (no copies after the chain),
+  a single-step f32 launch evaluates them in place and the rollout copies."""
+  import torch
+  from gym_solo_amd import abi
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  from gym_solo_amd.workloads import register_benchmark_workload
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  cfg = Solo8VanillaConfig()
+  cfg.dtype, cfg._dtype_pinned, cfg.auto_reset, cfg.steps_per_launch, cfg.rollout_streams = dtype, True, True, spl, streams
+  env = make_env(config=cfg)
+  register_benchmark_workload(env, max_steps=k - 2)   # the last step of the rollout ends the first episode
+  env._ensure_program()
+  eng = env.engine
+  g = torch.Generator(device='cuda').manual_seed(11)
+  acts = (torch.rand(k, env.num_envs, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.28
+  for t in (eng.obs, eng.reward):
+    t.fill_(float('nan'))
+  eng.done.fill_(7)
+  obs, rew, done = eng.rollout(acts, abi.STEP_ALL, record=True)
+  eng.synchronize()
+  np.testing.assert_array_equal(eng.obs.cpu().numpy(), obs[-1].cpu().numpy())
+  np.testing.assert_array_equal(eng.reward.cpu().numpy(), rew[-1].cpu().numpy())
+  np.testing.assert_array_equal(eng.done.cpu().numpy(), done[-1].cpu().numpy())
+  assert bool(done[-1].all()) and not bool(done[:-1].any())
+  env._close()
+
+
 def test_domain_randomisation_matches_oracle():
   """BASELINE config 4: per-env lateral friction and base-mass scale (changeDynamics per env,
   solo8v2vanilla.py:158-163) — engine.set_params + re-settle vs the oracle with the same params."""
