@@ -171,7 +171,7 @@ def test_view_holds_the_last_step_of_a_recorded_rollout(dtype, spl, streams, k):
   cfg = Solo8VanillaConfig()
   cfg.dtype, cfg._dtype_pinned, cfg.auto_reset, cfg.steps_per_launch, cfg.rollout_streams = dtype, True, True, spl, streams
   env = make_env(config=cfg)
-  register_benchmark_workload(env, max_steps=k - 2)   # the last step of the rollout ends the first episode
+  register_benchmark_workload(env, max_steps=k - 1)   # TimeBased(k - 1) fires on step k: the last step ends the first episode
   env._ensure_program()
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(11)
