@@ -253,10 +253,12 @@ struct Engine final : EngineBase {
       }
       // stepSimulation-only calls (settle loop, client.stepSimulation()) run the physics-only
       // instantiation: no termination code, and a separate name in profiles
+      constexpr int kG = solo::kRobotsPerGroup;  // (1; 8 in the EXPERIMENT build `make group8`)
+      if (count % kG != 0) { err = "this build steps whole groups of robots"; return SOLO_ERR_INVALID_ARG; }
       if (flags == SOLO_STEP_PHYSICS)
-        hipLaunchKernelGGL((solo::solo_step_kernel<T, false>), dim3(count), dim3(64), 0, s, dparams, b);
+        hipLaunchKernelGGL((solo::solo_step_kernel<T, false>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
       else
-        hipLaunchKernelGGL((solo::solo_step_kernel<T, true>), dim3(count), dim3(64), 0, s, dparams, b);
+        hipLaunchKernelGGL((solo::solo_step_kernel<T, true>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
       HIP_TRY(hipGetLastError());
       if (skip_outputs || inline_outputs || !(want_obs || want_reward)) continue;
       // where this launch's outputs go: a recording rollout keeps every step ([K][N][.] buffers of

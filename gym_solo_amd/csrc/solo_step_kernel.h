@@ -111,6 +111,17 @@ template <typename T> __device__ __forceinline__ T from_lower(T x) { return wave
 template <typename T> __device__ __forceinline__ V3<T> from_lower(V3<T> v) { return {from_lower(v.x), from_lower(v.y), from_lower(v.z)}; }
 
 
+}  // namespace solo
+#ifdef SOLO_GROUP8
+#include "solo_step_kernel_g8.h"  // EXPERIMENT build (make group8): one wave computes the dynamics of 8 robots
+#endif
+namespace solo {
+#ifdef SOLO_GROUP8
+constexpr int kLegSlots = kG8LegSlots;
+#else
+constexpr int kLegSlots = 20;
+#endif
+
 // ------------------------------------------------------------------------------------------
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
 // constraint impulse; physics_finish writes s_state (new).
@@ -118,7 +129,7 @@ template <typename T> __device__ __forceinline__ V3<T> from_lower(V3<T> v) { ret
 template <typename T>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
                                            const RowConst<T>& rc, const T* s_state, T my_target, T (*s_rowvec)[8], T (*s_hext)[8],
-                                           T* s_keep, T (*s_leg)[20], const T* s_math, T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps, int& prio_rot) {
+                                           T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps, int& prio_rot) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = C.dt;
@@ -137,6 +148,15 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   const V3<T> gb = {r00 * gw.x + r10 * gw.y + r20 * gw.z, r01 * gw.x + r11 * gw.y + r21 * gw.z, r02 * gw.x + r12 * gw.y + r22 * gw.z};
   const V3<T> nb = {r20, r21, r22};  // world z (ground normal) in base coordinates
 
+#ifdef SOLO_GROUP8
+  // (EXPERIMENT build: the dynamics phase ran in the group's dynamics wave - physics_dynamics_g8 - which parked
+  // its results in s_keep / s_leg; what the row phase reads of it besides those is re-derived here)
+  const T q1 = s_leg[leg][17], q2 = s_leg[leg][18];
+  const T c1 = s_leg[leg][19], s1 = s_leg[leg][20], c12 = s_leg[leg][21], s12 = s_leg[leg][22];
+  const V3<T> o1 = {L.hip[0], L.hip[1], L.hip[2]};
+  const V3<T> o2 = o1 + roty(c1, s1, V3<T>{L.knee[0], L.knee[1], L.knee[2]});
+  (void)om; (void)vb; (void)gb; (void)dt; (void)mass_scale;
+#else
   // ---- leg-local kinematics.  Each 16-lane row works on its own leg, and the two HALVES of the
   //      row on the leg's two links: lanes k < 8 carry the upper link, k >= 8 the lower link
   //      (+ welded foot) through the same instructions; per-leg quantities are the sum of the two
@@ -340,6 +360,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     s_leg[leg][15] = us1; s_leg[leg][16] = us2; s_leg[leg][17] = q1; s_leg[leg][18] = q2;
   }
   wave_sync();
+#endif  // SOLO_GROUP8
 
   SOLO_STAMP(B, 6);
   // ---- constraint rows: one per lane --------------------------------------------------------
@@ -615,7 +636,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 // K du_b), go back to world-frame velocities and integrate.  Everything is re-read from LDS.
 template <typename T>
 __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, const T (*s_rowvec)[8],
-                                               const T* s_keep, const T (*s_leg)[20], const T* s_math, T lam, int lane) {
+                                               const T* s_keep, const T (*s_leg)[kLegSlots], const T* s_math, T lam, int lane) {
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = C.dt;
@@ -690,13 +711,40 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
 // batch resident on the 1024 SIMDs); f64: 2 (the Delassus row alone is 112 VGPRs).
 // kFull = false: physics-only instantiation (flags are treated as SOLO_STEP_PHYSICS).
 // single-step launches evaluate their outputs in the step kernel itself (see the step loop): f32 only
+#ifdef SOLO_GROUP8
+template <typename T, bool kFull> constexpr bool kInlineOutputs = false;  // (the experiment build leaves records)
+constexpr int kRobotsPerGroup = kG8;
+#else
 template <typename T, bool kFull> constexpr bool kInlineOutputs = kFull && sizeof(T) == 4;
+constexpr int kRobotsPerGroup = 1;
+#endif
 
 template <typename T, bool kFull>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(const KParams<T>* __restrict__ Pin, KBuffers<T> Bin) {
+__global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(const KParams<T>* __restrict__ Pin, KBuffers<T> Bin) {
   KBuffers<T> B = Bin;
   if (!kFull) B.flags = SOLO_STEP_PHYSICS;
   using R = Real<T>;
+#ifdef SOLO_GROUP8
+  // EXPERIMENT build: 8 waves = 8 robots per workgroup; every robot's arrays are a slice of the group's
+  __shared__ T s_state_g[kG8][SOLO_STATE_STRIDE];
+  __shared__ T s_rowvec_g[kG8][64][8];
+  __shared__ T s_hext_g[kG8][64][8];
+  __shared__ T s_keep_g[kG8][32];
+  __shared__ T s_leg_g[kG8][4][kLegSlots];
+  __shared__ int s_cnt_g[kG8][64];
+  __shared__ int s_termlim_g[kG8][64];
+  __shared__ int s_termtick_g[kG8][64];
+  __shared__ T s_mass_g[kG8];
+  const int wave_in_group = (int)threadIdx.x >> 6;
+  T* const s_state = s_state_g[wave_in_group];
+  T (*const s_rowvec)[8] = s_rowvec_g[wave_in_group];
+  T (*const s_hext)[8] = s_hext_g[wave_in_group];
+  T* const s_keep = s_keep_g[wave_in_group];
+  T (*const s_leg)[kLegSlots] = s_leg_g[wave_in_group];
+  int* const s_cnt = s_cnt_g[wave_in_group];
+  int* const s_termlim = s_termlim_g[wave_in_group];
+  int* const s_termtick = s_termtick_g[wave_in_group];
+#else
   __shared__ T s_state[SOLO_STATE_STRIDE];
   __shared__ T s_rowvec[64][8];
   __shared__ T s_hext[64][8];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
@@ -708,6 +756,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   __shared__ int s_cnt[64];
   __shared__ int s_termlim[64];
   __shared__ int s_termtick[64];
+#endif
   // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
   // read them from LDS instead of paying a global-load latency each
   __shared__ LegConst<T> s_legc[4];
@@ -716,10 +765,15 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
   // coefficient table of Real<T>'s polynomials (f64 only: see Real<double>::sincos; f32 uses instruction literals)
   __shared__ T s_math[Real<T>::kTabSize > 0 ? Real<T>::kTabSize : 1];
 
+#ifdef SOLO_GROUP8
+  const int lane0 = lane_id() & 63;
+  const int slot = block_id() * kG8 + wave_in_group + B.env_base;  // (the engine launches whole groups only)
+#else
   const int lane0 = lane_id();
   // workgroup -> robot: the identity, or the cost-balanced launch order (solo_engine_set_order)
   const int slot = block_id() + B.env_base;
   if (slot >= B.num_envs) return;
+#endif
   // (wave_cold_args assumes the kernel's parameter layout - one pointer, then this block: checked on
   // two fields, so that a changed signature traps instead of reading garbage)
   if (wave_cold_args(Bin)->num_envs != B.num_envs || wave_cold_args(Bin)->steps != B.steps) __builtin_trap();
@@ -783,6 +837,9 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = state_w;
     s_cnt[lane0] = count_w;
     if constexpr (Real<T>::kTabSize > 0) { if (lane0 < Real<T>::kTabSize) s_math[lane0] = math_w; }
+#ifdef SOLO_GROUP8
+    if (lane0 == 0) s_mass_g[wave_in_group] = mass_scale;
+#endif
   }
   int prio_sweeps = wave_uniform(hist_w);
   const int hist_sweeps = prio_sweeps;
@@ -832,6 +889,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(c
     SOLO_STAMP(B, 1);
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
+#ifdef SOLO_GROUP8
+      group_sync();  // every robot of the group has its state of the previous step (or the prologue's) in LDS
+      if (wave_in_group == 0)
+        physics_dynamics_g8<T>(C, s_legc, &s_state_g[0][0], &s_keep_g[0][0], &s_leg_g[0][0][0], s_mass_g, s_math, lane);
+      group_sync();  // ... and its factors / unconstrained velocities from the dynamics wave
+#endif
       const T my_target = raw_target * target_scale;
       const T lam = physics_solve<T>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, prio_sweeps, prio_steps, prio_rot);
       physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, s_math, lam, lane);

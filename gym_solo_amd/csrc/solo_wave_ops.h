@@ -13,7 +13,14 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x; }
 __device__ __forceinline__ int block_id() { return blockIdx.x; }
 
 // Orders this wave's LDS writes before the following LDS reads of other lanes.
+#ifdef SOLO_GROUP8
+// (EXPERIMENT build, 8 waves per workgroup: a wave-local fence - the DS operations of one wave execute in order -
+// and a real barrier of the group where the waves hand data to each other)
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void group_sync() { __syncthreads(); }
+#else
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+#endif
 // barrier of a multi-wave block (the output kernels)
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
 // wave-uniform pointer made opaque to the optimiser (no instruction): loads through the result
