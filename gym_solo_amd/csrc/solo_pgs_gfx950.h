@@ -4,14 +4,16 @@
 // emulator run it, and tests/test_gpu_pgs_asm.py compares this file against it BIT FOR BIT on the GPU
 // (libsolo_hip_pgs_cpp.so: the same translation unit with -DSOLO_PGS_NO_ASM), sweep counts included.
 //
-// Why assembly.  One wave issues one instruction every ~7 cycles whatever the instruction is and whether
-// or not it depends on the one before (tools/microbench/pgs_chain.hip: the row-update block costs
-// 7 cycles x its instruction count with the register indexing, the v_readlane and the compare -> SGPR
-// hop removed one by one, and just the same with the next row made independent of the scalar chain:
-// a speculative, software-pipelined walk was built, measured 6 % SLOWER for its three extra
-// instructions per row, and dropped).  So the time of this loop - half the time of the slowest robot
-// of a launch, the one that decides how long the launch takes - is its INSTRUCTION COUNT, and that is
-// what is minimised here:
+// Why assembly.  The loop is a serial chain (a row's update decides which row is next), issued by ONE wave: what
+// that costs was re-measured in round 3 (tools/microbench/simd_rate.hip, 256-instruction bodies:
+// profiles/round3_microbench_simd_rate.log) - a lone wave issues INDEPENDENT instructions (v_fma_f32, s_add, s_nop)
+// every 4.1 cycles, a dependent v_fma_f32 chain every 5.1, and this loop's row-update block every 6.2 cycles per
+// instruction, whether its three neighbours on the SIMD have exited, sleep, or run at a lower priority; two
+// independent row updates interleaved instruction by instruction would run at 5.2.  (Round 2's "7 cycles whatever
+// the instruction" came from a microbenchmark that counted its 8-instruction loop's branch as measured work.)
+// Gauss-Seidel offers no second independent row, so the time of this loop - half the time of the slowest robot of
+// a launch, the one that decides how long the launch takes - follows its INSTRUCTION COUNT at ~6 cycles each, and
+// that is what is minimised here:
 //  * ONE 64-slot column bank.  The two 32-register tuples of ColumnBank<float> are pinned to
 //    v[64:95] / v[96:127], so a column is `v64` indexed by the row number: three walks per sweep
 //    instead of the compiler's six (one per phase and 32-register tuple);

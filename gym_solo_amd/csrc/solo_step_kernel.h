@@ -17,14 +17,13 @@
 //    inertia).  Every constraint row r (8 motor rows, 8 joint-limit rows, 3 per touching sphere) is
 //    owned by ONE LANE, which whitens its Jacobian against those factors (ghat_r in R^6, hhat_r in
 //    R^2), so that the Delassus matrix is  A_sr = ghat_s.ghat_r + [same leg] hhat_s.hhat_r.
-//  * f32: the scaled columns of that matrix for the rows that can move are built once per step into
-//    two 32-wide register tuples (ColumnBank, solo_wave_ops.h); f64 evaluates them from the whitened
-//    row vectors in LDS.  Projected Gauss-Seidel keeps, per lane, the row's candidate, impulse and
+//  * The scaled columns of that matrix for the rows that can move are built once per step into register
+//    tuples (ColumnBank, solo_wave_ops.h: 64 VGPRs in f32, 128 in f64).  Projected Gauss-Seidel keeps, per lane, the row's candidate, impulse and
 //    bounds; the rows that still move are found for all lanes at once (clamp, subtract, compare:
 //    the compare's lane mask is the set) and only those are visited, in solver order (non-contact
 //    rows, normal rows, friction rows), each with one register-indexed move for its column (see
-//    physics_solve; the f32 loop itself is written in assembly: solo_pgs_gfx950.h - a wave issues one
-//    instruction every ~7 cycles whatever it is, so the loop's time is its instruction count).  All
+//    physics_solve; the loop itself is written in assembly for both precisions: solo_pgs_gfx950.h - a serial
+//    chain issued by one wave at ~6 cycles per instruction, so its time is its instruction count).  All
 //    branching is wave-uniform: the whole wave belongs to one robot.
 //  * The ~50 scalars a step reads, the per-leg and per-row tables live in LDS for the launch; the
 //    rarely used kernel arguments are re-read from the kernarg segment where they are used.
@@ -484,8 +483,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // static, the LDS broadcasts of many columns in flight at once).  The Gauss-Seidel loop below
   // then fetches the column of the row it updates with ONE register-indexed move
   // (s_set_gpr_idx_on + v_mov) instead of an LDS round trip and a dot product on its serial chain.
-  // (f64: 64 doubles per lane do not fit next to the rest of the step in 256 VGPRs - the parity
-  // instantiation evaluates the same expression from LDS when the row is updated.)
+  // (f64 since round 3 as well: 64 doubles per lane = v[128:255], half of the 256 VGPRs of a wave at two waves per
+  // SIMD - everything the rest of the step needs while they are live fits in the other half.)
   const T nid = -inv_d;
   ColumnBank<T> A;
   A.init(gh, hh, nid, lane, &s_rowvec[0][0], &s_hext[0][2 * leg]);  // (+ 8 r: row r's joint-space part if r is on this lane's leg, else 0)
@@ -547,8 +546,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #endif
   int it = 0;
 #ifdef SOLO_PGS_GFX950
-  // f32 on the GPU: the loop below, written in assembly (solo_pgs_gfx950.h) - same rows, same order, same
-  // arithmetic; this C++ form stays the definition (f64, the CPU emulator, and the -DSOLO_PGS_NO_ASM test
+  // on the GPU: the loop below, written in assembly (solo_pgs_gfx950.h, f32 and f64) - same rows, same order, same
+  // arithmetic; this C++ form stays the definition (the CPU emulator, and the -DSOLO_PGS_NO_ASM test
   // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py)
   {
     int rows_updated = 0;
@@ -708,7 +707,7 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
 // the fused kernel
 // ------------------------------------------------------------------------------------------
 // __launch_bounds__(64, W): W waves per SIMD -> 512/W VGPRs.  f32: 4 (128 VGPRs, a whole 4096-robot
-// batch resident on the 1024 SIMDs); f64: 2 (the Delassus row alone is 112 VGPRs).
+// batch resident on the 1024 SIMDs); f64: 2 (256 VGPRs: the resident columns alone are 128).
 // kFull = false: physics-only instantiation (flags are treated as SOLO_STEP_PHYSICS).
 // single-step launches evaluate their outputs in the step kernel itself (see the step loop): f32 only
 #ifdef SOLO_GROUP8

@@ -197,8 +197,6 @@ template <> struct RowDot<float> {
 // index turns into one register-indexed move (s_set_gpr_idx_on / v_mov_b32 / s_set_gpr_idx_off);
 // a plain array would be demoted to scratch memory.  build() is only ever called with indices that
 // are constants after unrolling; get() with a constant bank and a uniform r inside that bank.
-// f64 (the parity instantiation): 64 doubles per lane do not fit; get() evaluates the same
-// expression from the whitened row vectors in LDS.
 typedef float solo_f32x32 __attribute__((ext_vector_type(32)));
 template <typename T> struct ColumnBank;
 template <> struct ColumnBank<float> {
