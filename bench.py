@@ -220,9 +220,9 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
   return ('latency bound, not HBM bound: %.0f VALU instructions per env-step (rocprofv3 --pmc SQ_INSTS_VALU, '
           'profiles/pmc_traffic.json) x %d cycles (wave64 on a SIMD-32 shared by %.0f waves, MI355X_MICROARCH.md) x %d '
           'env-steps x %d concurrent launch chains = %.2f of the %d SIMDs\' VALU issue capacity over the measured launch '
-          'duration at %.1f GHz; what binds is the issue rate of ONE wave per robot - one instruction of any kind every ~7 '
-          'cycles (tools/microbench), %s instructions per env-step - and the launch waiting for its slowest robot '
-          '(profiles/README.md)'
+          'duration at %.1f GHz; what binds is the issue rate of ONE wave per robot - 4.1 cycles per independent instruction, '
+          '6.2 per instruction of the solver\'s serial row-update chain (tools/microbench/simd_rate.hip), %s instructions per '
+          'env-step - and the launch waiting for its slowest robot (DESIGN.md section 4)'
           % (valu, cyc, waves_per_simd, env_steps_per_launch, chains, util, NUM_SIMDS, clock / 1e9,
              ('%.0f' % pmc['insts_per_env_step']) if pmc.get('insts_per_env_step') else '~2300'))
 
