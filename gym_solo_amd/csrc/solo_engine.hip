@@ -56,11 +56,9 @@ struct Engine final : EngineBase {
   solo::KParams<T>* dparams = nullptr;
   T *state = nullptr, *snapshot = nullptr, *targets = nullptr, *params = nullptr, *obs = nullptr,
     *reward = nullptr, *settle_actions = nullptr;
-  // per-launch scratch of the output kernels: the step records [S][N][32] and, when a rollout does
-  // not record, the rewards [S][N] the returns kernel scans (S = steps per launch)
-  T *traj = nullptr, *reward_scratch = nullptr;
-  uint8_t* events = nullptr;  // [S][N] event bits of the launch's steps
-  bool skip_outputs = false;  // time_step: the step kernel alone
+  // per-launch scratch: the step records [N][S][32] a fused launch leaves for its own output epilogue
+  // (S = steps per launch)
+  T* traj = nullptr;
   uint8_t* done = nullptr;
   int32_t* term_count = nullptr;
   int32_t *order = nullptr, *cost = nullptr;  // launch order (null = identity), per-robot sweeps of the last launch
@@ -80,7 +78,7 @@ struct Engine final : EngineBase {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : {(void*)dparams, (void*)state, (void*)snapshot, (void*)targets, (void*)params,
                     (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
-                    (void*)term_count, (void*)order, (void*)cost, (void*)stats, (void*)terrain, (void*)traj, (void*)reward_scratch, (void*)events})
+                    (void*)term_count, (void*)order, (void*)cost, (void*)stats, (void*)terrain, (void*)traj})
       if (p) (void)hipFree(p);
   }
 
@@ -105,8 +103,6 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMalloc((void**)&cost, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMemset(cost, 0, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&traj, (size_t)spl() * ns * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&reward_scratch, (size_t)spl() * n * sizeof(T)));
-    HIP_TRY(hipMalloc((void**)&events, (size_t)spl() * n));
     HIP_TRY(hipMemset(obs, 0, (size_t)n * SOLO_MAX_OBS * sizeof(T)));
     HIP_TRY(hipMemset(reward, 0, (size_t)n * sizeof(T)));
     HIP_TRY(hipMemset(done, 0, (size_t)n));
@@ -134,7 +130,8 @@ struct Engine final : EngineBase {
   solo::KBuffers<T> buffers(const T* actions, uint32_t flags) const {
     solo::KBuffers<T> b;
     b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
-    b.params = params; b.traj = nullptr; b.events = events; b.obs_inline = b.reward_inline = nullptr; b.done = done; b.term_count = term_count;
+    b.params = params; b.traj = nullptr; b.obs_inline = b.reward_inline = nullptr; b.done = done; b.term_count = term_count;
+    b.obs_rec = b.reward_rec = b.view_obs = b.view_reward = nullptr; b.view_done = nullptr; b.obs_rec_stride = b.reward_rec_stride = 0; b.obs_from = 0;
     b.stats = stats; b.terrain = terrain; b.order = use_order ? order : nullptr; b.cost = cost; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
     b.action_stride = b.done_stride = 0;
 #ifdef SOLO_STAMPS
@@ -242,14 +239,27 @@ struct Engine final : EngineBase {
       b.steps = steps;
       b.action_stride = act_stride;
       if (done_out) { b.done = done_out + (size_t)i * n; b.done_stride = n; }
-      // a single-step launch (closed-loop step(), or a rollout with steps_per_launch = 1) evaluates
-      // its outputs inside the step kernel; a fused launch leaves records for the output kernels
+      // a single-step f32 launch (closed-loop step(), or a rollout with steps_per_launch = 1) evaluates its outputs
+      // lane-parallel over the items of the one step; every other launch leaves records, which the robot's wave
+      // evaluates after its last step (the output epilogue of the step kernel): where they go -
       const bool inline_outputs = steps == 1 && (want_obs || want_reward) && solo::kInlineOutputs<T, true>;
       if (inline_outputs) {
         if (want_obs) b.obs_inline = obs_out ? obs_out + (size_t)i * n * obs_dim : obs;
         if (want_reward) b.reward_inline = reward_out ? reward_out + (size_t)i * n : reward;
       } else if (want_obs || want_reward) {
         b.traj = traj;
+        // a recording rollout keeps every step ([K][N][.] buffers of the caller) and its last launch also leaves the
+        // last step in the engine's view; otherwise only the last step's observation / reward / done stay in the view
+        const bool tail_to_view = final_chunk && i + S >= k;
+        if (want_obs) {
+          if (obs_out) { b.obs_rec = obs_out + (size_t)i * n * obs_dim; b.obs_rec_stride = (long long)n * obs_dim; if (tail_to_view) b.view_obs = obs; }
+          else b.view_obs = obs;
+        }
+        if (want_reward) {
+          if (reward_out) { b.reward_rec = reward_out + (size_t)i * n; b.reward_rec_stride = n; if (tail_to_view) b.view_reward = reward; }
+          else b.view_reward = reward;
+        }
+        if (done_out && (flags & SOLO_STEP_DONE) && tail_to_view) b.view_done = done;
       }
       // stepSimulation-only calls (settle loop, client.stepSimulation()) run the physics-only
       // instantiation: no termination code, and a separate name in profiles
@@ -260,38 +270,6 @@ struct Engine final : EngineBase {
       else
         hipLaunchKernelGGL((solo::solo_step_kernel<T, true>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
       HIP_TRY(hipGetLastError());
-      if (skip_outputs || inline_outputs || !(want_obs || want_reward)) continue;
-      // where this launch's outputs go: a recording rollout keeps every step ([K][N][.] buffers of
-      // the caller), otherwise only the last step's observation / reward stay in the engine's view
-      T* o = nullptr; long long o_stride = 0; int o_from = 0;
-      if (want_obs) {
-        if (obs_out) { o = obs_out + (size_t)i * n * obs_dim; o_stride = (long long)n * obs_dim; }
-        else { o = obs; o_stride = 0; o_from = steps - 1; }
-      }
-      T* r = nullptr; long long r_stride = 0;
-      if (want_reward) {
-        if (reward_out) { r = reward_out + (size_t)i * n; r_stride = n; }
-        else { r = reward_scratch; r_stride = n; }
-      }
-      const bool bookkeeping = want_reward && (flags & SOLO_STEP_DONE);
-      constexpr int kT = sizeof(T) == 4 ? 128 : 64;  // threads per block: ~50 KB of LDS staging either way
-      const int gx = (count + kT - 1) / kT, gy = steps < 1024 / gx + 1 ? steps : 1024 / gx + 1;  // ~1000 blocks, each walking steps / gy steps
-      const bool tail_to_view = final_chunk && i + S >= k;  // (the view's copy of a recorded rollout's last step)
-      hipLaunchKernelGGL((solo::solo_outputs_kernel<T, kT>), dim3(gx, gy), dim3(kT), 0, s, dparams, traj, steps, n, lo,
-                         count, o, o_stride, o_from, r, r_stride, events, (flags & SOLO_STEP_DONE) ? b.done : (uint8_t*)nullptr,
-                         (long long)b.done_stride, (tail_to_view && obs_out) ? obs : (T*)nullptr,
-                         (tail_to_view && reward_out) ? reward : (T*)nullptr,
-                         (tail_to_view && done_out && (flags & SOLO_STEP_DONE)) ? done : (uint8_t*)nullptr);
-      HIP_TRY(hipGetLastError());
-      if (bookkeeping) {
-        hipLaunchKernelGGL(solo::solo_returns_kernel<T>, dim3((count + solo::kOutputThreads - 1) / solo::kOutputThreads),
-                           dim3(solo::kOutputThreads), 0, s, state, events, steps, n, lo, count, r, r_stride, stats,
-                           r == reward_scratch ? reward : (T*)nullptr);
-        HIP_TRY(hipGetLastError());
-      } else if (want_reward && r == reward_scratch) {  // the view keeps the last step's reward
-        HIP_TRY(hipMemcpyAsync(reward + lo, reward_scratch + (size_t)(steps - 1) * n + lo, (size_t)count * sizeof(T),
-                               hipMemcpyDeviceToDevice, s));
-      }
     }
     return SOLO_OK;
   }
@@ -388,9 +366,7 @@ struct Engine final : EngineBase {
     hipEvent_t* e0 = ev.e;
     hipEvent_t* e1 = ev.e + kMaxStreams;
     int groups = 1;
-    skip_outputs = true;  // the dominant kernel alone (the output kernels are separate, short launches)
     const int rc_chain = rollout_impl((const T*)a, reps * spl(), flags, nullptr, nullptr, nullptr, s, e0, e1, &groups);
-    skip_outputs = false;
     if (rc_chain) return rc_chain;
     HIP_TRY(hipStreamSynchronize(s));
     // every slice's chain is timed on its own stream; the AVERAGE launch duration over all slices

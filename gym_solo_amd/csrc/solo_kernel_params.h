@@ -102,11 +102,19 @@ struct KBuffers {
   T* targets;         // [N][12]
   const T* actions;   // [N][12] or null
   const T* params;    // [N][4]
-  T* traj;            // [steps][N][32] per-step records for the output kernels (solo_outputs.h), or null
-  uint8_t* events;    // [steps][N] per-step event bits for the returns kernel (with traj)
-  T* obs_inline;      // single-step launches (the closed-loop step()): [N][D] / [N] outputs evaluated by the
-  T* reward_inline;   // robot's own wave instead of a second launch; null otherwise
-  uint8_t* done;      // [N]
+  T* traj;            // [N][steps][32] per-step records of a fused launch (robot-major: a robot's records are
+                      // contiguous), evaluated by the robot's own wave at the end of the launch (lane = step), or null
+  T* obs_inline;      // single-step f32 launches (the closed-loop step()): [N][D] / [N] outputs evaluated lane-parallel
+  T* reward_inline;   // over the ITEMS of the one step; null otherwise
+  // where the outputs of a launch that leaves records go (all optional):
+  T* obs_rec;         // observation row of step k, robot e at obs_rec + k * obs_rec_stride + e * D, for k >= obs_from
+  T* reward_rec;      // reward of step k, robot e at reward_rec + k * reward_rec_stride + e
+  T* view_obs;        // the engine's view [N][D] / [N] / [N]: the LAST step's outputs (a recording rollout's last
+  T* view_reward;     // launch, and every rollout that does not record)
+  uint8_t* view_done;
+  long long obs_rec_stride, reward_rec_stride;
+  int32_t obs_from;
+  uint8_t* done;      // [N], or [steps][N] with done_stride = N
   int32_t* term_count;  // [N][4]
   double* stats;      // [SOLO_STATS_SHARDS][8]
   const T* terrain;   // [ny][nx] heights, or null = flat plane z = 0

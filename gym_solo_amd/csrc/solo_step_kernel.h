@@ -27,11 +27,12 @@
 //    branching is wave-uniform: the whole wave belongs to one robot.
 //  * The ~50 scalars a step reads, the per-leg and per-row tables live in LDS for the launch; the
 //    rarely used kernel arguments are re-read from the kernarg segment where they are used.
-//  * Termination (TimeBased counters) and the auto-reset stay in the robot's wave; observations,
-//    rewards and episodic returns do NOT: a fused launch leaves one 128-B record per robot-step
-//    and the output kernels at the end of this file evaluate them with one THREAD per robot-step
-//    (solo_outputs.h).  Only a single-step launch - the closed-loop step() - evaluates its outputs
-//    in place, with the same per-item functions.
+//  * Termination (TimeBased counters) and the auto-reset belong to the step; observations, rewards and
+//    episodic returns do NOT: a fused launch leaves one 128-B record per robot-step and the robot's wave
+//    evaluates them AFTER its last step, 32 steps at a time with lane = step (solo_outputs.h's per-item
+//    functions; round 3 - rounds 1-2 ran separate output kernels, one thread per robot-step, after the
+//    launch: ~14 % of a 20-step rollout).  Only a single-step f32 launch - the closed-loop step() -
+//    evaluates its outputs in place, lane = item, with the same functions.
 // No MFMA: there is no dense contraction here (14 dofs, <= 64 rows per robot).
 //
 // The including translation unit must provide solo::lane_id/block_id/wave_sync/wave_readlane/
@@ -726,8 +727,7 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
 #ifdef SOLO_GROUP8
   // EXPERIMENT build: 8 waves = 8 robots per workgroup; every robot's arrays are a slice of the group's
   __shared__ T s_state_g[kG8][SOLO_STATE_STRIDE];
-  __shared__ T s_rowvec_g[kG8][64][8];
-  __shared__ T s_hext_g[kG8][64][8];
+  __shared__ T s_rows_g[kG8][2][64][8];
   __shared__ T s_keep_g[kG8][32];
   __shared__ T s_leg_g[kG8][4][kLegSlots];
   __shared__ int s_cnt_g[kG8][64];
@@ -736,8 +736,9 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
   __shared__ T s_mass_g[kG8];
   const int wave_in_group = (int)threadIdx.x >> 6;
   T* const s_state = s_state_g[wave_in_group];
-  T (*const s_rowvec)[8] = s_rowvec_g[wave_in_group];
-  T (*const s_hext)[8] = s_hext_g[wave_in_group];
+  T (*const s_rows)[64][8] = s_rows_g[wave_in_group];
+  T (*const s_rowvec)[8] = s_rows[0];
+  T (*const s_hext)[8] = s_rows[1];
   T* const s_keep = s_keep_g[wave_in_group];
   T (*const s_leg)[kLegSlots] = s_leg_g[wave_in_group];
   int* const s_cnt = s_cnt_g[wave_in_group];
@@ -745,8 +746,9 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
   int* const s_termtick = s_termtick_g[wave_in_group];
 #else
   __shared__ T s_state[SOLO_STATE_STRIDE];
-  __shared__ T s_rowvec[64][8];
-  __shared__ T s_hext[64][8];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
+  __shared__ T s_rows[2][64][8];   // ONE block: the output epilogue uses it as its 1024-value scratch
+  T (*const s_rowvec)[8] = s_rows[0];
+  T (*const s_hext)[8] = s_rows[1];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][20];
   // termination (termination.py:38-83), one lane per termination (lanes >= SOLO_MAX_TERMS: never fire):
@@ -921,14 +923,14 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
       s_cnt[lane] = old + ((s_termtick[lane] != 0 && lane <= first) ? 1 : 0);
     }
     const bool restart = may_restart && (done || diverged);
-    // ---- the step's record for the output kernels (solo_outputs.h): the state after the step, before
+    // ---- the step's record for the output epilogue (end of this kernel): the state after the step, before
     //      an auto-reset, as ONE coalesced 32-real store; slot 31 carries the step's event bits (the
-    //      outputs kernel turns them into the events / done arrays: no byte stores from this wave)
+    //      epilogue turns them into the done flags and the episodic bookkeeping: no byte stores here)
     if (B.traj != nullptr) {
       const T ev = T((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
       const T word = s_state[lane & (SOLO_STATE_STRIDE - 1)];
       if (lane < SOLO_STATE_STRIDE)
-        B.traj[(unsigned)(step * B.num_envs + env) * (unsigned)SOLO_STATE_STRIDE + (unsigned)lane] = lane == SOLO_S_SPARE ? ev : word;
+        B.traj[(unsigned)(env * B.steps + step) * (unsigned)SOLO_STATE_STRIDE + (unsigned)lane] = lane == SOLO_S_SPARE ? ev : word;
     }
     // closed-loop step() = a single-step launch: its outputs are evaluated right here with the
     // same per-item functions the output kernels use (no second launch on the critical path of a
@@ -986,7 +988,7 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
         // reset() leaves the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
         if (lane < SOLO_NUM_JOINTS) wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = C.settle_tgt[lane];
       }
-      // (a launch that leaves records has its done flags written by the outputs kernel, from slot 31)
+      // (a launch that leaves records has its done flags written by the output epilogue, from slot 31)
       if (B.traj == nullptr && lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
     }
     SOLO_STAMP(B, 12);
@@ -994,105 +996,79 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
   }
   SOLO_STAMP(B, 13);
   const int lane1 = wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
+  // ---- THE OUTPUT EPILOGUE (round 3): the launch's observations, rewards, done flags and episodic bookkeeping,
+  //      evaluated by the robot's own wave from the records it left, 32 steps per pass with LANE = STEP - one pass
+  //      costs what one item costs (~450 instructions), whatever the number of steps in it: 0.2 % of a 250-step
+  //      launch, 3 % of a 20-step one, and a wave that finishes early does this while the launch waits for its slowest
+  //      robot anyway.  Rounds 1-2 ran two more kernels after the launch (one thread per robot-step; 15 + 5 us and two
+  //      launch gaps per 0.36-ms 20-step rollout in f32, 44 + 6 us in f64); the per-item functions are the same
+  //      (solo_outputs.h), so are the results, bit for bit.  The records are re-read from global memory (this wave
+  //      wrote them: L2-resident, its own robot's are contiguous); the reward program's values live in the row-vector
+  //      block of LDS, which is dead by now; lane 0 then folds the pass's rewards into the episodic accumulators in
+  //      step order (accumulate_returns: the additions stay sequential).
+  if constexpr (kFull) if (B.traj != nullptr) {
+    wave_fence_global();  // this wave's record stores before its loads of them
+    const auto A = wave_cold_args(Bin);
+    const int n_obs = wave_uniform(s_const.num_obs), n_rops = wave_uniform(s_const.num_reward_ops);
+    constexpr int kPass = 32;
+    T* const val = &s_rows[0][0][0];                                 // [n_rops][kPass]
+    uint8_t* const ev_bytes = reinterpret_cast<uint8_t*>(s_termlim);  // (the termination tables are dead)
+    const T* const my_traj = B.traj + (size_t)env * (size_t)B.steps * SOLO_STATE_STRIDE;
+    const bool want_reward = (B.flags & SOLO_STEP_REWARD) != 0;
+    const bool bookkeeping = want_reward && (B.flags & SOLO_STEP_DONE) != 0;
+    T* const obs_rec = A->obs_rec; T* const reward_rec = A->reward_rec;
+    T* const view_obs = A->view_obs; T* const view_reward = A->view_reward; uint8_t* const view_done = A->view_done;
+    const long long obs_stride = A->obs_rec_stride, reward_stride = A->reward_rec_stride;
+    const int obs_from = A->obs_from;
+    for (int base = 0; base < B.steps; base += kPass) {
+      const int k = base + lane1;
+      if (lane1 < kPass && k < B.steps) {
+        const T* rec = my_traj + (size_t)k * SOLO_STATE_STRIDE;
+        const bool last = k == B.steps - 1;
+        const int ev = (int)rec[SOLO_S_SPARE];
+        ev_bytes[lane1] = (uint8_t)ev;
+        if (B.flags & SOLO_STEP_DONE) {
+          if (B.done_stride != 0 || last) B.done[(size_t)k * B.done_stride + env] = (uint8_t)(ev & kEventDone);
+          if (view_done != nullptr && last) view_done[env] = (uint8_t)(ev & kEventDone);
+        }
+        T roll, pitch, yaw;
+        euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
+        if (B.flags & SOLO_STEP_OBS) {
+          T* o_rec = (obs_rec != nullptr && k >= obs_from) ? obs_rec + (size_t)k * obs_stride + (size_t)env * n_obs : nullptr;
+          T* o_view = (view_obs != nullptr && last) ? view_obs + (size_t)env * n_obs : nullptr;
+          if (o_rec != nullptr || o_view != nullptr)
+            for (int i = 0; i < n_obs; ++i) {
+              const T x = observation_value<T>(P0->obs[i], rec, roll, pitch, yaw);
+              if (o_rec != nullptr) o_rec[i] = x;
+              if (o_view != nullptr) o_view[i] = x;
+            }
+        }
+        if (want_reward) {
+          const T rv = eval_reward<T>(P0, rec, roll, pitch, val + lane1, kPass);
+          if (reward_rec != nullptr) reward_rec[(size_t)k * reward_stride + env] = rv;
+          if (view_reward != nullptr && last) view_reward[env] = rv;
+        }
+      }
+      wave_sync();
+      if (bookkeeping && lane1 == 0) {
+        const int cnt = B.steps - base < kPass ? B.steps - base : kPass;
+        accumulate_returns<T>(s_state, ev_bytes, 1, val + (size_t)(n_rops - 1) * kPass, 1, cnt, SOLO_STATS_ROW,
+                              [](double* p, double x) { stats_add(p, x); });
+      }
+      wave_sync();
+    }
+  }
   if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
   if ((B.flags & SOLO_STEP_PHYSICS) && lane1 == 0) { int32_t* cost = wave_cold_args(Bin)->cost; if (cost != nullptr) cost[env] = prio_sweeps - hist_sweeps; }
-  // (slots SOLO_S_RETURN.. of the record are the returns kernel's after a fused launch; a single-step
-  // launch that evaluated its reward in place keeps the accumulators itself)
-  const bool own_returns = kInlineOutputs<T, kFull> && B.reward_inline != nullptr && (B.flags & SOLO_STEP_DONE);
+  // (slots SOLO_S_RETURN.. of the record: the episodic accumulators, kept by whichever path evaluated the rewards)
+  const bool own_returns = (B.flags & SOLO_STEP_REWARD) && (B.flags & SOLO_STEP_DONE) &&
+                           (B.traj != nullptr || (kInlineOutputs<T, kFull> && B.reward_inline != nullptr));
   if (lane1 < (own_returns ? SOLO_S_SPARE : SOLO_S_RETURN)) wave_cold_args(Bin)->state[rec + lane1] = s_state[lane1];
   SOLO_STAMP(B, 14);
 #ifdef SOLO_STAMPS
   wave_sync();
   if (lane1 < 16) B.stamps[(size_t)env * 32 + 16 + lane1] = s_acc[lane1];
 #endif
-}
-
-// ---- output kernels: one THREAD per (step, robot) of a launch (see solo_outputs.h) -------------
-constexpr int kOutputThreads = 256;   // returns kernel
-constexpr int kObsStageMax = 32;      // observations of up to this many elements leave through LDS, coalesced
-
-// Observations (steps >= obs_from_step only), rewards, event bytes and done flags of `steps` x `count` robot-steps.
-// grid = (ceil(count / kThreads), <= steps): a block owns kThreads consecutive robots of ONE step at a time,
-// whose records are contiguous in traj [steps][num_envs][32] and whose observation rows are
-// contiguous in obs - both move through LDS with fully coalesced accesses (a thread reading its
-// own 128-B record / writing its own D-element row directly would touch 64 different lines per
-// instruction).  obs / reward: element (k, env) at k * stride + env (* num_obs).
-template <typename T, int kThreads>
-__global__ __launch_bounds__(kThreads) void solo_outputs_kernel(const KParams<T>* __restrict__ P, const T* __restrict__ traj,
-                                                                int steps, int num_envs, int env_base, int count,
-                                                                T* __restrict__ obs, long long obs_stride, int obs_from_step,
-                                                                T* __restrict__ reward, long long reward_stride,
-                                                                uint8_t* __restrict__ events, uint8_t* __restrict__ done, long long done_stride,
-                                                                T* __restrict__ view_obs, T* __restrict__ view_reward, uint8_t* __restrict__ view_done) {
-  __shared__ T s_rec[kThreads][SOLO_STATE_STRIDE + 1];        // (+1: conflict-free row access)
-  __shared__ T s_val[SOLO_MAX_REWARD_OPS][kThreads];           // reward program values, one column per thread
-  __shared__ T s_obs[kThreads][kObsStageMax + 1];
-  const int tid = threadIdx.x;
-  const int e0 = blockIdx.x * kThreads;                        // first robot of this block within the launch's slice
-  const int nb = count - e0 < kThreads ? count - e0 : kThreads;
-  const int n_obs = P->c.num_obs;
-  const bool staged = n_obs <= kObsStageMax;
-  const int env = env_base + e0 + tid;
-  // (a block walks several steps: few fat blocks instead of one small block per step)
-  for (int k = blockIdx.y; k < steps; k += gridDim.y) {
-    const T* src = traj + ((size_t)k * num_envs + env_base + e0) * SOLO_STATE_STRIDE;
-    for (int w = tid; w < nb * SOLO_STATE_STRIDE; w += kThreads) s_rec[w / SOLO_STATE_STRIDE][w % SOLO_STATE_STRIDE] = src[w];
-    block_sync();
-    const bool want_obs = obs != nullptr && k >= obs_from_step;
-    if (tid < nb) {
-      const T* rec = s_rec[tid];
-      // the step's event bits travel in slot 31 of its record: the events array of the returns kernel and
-      // the caller's done flags ([K][N], or the engine's view: the last step's) are written here, coalesced
-      const int ev = (int)rec[SOLO_S_SPARE];
-      events[(size_t)k * num_envs + env] = (uint8_t)ev;
-      if (done != nullptr && (done_stride != 0 || k == steps - 1)) done[(size_t)k * done_stride + env] = (uint8_t)(ev & kEventDone);
-      if (view_done != nullptr && k == steps - 1) view_done[env] = (uint8_t)(ev & kEventDone);
-      T roll, pitch, yaw;
-      euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
-      if (want_obs)
-        eval_observations<T>(P, rec, roll, pitch, yaw, staged ? &s_obs[tid][0] : obs + (size_t)k * obs_stride + (size_t)env * n_obs);
-      if (want_obs && !staged && view_obs != nullptr && k == steps - 1)   // (wide observations: the thread's own row, just written)
-        for (int j = 0; j < n_obs; ++j) view_obs[(size_t)env * n_obs + j] = obs[(size_t)k * obs_stride + (size_t)env * n_obs + j];
-      if (reward != nullptr) {
-        const T rv = eval_reward<T>(P, rec, roll, pitch, &s_val[0][tid], kThreads);
-        reward[(size_t)k * reward_stride + env] = rv;
-        if (view_reward != nullptr && k == steps - 1) view_reward[env] = rv;  // (a recorded rollout's last step: also the engine's view)
-      }
-    }
-    block_sync();
-    if (want_obs && staged) {
-      T* dst = obs + (size_t)k * obs_stride + (size_t)(env_base + e0) * n_obs;  // nb rows of n_obs, contiguous
-      int row = tid / n_obs, col = tid % n_obs;
-      const int drow = kThreads / n_obs, dcol = kThreads % n_obs;
-      T* vdst = (view_obs != nullptr && k == steps - 1) ? view_obs + (size_t)(env_base + e0) * n_obs : nullptr;
-      for (int w = tid; w < nb * n_obs; w += kThreads) {
-        const T x = s_obs[row][col];
-        dst[w] = x;
-        if (vdst != nullptr) vdst[w] = x;
-        row += drow; col += dcol;
-        if (col >= n_obs) { col -= n_obs; row += 1; }
-      }
-    }
-  }
-}
-
-// episodic return / length accumulators and episode statistics of a multi-step launch: one thread
-// per robot, a scan over the launch's steps (rewards.py has no counterpart: bookkeeping an RL loop
-// does in Python).  Consecutive threads = consecutive robots: every load is coalesced.
-template <typename T>
-__global__ __launch_bounds__(kOutputThreads) void solo_returns_kernel(T* __restrict__ state, const uint8_t* __restrict__ events, int steps,
-                                                                      int num_envs, int env_base, int count,
-                                                                      const T* __restrict__ reward, long long reward_stride,
-                                                                      double* __restrict__ stats, T* __restrict__ view_reward) {
-  const int e = blockIdx.x * kOutputThreads + threadIdx.x;
-  if (e >= count) return;
-  const int env = env_base + e;
-  // (a rollout that does not record keeps its last step's reward in the engine's view)
-  if (view_reward != nullptr) view_reward[env] = reward[(size_t)(steps - 1) * reward_stride + env];
-  // sharded: all robots of a batch finish their episodes in the same step, and same-address
-  // atomics serialise
-  accumulate_returns<T>(state + (size_t)env * SOLO_STATE_STRIDE, events + env, num_envs, reward + env, reward_stride, steps,
-                        stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH, [](double* p, double x) { stats_add(p, x); });
 }
 
 // setJointMotorControlArray without a step (solo8v2vanilla.py:87-90)

@@ -21,8 +21,12 @@ __device__ __forceinline__ void group_sync() { __syncthreads(); }
 #else
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 #endif
-// barrier of a multi-wave block (the output kernels)
-__device__ __forceinline__ void block_sync() { __syncthreads(); }
+// orders this wave's global stores before its later global loads of the same lines by OTHER lanes of the wave
+// (the output epilogue re-reads the step records): release + acquire at workgroup scope = the waits, no cache operation
+__device__ __forceinline__ void wave_fence_global() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // wave-uniform pointer made opaque to the optimiser (no instruction): loads through the result
 // are not hoisted above this point
 template <typename P> __device__ __forceinline__ P* wave_opaque(P* p) {

@@ -60,7 +60,6 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   std::vector<T> par = conv(params, (size_t)n * 4);
   std::vector<T> ob((size_t)steps * n * (D > 0 ? D : 1)), rew((size_t)steps * n);
   std::vector<T> traj((size_t)steps * n * SOLO_STATE_STRIDE);
-  std::vector<uint8_t> events((size_t)steps * n);
   std::vector<T> terr;
   if (terrain) {
     terr = conv(terrain->heights, (size_t)terrain->nx * terrain->ny);
@@ -73,39 +72,24 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   B.order = nullptr; B.cost = nullptr;
   B.state = st.data(); B.snapshot = snap.data(); B.targets = tg.data();
   B.actions = actions ? act.data() : nullptr; B.params = par.data();
-  // as Engine::launch_chain: a single-step launch evaluates its outputs inside the step kernel
+  // as Engine::launch_chain: a single-step f32 launch evaluates its outputs lane-parallel over the items of the
+  // step; every other launch leaves records and evaluates them in its output epilogue (lane = step), recording
+  // every step into the caller's [steps][n][.] buffers
   const bool inline_outputs = steps == 1 && (want_obs || want_reward) && kInlineOutputs<T, true>;
   B.traj = (!inline_outputs && (want_obs || want_reward)) ? traj.data() : nullptr;
-  B.events = events.data();
   B.obs_inline = (inline_outputs && want_obs) ? ob.data() : nullptr;
   B.reward_inline = (inline_outputs && want_reward) ? rew.data() : nullptr;
+  B.obs_rec = (!inline_outputs && want_obs) ? ob.data() : nullptr;
+  B.reward_rec = (!inline_outputs && want_reward) ? rew.data() : nullptr;
+  B.obs_rec_stride = (long long)n * D; B.reward_rec_stride = n; B.obs_from = 0;
+  B.view_obs = B.view_reward = nullptr; B.view_done = nullptr;
   B.done = done; B.term_count = term_count; B.stats = stats;
   B.num_envs = n; B.flags = flags; B.env_base = 0; B.steps = steps;
   B.action_stride = (long long)n * SOLO_NUM_JOINTS; B.done_stride = n;
   const KParams<T>* Pp = &P;
-  // the step kernel: one emulated wavefront per robot (as Engine::launch_chain launches it) ...
+  // the step kernel, output epilogue included: one emulated wavefront per robot (as Engine::launch_chain launches it)
   for (int b = 0; b < n; ++b)
     WaveEmu::get().run_block(b, n, [&]() { solo_step_kernel<T, true>(Pp, B); });
-  // ... then the output "kernels": the same per-item functions, in plain loops
-  if (!inline_outputs && (want_obs || want_reward)) {
-    for (int k = 0; k < steps; ++k)
-      for (int e = 0; e < n; ++e) {
-        const T* rec = traj.data() + ((size_t)k * n + e) * SOLO_STATE_STRIDE;
-        // (as solo_outputs_kernel: the step's event bits travel in slot 31 of its record)
-        const int ev = (int)rec[SOLO_S_SPARE];
-        events[(size_t)k * n + e] = (uint8_t)ev;
-        if ((flags & SOLO_STEP_DONE) && done) done[(size_t)k * n + e] = (uint8_t)(ev & kEventDone);
-        T roll, pitch, yaw, val[SOLO_MAX_REWARD_OPS];
-        euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
-        if (want_obs) eval_observations<T>(Pp, rec, roll, pitch, yaw, ob.data() + ((size_t)k * n + e) * D);
-        if (want_reward) rew[(size_t)k * n + e] = eval_reward<T>(Pp, rec, roll, pitch, val, 1);
-      }
-    if (want_reward && (flags & SOLO_STEP_DONE))
-      for (int e = 0; e < n; ++e)
-        accumulate_returns<T>(st.data() + (size_t)e * SOLO_STATE_STRIDE, events.data() + e, n, rew.data() + e, n, steps,
-                              stats + (size_t)(e % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH,
-                              [](double* p, double x) { *p += x; });
-  }
   for (size_t i = 0; i < st.size(); ++i) state[i] = (double)st[i];
   for (size_t i = 0; i < tg.size(); ++i) targets[i] = (double)tg[i];
   if (flags & SOLO_STEP_OBS) for (size_t i = 0; i < (size_t)steps * n * D; ++i) obs[i] = (double)ob[i];

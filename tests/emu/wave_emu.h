@@ -128,7 +128,7 @@ inline void wave_set_priority_level(int) {}
 template <typename B> using ColdArgs = const B*;
 template <typename B> inline ColdArgs<B> wave_cold_args(const B& by_value) { return &by_value; }
 inline int wave_slot_id() { return 0; }
-inline void block_sync() {}  // (the thread-per-item output kernels are not emulated: their per-item functions run in loops)
+inline void wave_fence_global() {}  // (one emulated wave runs its lanes as fibres over plain memory)
 template <typename T> struct RowDot {
   T g[6], h[2];
   void set(const T* gh, const T* hh) { for (int i = 0; i < 6; ++i) g[i] = gh[i]; h[0] = hh[0]; h[1] = hh[1]; }

@@ -1,32 +1,41 @@
-"""DIAGNOSTIC: host-call / device segments of the driver's 20-step rollout (K = 20, one fused launch per
-slice) in a tight repeat loop, for 1 / 2 / 4 stream slices."""
-import sys, os, time
+"""MEASUREMENT: what a K = 20 timed repeat of bench.py is made of besides the step kernel - host launch, the
+statistics reduction, and the host's wake-up from the device synchronisation that the bench contract puts on both
+sides of every repeat.  usage: gpu_k20_segments.py [float32|float64]"""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch, numpy as np
-from bench import build_env
+import numpy as np, torch
 from gym_solo_amd import abi
-n=4096
-for k,spl,streams in ((20,20,2),(20,20,1),(20,20,4)):
-  env=build_env(n,0,'float32',steps_per_launch=spl,rollout_streams=streams); eng=env.engine
-  g=torch.Generator(device='cuda').manual_seed(1234)
-  acts=(torch.rand(k,n,12,device='cuda',generator=g)*2-1)*6.283
-  out=eng.rollout_buffers(k)
-  eng.rollout(acts[:5], abi.STEP_ALL)
-  torch.cuda.synchronize()
-  res=[]
-  for rep in range(12):
-    sb=eng.stats.clone(); torch.cuda.synchronize()
-    t0=time.perf_counter()
-    eng.rollout(acts, abi.STEP_ALL, out=out)
-    t1=time.perf_counter()
-    torch.cuda.synchronize()
-    t2=time.perf_counter()
-    st=(eng.stats-sb).clone()
-    t3=time.perf_counter()
-    torch.cuda.synchronize()
-    t4=time.perf_counter()
-    res.append(((t1-t0)*1e3,(t2-t0)*1e3,(t3-t2)*1e3,(t4-t2)*1e3))
-  r=np.array(res)
-  print('K=%d S=%d streams=%d: median ms: rollout host call %.3f ; rollout to sync %.3f ; stats host %.3f ; stats to sync %.3f ; => %.3g env-steps/s'%(k,spl,streams,*np.median(r,axis=0), n*k/(np.median(r[:,1])+np.median(r[:,3]))*1e3))
-  env._close()
+from bench import build_env, desynchronise_episodes
+dtype = (sys.argv[1:] or ['float32'])[0]
+tdt = torch.float32 if dtype == 'float32' else torch.float64
+n, k = 4096, 20
+env = build_env(n, 0, dtype, steps_per_launch=k, rollout_streams=1)
+eng = env.engine
+g = torch.Generator(device='cuda').manual_seed(1234)
+desynchronise_episodes(eng, g)
+pool = (torch.rand(40 * k, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
+out = eng.rollout_buffers(k)
+def med(f, reps=40):
+  ts = []
+  for r in range(reps):
+    ts.append(f(r))
+  return 1e6 * float(np.median(ts))
+def sync(): torch.cuda.synchronize()
+def t_rollout_sync(r):
+  a = pool[(r % 40) * k:(r % 40 + 1) * k]; sync(); t0 = time.perf_counter(); eng.rollout(a, abi.STEP_ALL, out=out); sync(); return time.perf_counter() - t0
+def t_rollout_stats_sync(r):
+  a = pool[(r % 40) * k:(r % 40 + 1) * k]; sync(); t0 = time.perf_counter(); eng.rollout(a, abi.STEP_ALL, out=out); s = eng.stats_shards.sum(dim=0); sync(); return time.perf_counter() - t0
+def t_events(r):
+  a = pool[(r % 40) * k:(r % 40 + 1) * k]; e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); sync()
+  e0.record(); eng.rollout(a, abi.STEP_ALL, out=out); e1.record(); sync(); return e0.elapsed_time(e1) * 1e-3
+def t_empty_sync(r):
+  sync(); t0 = time.perf_counter(); sync(); return time.perf_counter() - t0
+x = torch.zeros(64, device='cuda')
+def t_tiny_kernel_sync(r):
+  sync(); t0 = time.perf_counter(); x.add_(1.0); sync(); return time.perf_counter() - t0
+def t_launch_only(r):
+  a = pool[(r % 40) * k:(r % 40 + 1) * k]; sync(); t0 = time.perf_counter(); eng.rollout(a, abi.STEP_ALL, out=out); t = time.perf_counter() - t0; sync(); return t
+for f in (t_rollout_sync, t_rollout_sync, t_rollout_stats_sync, t_events, t_empty_sync, t_tiny_kernel_sync, t_launch_only):
+  print('%-24s %8.1f us (median of 40)' % (f.__name__, med(f)), flush=True)
+print('step kernel alone (HIP events inside the engine): %.1f us' % (1e3 * np.median([eng.time_step(pool[:k], abi.STEP_ALL) for _ in range(5)])))
