@@ -5,17 +5,17 @@
 // latency; the reductions of the reference's factories
 //   ObservationFactory.get_obs   gym_solo/core/obs.py:130-159 (TorsoIMU :268-279, MotorEncoder :354-362)
 //   RewardFactory.get_reward     gym_solo/core/rewards.py:104-118 (+ the reward classes :121-373)
-// are pure functions of one robot's state after a step.  Evaluated inside the robot's wave they
-// were another ~25 % of serial latency per step (measured); evaluated here, one THREAD per
-// (step, robot) over a whole fused launch (hundreds of thousands of independent items), they are
-// throughput work that disappears next to the physics.  The functions below are plain per-item
-// code (no wave operations): the HIP kernels in solo_step_kernel.h call them per thread, the CPU
-// emulator harness (tests/emu) calls them in a loop.
+// are pure functions of one robot's state after a step.  Evaluated inside every step of the robot's wave
+// (lane = item) they were another ~25 % of serial latency per step (measured); a fused launch therefore
+// leaves one record per robot-step and evaluates them AFTER its last step, one item per LANE (lane =
+// step: the output epilogue of the step kernel; rounds 1-2: separate kernels, one item per thread).  The
+// functions below are plain per-item code (no wave operations): the step kernel's epilogue calls them per
+// lane, its single-step f32 path per item, and the CPU emulator (tests/emu) runs both.
 //
 // What the step kernel leaves behind per robot-step:
-//   traj   [steps][N][SOLO_STATE_STRIDE] reals: [0..28] the state after the step (before an
-//          auto-reset restores the snapshot), SOLO_S_* offsets
-//   events [steps][N] bytes: 1 = done, 2 = restarted from the snapshot
+//   traj   [N][steps][SOLO_STATE_STRIDE] reals: [0..28] the state after the step (before an
+//          auto-reset restores the snapshot), SOLO_S_* offsets; [31] the step's event bits:
+//          1 = done, 2 = restarted from the snapshot
 #pragma once
 
 #include "solo_kernel_params.h"

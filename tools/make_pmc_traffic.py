@@ -56,7 +56,7 @@ out = {key: {
   'effective_clock_hz': (s['GRBM_GUI_ACTIVE'] / 8.0 / (s['_duration_ns_under_pmc'] * 1e-9)) if s.get('GRBM_GUI_ACTIVE') else None,
   'step_kernel_ms_under_pmc_serialised': s.get('_duration_ns_under_pmc', 0) * 1e-6,
   'traffic_note': 'measured HBM bytes per env-step (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, '
-                  'KB x 1024, step + outputs + returns kernels of one fused launch of %d robots x %d steps) x this run\'s '
+                  'KB x 1024, every solo kernel of one fused launch of %d robots x %d steps - since round 3 the step kernel alone, its output epilogue included) x this run\'s '
                   'env-steps per launch; raw FETCH_SIZE (dword-per-lane loads: uncalibrated width; with the guide\'s 2x '
                   'correction for wide reads the total would be %.0f B/env-step); algorithmic figure of the whole path: %d '
                   'B/env-step (a fused launch neither re-reads nor re-writes the state record per step, and the returns '
