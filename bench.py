@@ -47,12 +47,13 @@ SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICR
 METRIC = 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X'
 
 
-def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1):
+def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1, residual_threshold=0.0):
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
   cfg = Solo8VanillaConfig()
   cfg.num_envs, cfg.device, cfg.dtype, cfg.auto_reset = num_envs, device, dtype, True
   cfg.steps_per_launch, cfg.rollout_streams = steps_per_launch, rollout_streams
+  cfg.solver_residual_threshold = residual_threshold
   env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
   register_benchmark_workload(env, max_steps=max_steps)
   env._ensure_program()
@@ -348,7 +349,7 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
-  def timed(dtype, k, closed_loop, min_seconds, max_repeats):
+  def timed(dtype, k, closed_loop, min_seconds, max_repeats, residual_threshold=0.0):
     """Repeats of the K-step timed region on a fresh engine; returns per-repeat seconds (max over
     ranks), the summed episodic statistics of the timed repeats and the engine."""
     tdtype = torch.float32 if dtype == 'float32' else torch.float64
@@ -356,7 +357,7 @@ def main():
     # chain is all there is to overlap: no stream slices)
     spl = 1 if closed_loop else max(1, min(args.steps_per_launch, k))
     streams = max(1, args.rollout_streams) if (k > spl and not closed_loop) else 1
-    env = build_env(n, local_rank, dtype, steps_per_launch=spl, rollout_streams=streams)
+    env = build_env(n, local_rank, dtype, steps_per_launch=spl, rollout_streams=streams, residual_threshold=residual_threshold)
     eng = env.engine
     gen = torch.Generator(device=dev).manual_seed(rank_seed(1234, rank))
 
@@ -449,6 +450,15 @@ def main():
       extra['roofline_f64'] = roofline('float64', g64, pool64, ke, spl64, streams64)[0]
       extra['episodes_f64'] = summarize(s64.cpu().numpy())
       e64._close()
+    # pybullet's documented default solverResidualThreshold (1e-7 [recalled]) as an OPT-IN: off in `value`
+    for key, dt_ in (('value_residual_1e-7', args.dtype),) + ((('value_f64_residual_1e-7', 'float64'),) if args.dtype == 'float32' else ()):
+      tr, _, _, er, _, _, _ = timed(dt_, ke, False, 0.3, 10, residual_threshold=1e-7)
+      extra[key] = world * n * ke / statistics.median(tr)
+      er._close()
+    extra['value_residual_note'] = ('the same rollout with SoloConfig.solver_residual_threshold = 1e-7 (pybullet\'s documented default; the '
+                                    'Gauss-Seidel iteration ends after a sweep whose largest squared velocity-level change is below it); NOT '
+                                    'the configuration of `value`: without warm starting it leaves a resting robot jittering at 5e-5 rad/s, '
+                                    'where the reference\'s recorded rest state has 1e-11')
     tcl, _, _, ecl, _, _, _ = timed(args.dtype, ke, True, 0.3, 10)
     extra['value_closed_loop'] = world * n * ke / statistics.median(tcl)
     extra['value_closed_loop_note'] = ('one solo_engine_step launch per env step (outputs evaluated in that launch), the '

@@ -7,7 +7,7 @@ as DATA (``SoloModel``/``SoloConfig``).
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_LEGS = 4
 NUM_DOF = 8
 NUM_JOINTS = 12
@@ -95,6 +95,7 @@ class SoloConfig(C.Structure):
     ('steps_per_launch', C.c_int32),
     ('rollout_streams', C.c_int32),
     ('solver_ulp_tolerance', C.c_int32),
+    ('solver_residual_threshold', C.c_double),
   ]
 
 

@@ -459,6 +459,7 @@ int check_config(const SoloConfig* c, std::string* err) {
   if (!(c->dt > 0)) return fail("dt must be positive");
   if (c->solver_iterations < 1 || c->solver_iterations > 10000) return fail("solver_iterations out of range");
   if (c->solver_ulp_tolerance < 0 || c->solver_ulp_tolerance > (1 << 20)) return fail("solver_ulp_tolerance out of range");
+  if (!(c->solver_residual_threshold >= 0)) return fail("solver_residual_threshold must be >= 0");
   if (c->settle_steps < 0 || c->settle_steps > 100000) return fail("settle_steps out of range");
   if (c->steps_per_launch < 0 || c->steps_per_launch > 100000) return fail("steps_per_launch out of range");
   if (c->restitution != 0.0) return fail("only restitution 0 is supported (gym_solo configs.py:23)");

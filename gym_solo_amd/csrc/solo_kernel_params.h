@@ -73,6 +73,7 @@ struct StepConst {
   T lin_damp, ang_damp;
   T erp_over_dt, margin;
   T limit_margin;  // SoloConfig::joint_limit_margin
+  T resid_thr;     // SoloConfig::solver_residual_threshold (squared velocity-level change; 0 = off)
   T action_scale;
   // heightfield ground (SoloTerrain): 1/cell, origin; grid size below; heights live in KBuffers::terrain
   T terr_inv_cell, terr_ox, terr_oy;
@@ -177,6 +178,7 @@ inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) 
   k->c.iterations = c.solver_iterations;
   k->c.auto_reset = c.auto_reset;
   k->c.ulp_tol = c.solver_ulp_tolerance;
+  k->c.resid_thr = (T)c.solver_residual_threshold;
   for (int j = 0; j < SOLO_NUM_JOINTS; ++j) k->c.settle_tgt[j] = (T)c.settle_targets[j];
   k->c.base_mass = (T)m.mass[0];
   for (int a = 0; a < 6; ++a) k->c.base_I[a] = (T)m.inertia[0][a];

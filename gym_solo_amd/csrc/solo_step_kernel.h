@@ -463,6 +463,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     hh[0] = hh[1] = T(0);
     inv_d = T(0);
     w = T(0);
+    diag = T(0);
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) s_rowvec[lane][i] = gh[i];
@@ -533,6 +534,13 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   T v = live ? w * nid : T(0);  // lam = 0
   const T tol_rel = T(wave_uniform(C.ulp_tol)) * R::half_ulp();
   const int iters = wave_uniform(C.iterations);  // scalar trip count
+  // pybullet's solverResidualThreshold ([recalled] default 1e-7; SoloConfig::solver_residual_threshold): the iteration
+  // ends after the first sweep in which max over the rows of (delta impulse x A_rr)^2 - the squared velocity-level
+  // change of the row, what [recalled] btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric returns - is
+  // <= the threshold.  A row is updated at most once per sweep, so its delta is lam - lam at the start of the sweep:
+  // ONE test per sweep for all 64 rows.  Threshold 0 (the host default): off - the iteration runs to its fixed point.
+  const T resid_thr = C.resid_thr;
+  const bool use_resid = wave_uniform((int)(resid_thr > T(0))) != 0;
   // rows of one sweep, in solver order ([recalled] btMultiBodyConstraintSolver::solveSingleIteration):
   // the non-contact rows (joint motors, joint limits), then ALL normal contact rows, then ALL friction rows
   constexpr unsigned long long kPhaseLanes[3] = {0xc003c003c003c003ull,    // motors k = 0, 1 and joint limits k = 14, 15, leg by leg
@@ -552,9 +560,13 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py)
   {
     int rows_updated = 0;
-    it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu,
-                          wave_ballot(type == ROW_TAN1), wave_ballot(is_tangent), kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2],
-                          iters, rows_updated);
+    const unsigned long long tan1_lanes = wave_ballot(type == ROW_TAN1), tangent_lanes = wave_ballot(is_tangent);
+    if (use_resid)   // (two copies of the loop: the default path carries no residual test)
+      it = pgs_solve_gfx950<true>(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes,
+                                  kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2], iters, rows_updated, diag, resid_thr);
+    else
+      it = pgs_solve_gfx950<false>(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes,
+                                   kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2], iters, rows_updated, diag, resid_thr);
 #ifdef SOLO_STAMPS
     n_changed = rows_updated;
 #endif
@@ -564,6 +576,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
     // (the register banks of the matrix are walked one after the other - static bank per loop - which
     // keeps the rows of a phase in ascending lane order)
+    const T lam_sweep_start = lamv;
     bool normals_moved = false;  // (wave-uniform)
 #pragma unroll
     for (int phase = 0; phase < 3; ++phase) {
@@ -603,6 +616,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
       }
     }
     SOLO_PGS_SWEEP_HOOK(it, pend, lamv, v);
+    const T dvel = (lamv - lam_sweep_start) * diag;
+    if (use_resid && wave_ballot(dvel * dvel > resid_thr) == 0ull) { ++it; break; }  // the residual threshold (see above)
   }
 #endif
 #ifdef SOLO_STAMPS

@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define SOLO_ABI_VERSION 2  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets */
+#define SOLO_ABI_VERSION 3  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets
+                               3: SoloConfig::solver_residual_threshold */
 
 /* ---- fixed Solo8 dimensions -------------------------------------------- */
 #define SOLO_NUM_LEGS 4
@@ -136,6 +137,14 @@ typedef struct SoloConfig {
                                 identical to always running solver_iterations sweeps); 2 (the host default)
                                 also stops last-bit limit cycles, which otherwise keep ~3% of the robots
                                 iterating to the cap.  Negative values are rejected. */
+  double solver_residual_threshold; /* pybullet's solverResidualThreshold ([recalled] documented default 1e-7, set in
+                                PhysicsServerCommandProcessor::createEmptyDynamicsWorld; the reference never changes it;
+                                the host default here is 0 = off - gym_solo_amd/core/configs.py says why):
+                                the iteration ends after the first sweep in which max over the rows of
+                                (delta impulse x A_rr)^2 - the squared velocity-level change, [recalled]
+                                btMultiBodyConstraintSolver::solveSingleIteration / resolveSingleConstraintRowGeneric
+                                returning deltaImpulse / jacDiagABInv - is <= this value.  0 = never (every sweep that
+                                still changes a row runs, up to solver_iterations).  Negative values are rejected. */
 } SoloConfig;
 
 /* ---- fused observation / reward / termination programs ------------------ */

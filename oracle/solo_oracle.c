@@ -570,7 +570,11 @@ int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, co
     for (int r = 0; r < R.n; ++r) if (R.sphere[r] < 0 && R.leg[r] == leg) order[no++] = r;
   for (int r = 0; r < R.n; ++r) if (R.sphere[r] >= 0 && R.normal_row[r] < 0) order[no++] = r;
   for (int r = 0; r < R.n; ++r) if (R.sphere[r] >= 0 && R.normal_row[r] >= 0) order[no++] = r;
-  for (int it = 0; it < cfg->solver_iterations; ++it)
+  /* pybullet's solverResidualThreshold ([recalled] btMultiBodyConstraintSolver: leastSquaredResidual = max over the
+   * rows of (deltaImpulse / jacDiagABInv)^2 = (delta impulse x A_rr)^2; the iteration ends after the first sweep in
+   * which it is <= the threshold; 0 = run every sweep) */
+  for (int it = 0; it < cfg->solver_iterations; ++it) {
+    double residual = 0;
     for (int o = 0; o < no; ++o) {
       const int r = order[o];
       double rel = 0;
@@ -583,7 +587,11 @@ int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, co
       double dl = nl - lam[r];
       lam[r] = nl;
       for (int i = 0; i < NV; ++i) up[i] += B[r][i] * dl;
+      const double dv = dl * diag[r];
+      if (dv * dv > residual) residual = dv * dv;
     }
+    if (cfg->solver_residual_threshold > 0 && residual <= cfg->solver_residual_threshold) break;  /* (0 = off) */
+  }
   /* back to world-frame velocities, integrate positions (semi-implicit Euler) */
   double ww[3], vw[3];
   m3v(k.Rwb[0], up, ww);

@@ -31,6 +31,14 @@ extern "C" int solo_emu_trace(double* lam, double* v, unsigned long long* pend) 
 
 using namespace solo;
 
+// Gauss-Seidel sweeps each robot ran in the last emulated launch (view.cost of the engine)
+static std::vector<int32_t> g_last_cost;
+extern "C" int solo_emu_last_cost(int32_t* out, int n) {
+  const int m = (int)g_last_cost.size() < n ? (int)g_last_cost.size() : n;
+  for (int i = 0; i < m; ++i) out[i] = g_last_cost[i];
+  return m;
+}
+
 // steps > 1: one fused multi-step "launch" per robot (actions [steps][n][12], outputs [steps][n][.])
 template <typename T>
 static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* prog, int n,
@@ -69,7 +77,8 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   const bool want_obs = (flags & SOLO_STEP_OBS) != 0, want_reward = (flags & SOLO_STEP_REWARD) != 0;
   KBuffers<T> B;
   B.terrain = terrain ? terr.data() : nullptr;
-  B.order = nullptr; B.cost = nullptr;
+  g_last_cost.assign((size_t)n, 0);
+  B.order = nullptr; B.cost = g_last_cost.data();
   B.state = st.data(); B.snapshot = snap.data(); B.targets = tg.data();
   B.actions = actions ? act.data() : nullptr; B.params = par.data();
   // as Engine::launch_chain: a single-step f32 launch evaluates its outputs lane-parallel over the items of the

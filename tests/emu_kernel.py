@@ -29,6 +29,8 @@ def load(variant=''):
   lib.solo_emu_rollout.argtypes = [C.POINTER(abi.SoloConfig), C.POINTER(abi.SoloModel), C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_void_p,
                                    C.c_void_p, dp, C.c_uint32, C.c_void_p]
+  lib.solo_emu_last_cost.restype = C.c_int
+  lib.solo_emu_last_cost.argtypes = [C.c_void_p, C.c_int]
   return lib
 
 
@@ -77,6 +79,13 @@ class EmuEngine:
       C.byref(self.terrain) if getattr(self, 'terrain', None) is not None else None)
     if rc:
       raise RuntimeError('emu step failed: %d' % rc)
+
+  @property
+  def cost(self):
+    """Gauss-Seidel sweeps each robot ran in the last launch (the engine's view.cost)."""
+    out = np.zeros(self.n, dtype=np.int32)
+    self.lib.solo_emu_last_cost(out.ctypes.data, self.n)
+    return out
 
   def rollout(self, actions, flags=abi.STEP_ALL):
     """One fused multi-step launch: actions [K, N, 12] -> (obs [K,N,D], reward [K,N], done [K,N])."""

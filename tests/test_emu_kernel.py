@@ -194,12 +194,15 @@ def test_all_sixteen_spheres_in_contact():
   assert max(contacts) == 16
 
 
+@pytest.mark.parametrize('resid,on_limit', [(0.0, 1e-9), (1e-7, 1e-6)])
 @pytest.mark.parametrize('dtype,tol', [('float64', 1e-10), ('float32', 2e-3)])
-def test_joint_limit_rows_match_oracle(dtype, tol):
+def test_joint_limit_rows_match_oracle(dtype, tol, resid, on_limit):
   """URDF joint limits as unilateral rows on lanes k = 14, 15 ([recalled]
-  btMultiBodyJointLimitConstraint): joints driven into +-10 rad stop there, emulator == oracle."""
+  btMultiBodyJointLimitConstraint): joints driven into +-10 rad stop there, emulator == oracle.  Solved to the
+  fixed point (solver_residual_threshold 0) the joints sit ON the limit to 1e-9 rad; with pybullet's default
+  residual threshold (1e-7: a velocity residual of up to 3.2e-4 rad/s per row is accepted) to 1e-6."""
   from helpers import joint_limit_case
-  ca, ma = make_abi(dtype)
+  ca, ma = make_abi(dtype, solver_residual_threshold=resid)
   ph = so.OraclePhysics(ca, ma)
   st, tg = joint_limit_case(ph, n=3)
   e = EmuEngine(ca, ma, 3)
@@ -208,7 +211,36 @@ def test_joint_limit_rows_match_oracle(dtype, tol):
   for k in range(25):
     ph.step(st, tg)
     e.step(tg, abi.STEP_PHYSICS)
-    assert np.abs(st[:, abi.S_Q:abi.S_Q + 8]).max() <= 10.0 + 1e-9
-    hit |= (np.abs(st[:, abi.S_Q:abi.S_Q + 8]) > 10.0 - 1e-9).any(axis=1)
+    assert np.abs(st[:, abi.S_Q:abi.S_Q + 8]).max() <= 10.0 + on_limit
+    hit |= (np.abs(st[:, abi.S_Q:abi.S_Q + 8]) > 10.0 - on_limit).any(axis=1)
   assert hit.all()   # every robot has a joint sitting ON its limit
   np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize('dtype,tol', [('float64', 1e-10), ('float32', 2e-3)])
+def test_residual_threshold_exit_matches_oracle(dtype, tol):
+  """pybullet's solverResidualThreshold (SoloConfig::solver_residual_threshold, off by default): with 1e-7 the
+  iteration ends after the first sweep whose largest squared velocity-level change (delta impulse x A_rr)^2 is below
+  it - emulated kernel == oracle on contact-rich random steps, far fewer sweeps than the fixed-point iteration, and a
+  result within the residual of it; a huge threshold is exactly ONE sweep."""
+  n = 6
+  rng = np.random.default_rng(12)
+  acts = [random_actions(rng, n) for _ in range(12)]
+  out = {}
+  for thr in (0.0, 1e-7, 1e9):
+    ca, ma = make_abi(dtype, settle_steps=0, solver_residual_threshold=thr)
+    ph = so.OraclePhysics(ca, ma)
+    e = EmuEngine(ca, ma, n)
+    ca_settle, _ = make_abi('float64')
+    st = np.tile(so.OraclePhysics(ca_settle, ma).settle(1), (n, 1))   # at rest on the ground: knees, feet, belly in contact
+    e.state[:] = st
+    sweeps = 0
+    for a in acts:
+      ph.step(st, a)
+      e.step(a, abi.STEP_PHYSICS)
+      sweeps += int(e.cost.sum())
+    np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=tol, err_msg='threshold %g' % thr)
+    out[thr] = (e.state.copy(), sweeps)
+  assert out[1e9][1] == n * len(acts)              # one sweep per robot-step
+  assert out[1e-7][1] < 0.6 * out[0.0][1]          # far fewer sweeps than the fixed-point iteration ...
+  assert np.abs(out[1e-7][0][:, :29] - out[0.0][0][:, :29]).max() < 5e-2   # ... for a nearby result

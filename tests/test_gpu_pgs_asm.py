@@ -37,8 +37,9 @@ if case == 'flail':      # the bench workload: random targets, robots tumbling o
   res = dict(state=eng.state.cpu().numpy(), cost=eng.cost.cpu().numpy(),
              reward=o[1].cpu().numpy(), done=o[2].cpu().numpy(), obs=o[0].cpu().numpy())
 else:                     # few sweeps allowed / exact tolerance / one sweep: the loop's exits
-  iters, tol = {'cap3': (3, 2), 'exact': (50, 0), 'one': (1, 2)}[case]
-  ca, ma = make_abi(dtype, solver_iterations=iters, solver_ulp_tolerance=tol, settle_steps=100)
+  # ('resid': pybullet's solverResidualThreshold 1e-7 - the copy of the loop with the residual test at the end of a sweep)
+  iters, tol, resid = {'cap3': (3, 2, 0.0), 'exact': (50, 0, 0.0), 'one': (1, 2, 0.0), 'resid': (50, 2, 1e-7), 'resid_cap': (4, 2, 1e-9)}[case]
+  ca, ma = make_abi(dtype, solver_iterations=iters, solver_ulp_tolerance=tol, settle_steps=100, solver_residual_threshold=resid)
   eng = Engine(ca, ma, 256)
   rng = np.random.default_rng(5)
   acts = torch.as_tensor(rng.uniform(-6, 6, (120, 256, 12)), device='cuda', dtype=tdt)
@@ -58,7 +59,7 @@ def _run(lib, case, dtype, tmp_path):
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
-@pytest.mark.parametrize('case', ['flail', 'cap3', 'exact', 'one'])
+@pytest.mark.parametrize('case', ['flail', 'cap3', 'exact', 'one', 'resid', 'resid_cap'])
 def test_assembly_loop_equals_cpp_loop_bit_for_bit(case, dtype, tmp_path):
   asm_lib, cpp_lib = os.path.join(CSRC, 'libsolo_hip.so'), os.path.join(CSRC, 'libsolo_hip_pgs_cpp.so')
   assert os.path.isfile(cpp_lib), 'build it: make -C gym_solo_amd/csrc test-libs (or __graft_entry__.build())'

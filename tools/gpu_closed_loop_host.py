@@ -11,21 +11,31 @@ env = build_env(n, 0, 'float32', steps_per_launch=1, rollout_streams=1)
 eng = env.engine
 g = torch.Generator(device='cuda').manual_seed(1234)
 acts = (torch.rand(k, n, 12, device='cuda', generator=g) * 2 - 1) * (2 * np.pi)
-for i in range(100):
-  eng.step(acts[i], abi.STEP_ALL)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(k):
-  eng.step(acts[i], abi.STEP_ALL)
-t1 = time.perf_counter()            # every launch is enqueued
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print('closed loop, %d steps: host enqueue %.1f us/step, device-bound total %.1f us/step -> %.3g env-steps/s' % (
-  k, (t1 - t0) / k * 1e6, (t2 - t0) / k * 1e6, n * k / (t2 - t0)))
-# Solo8VanillaEnv.step (the reference's API; zero-copy outputs)
-t0 = time.perf_counter()
-for i in range(k):
-  env.step(acts[i])
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print('Solo8VanillaEnv.step: %.1f us/step -> %.3g env-steps/s' % ((t2 - t0) / k * 1e6, n * k / (t2 - t0)))
+from bench import desynchronise_episodes
+desynchronise_episodes(eng, g)     # steady state first: the cost of a step depends on the episode phase
+def raw():
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(k):
+    eng.step(acts[i], abi.STEP_ALL)
+  t1 = time.perf_counter()            # every launch is enqueued
+  torch.cuda.synchronize()
+  t2 = time.perf_counter()
+  print('raw solo_engine_step, %d steps: host enqueue %.1f us/step, device-bound total %.1f us/step -> %.4g env-steps/s' % (
+    k, (t1 - t0) / k * 1e6, (t2 - t0) / k * 1e6, n * k / (t2 - t0)), flush=True)
+def api():
+  # Solo8VanillaEnv.step (the reference's API; zero-copy outputs)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(k):
+    env.step(acts[i])
+  t1 = time.perf_counter()
+  torch.cuda.synchronize()
+  t2 = time.perf_counter()
+  print('Solo8VanillaEnv.step,  %d steps: host enqueue %.1f us/step, device-bound total %.1f us/step -> %.4g env-steps/s' % (
+    k, (t1 - t0) / k * 1e6, (t2 - t0) / k * 1e6, n * k / (t2 - t0)), flush=True)
+# alternating, on the same steady-state workload (round 2 ran the two one after the other on a drifting one and
+# read the drift as API overhead)
+for rep in range(3):
+  raw()
+  api()
