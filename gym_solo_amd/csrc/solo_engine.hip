@@ -265,10 +265,15 @@ struct Engine final : EngineBase {
       // instantiation: no termination code, and a separate name in profiles
       constexpr int kG = solo::kRobotsPerGroup;  // (1; 8 in the EXPERIMENT build `make group8`)
       if (count % kG != 0) { err = "this build steps whole groups of robots"; return SOLO_ERR_INVALID_ARG; }
-      if (flags == SOLO_STEP_PHYSICS)
-        hipLaunchKernelGGL((solo::solo_step_kernel<T, false>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
-      else
-        hipLaunchKernelGGL((solo::solo_step_kernel<T, true>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
+      // (pybullet's residual threshold, an opt-in, is a kernel instantiation of its own: the default kernels carry none of it)
+      const bool resid = cfg.solver_residual_threshold > 0;
+      if (flags == SOLO_STEP_PHYSICS) {
+        if (resid) hipLaunchKernelGGL((solo::solo_step_kernel<T, false, true>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
+        else hipLaunchKernelGGL((solo::solo_step_kernel<T, false, false>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
+      } else {
+        if (resid) hipLaunchKernelGGL((solo::solo_step_kernel<T, true, true>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
+        else hipLaunchKernelGGL((solo::solo_step_kernel<T, true, false>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
+      }
       HIP_TRY(hipGetLastError());
     }
     return SOLO_OK;
@@ -449,7 +454,11 @@ struct Engine final : EngineBase {
     return SOLO_OK;
   }
 
-  const char* kernel_name() override { return sizeof(T) == 4 ? "solo_step_kernel<float, true>" : "solo_step_kernel<double, true>"; }
+  const char* kernel_name() override {
+    const bool resid = cfg.solver_residual_threshold > 0;
+    if (sizeof(T) == 4) return resid ? "solo_step_kernel<float, true, true>" : "solo_step_kernel<float, true, false>";
+    return resid ? "solo_step_kernel<double, true, true>" : "solo_step_kernel<double, true, false>";
+  }
 };
 
 int check_config(const SoloConfig* c, std::string* err) {

@@ -20,7 +20,7 @@
 //  * 15 instructions per updated row (compiler: 17): the column is not fetched into a register - the
 //    FMA reads it register-indexed as its source 0 - and the rows beyond the cursor are the phase's
 //    lanes above it (no window register to carry);
-//  * 16 instructions per sweep besides them, + 7 for the residual test of round 3 (compiler: ~70: flag registers for "a normal row moved",
+//  * 16 instructions per sweep besides them (compiler: ~70: flag registers for "a normal row moved",
 //    mask halves moved about, 64-bit compares after instructions that had already set SCC, the
 //    friction-limit refresh in 12 instructions instead of 8 with the DPP shifts folded into the
 //    multiplies), with no "anything pending?" test in the loop.  The slowest robot of a closed-loop
@@ -93,98 +93,73 @@ namespace solo {
 // to `done` when all three fail - a sweep that finds work in a phase continues on the other path (b1, b2),
 // which ends in the counter.  One instruction per sweep is one per cent of a closed-loop step: the
 // slowest robot of a step runs all 50 sweeps with three rows moving in each.
-// kResid: the copy with pybullet's solverResidualThreshold test at the end of every sweep (+1 instruction at its
-// top, +7 at its end); the default configuration (threshold 0) runs the copy without it.
-// The asm statement of the f32 loop, as a macro of its three varying pieces (the padding in front of the loops, the first
-// instruction of a sweep, the end of a sweep).  The loops sit at a FIXED position relative to the 64-byte instruction lines
-// (the padding is jumped over): a loop whose head lies 0..4 dwords past a 32-byte boundary takes 120 cycles per iteration,
-// 5..7 dwords past it 128..132 (tools/microbench/loop_align.hip: instructions are fetched in 32-byte blocks, and a taken
-// branch into the tail of a block gets little from its first fetch).  From the entry the row loops of the paths a slow
-// robot takes start 0, 4 and 1 dwords past a boundary (p0, q1, p2; p1: 6).  Sixteen entry positions measured on the closed
-// loop: 1.10 ... 1.15e8 env-steps/s - without the pinning, every edit of the code in front of the loop moved all timings.
-// Sweep structure: the non-contact rows (joint motors, joint limits) leg by leg, all normal rows and then the friction
-// limits, all friction rows; a sweep that has found no work so far continues on the a-labels, whose phase tests lead to
-// `done` when all three fail.
-#ifdef SOLO_STAMPS
-#define SOLO_PGS_NCH_OPERAND , [nch] "+s"(n_changed)
-#else
-#define SOLO_PGS_NCH_OPERAND
-#endif
-#define SOLO_PGS_F32_ASM(FILL, SWEEP_TOP, SWEEP_END) \
-  asm volatile( \
-      "s_branch .Lpgs_%=_entry\n\t" \
-      ".p2align 6\n\t" \
-      FILL \
-      ".Lpgs_%=_entry:\n\t" \
-      "s_sub_u32 %[it], 0, %[iters]\n\t" \
-      "s_cbranch_scc0 .Lpgs_%=_done\n" \
-      ".Lpgs_%=_sweep:\n\t" \
-      SWEEP_TOP \
-      "s_and_b64 %[todo], %[pend], %[ph0]\n\t" \
-      "s_cbranch_scc0 .Lpgs_%=_a1\n" \
-      SOLO_PGS_WALK("p0", "%[ph0]") \
-      "s_and_b64 %[todo], %[pend], %[ph1]\n\t" \
-      "s_cbranch_scc0 .Lpgs_%=_b2\n" \
-      SOLO_PGS_WALK("p1", "%[ph1]") \
-      SOLO_PGS_LIMITS \
-      "s_branch .Lpgs_%=_b2\n" \
-      ".Lpgs_%=_a1:\n\t" \
-      "s_and_b64 %[todo], %[pend], %[ph1]\n\t" \
-      "s_cbranch_scc0 .Lpgs_%=_a2\n" \
-      SOLO_PGS_WALK("q1", "%[ph1]") \
-      SOLO_PGS_LIMITS \
-      ".Lpgs_%=_b2:\n\t" \
-      "s_and_b64 %[todo], %[pend], %[ph2]\n\t" \
-      "s_cbranch_scc0 .Lpgs_%=_next\n" \
-      ".Lpgs_%=_p2:\n" \
-      SOLO_PGS_WALK("p2", "%[ph2]") \
-      ".Lpgs_%=_next:\n\t" \
-      SWEEP_END \
-      ".Lpgs_%=_a2:\n\t" \
-      "s_and_b64 %[todo], %[pend], %[ph2]\n\t" \
-      "s_cbranch_scc1 .Lpgs_%=_p2\n" \
-      ".Lpgs_%=_done:\n\t" \
-      : [v] "+v"(v), [lam] "+v"(lam), [cand] "+v"(cand), [dl] "+v"(dl), [lo] "+v"(lo), [hi] "+v"(hi), [pend] "+s"(pend), \
-        [thr] "=&v"(thr), [x1] "=&v"(x1), [x2] "=&v"(x2), [lam0] "=&v"(lam0), \
-        [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [sd] "=&s"(sd), [it] "=&s"(it) \
-        SOLO_PGS_NCH_OPERAND \
-      : [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2), \
-        [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes), [diag] "v"(diag), [rthr] "v"(resid_thr), "{v[64:95]}"(A.a0), "{v[96:127]}"(A.a1) \
-      : "vcc", "scc");
-
-template <bool kResid>
 __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, float& v, float& lam, float& cand, float& dl,
                                                 unsigned long long& pend, float& lo, float& hi, float tol, int lane, float mu,
                                                 unsigned long long tan1_lanes, unsigned long long tangent_lanes,
                                                 unsigned long long phase0, unsigned long long phase1, unsigned long long phase2,
-                                                int iters, int& n_changed, float diag, float resid_thr) {
-  float thr, x1, x2, lam0;
+                                                int iters, int& n_changed) {
+  float thr, x1, x2;
   unsigned long long w, t, todo;
   int rs, sd, it;
-  // (the loops sit at a FIXED position relative to the 64-byte instruction lines - see SOLO_PGS_F32_ASM; the copy with the
-  // residual test has one instruction more in front of them and one s_nop less in its padding)
-  if constexpr (kResid) {
-    SOLO_PGS_F32_ASM(".fill 11, 4, 0xbf800000\n", "v_mov_b32_e32 %[lam0], %[lam]\n\t",
-      "s_add_u32 %[it], %[it], 1\n\t"                                                              \
-      "s_cbranch_scc1 .Lpgs_%=_done\n\t"         /* (carry: the sweep cap) */                         \
-      "v_sub_f32_e32 %[x1], %[lam], %[lam0]\n\t"  /* another sweep only if some row's squared velocity-level change */ \
-      "v_mul_f32_e32 %[x1], %[x1], %[diag]\n\t"   /* (delta impulse x A_rr)^2 of THIS sweep is above the threshold */ \
-      "v_mul_f32_e32 %[x1], %[x1], %[x1]\n\t"                                                         \
-      "v_cmp_gt_f32_e64 %[w], %[x1], %[rthr]\n\t"                                                     \
-      "s_cmp_lg_u64 %[w], 0\n\t"                                                                      \
-      "s_cbranch_scc1 .Lpgs_%=_sweep\n\t"                                                             \
-      "s_branch .Lpgs_%=_done\n")
-  } else {
-    SOLO_PGS_F32_ASM(".fill 12, 4, 0xbf800000\n", "",
-      "s_add_u32 %[it], %[it], 1\n\t"                                                              \
-      "s_cbranch_scc0 .Lpgs_%=_sweep\n\t"        /* (no carry: below the sweep cap) */                \
-      "s_branch .Lpgs_%=_done\n")
-  }
+  asm volatile(
+      // The loops below sit at a FIXED position relative to the 64-byte instruction lines (the padding is
+      // jumped over): a loop whose head lies 0..4 dwords past a 32-byte boundary takes 120 cycles per
+      // iteration, 5..7 dwords past it 128..132 (tools/microbench/loop_align.hip: instructions are fetched
+      // in 32-byte blocks, and a taken branch into the tail of a block gets little from its first fetch).
+      // From this entry the row loops of the paths a slow robot takes start 0, 4 and 1 dwords past a boundary
+      // (p0, q1, p2; p1: 6).  Sixteen entry positions measured on the closed loop: 1.10 ... 1.15e8
+      // env-steps/s - without the pinning, every edit of the code in front of the loop moved all timings
+      "s_branch .Lpgs_%=_entry\n\t"
+      ".p2align 6\n\t"
+      ".fill 12, 4, 0xbf800000\n"              // (s_nop 0)
+      ".Lpgs_%=_entry:\n\t"
+      "s_sub_u32 %[it], 0, %[iters]\n\t"       // counts up to zero: the carry of the increment is "cap reached"
+      "s_cbranch_scc0 .Lpgs_%=_done\n"          // (no sweeps allowed)
+      ".Lpgs_%=_sweep:\n\t"
+      // ---- the non-contact rows (joint motors, joint limits), leg by leg
+      "s_and_b64 %[todo], %[pend], %[ph0]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_a1\n"
+      SOLO_PGS_WALK("p0", "%[ph0]")
+      // ---- all normal rows, then the friction limits
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_b2\n"            // no normal row moves in this sweep: the friction limits stand
+      SOLO_PGS_WALK("p1", "%[ph1]")
+      SOLO_PGS_LIMITS
+      "s_branch .Lpgs_%=_b2\n"
+      // (the same phase for a sweep that has found no work so far)
+      ".Lpgs_%=_a1:\n\t"
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_a2\n"
+      SOLO_PGS_WALK("q1", "%[ph1]")
+      SOLO_PGS_LIMITS
+      // ---- all friction rows
+      ".Lpgs_%=_b2:\n\t"
+      "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_next\n"
+      ".Lpgs_%=_p2:\n"
+      SOLO_PGS_WALK("p2", "%[ph2]")
+      ".Lpgs_%=_next:\n\t"
+      "s_add_u32 %[it], %[it], 1\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_sweep\n\t"       // (no carry: below the sweep cap)
+      "s_branch .Lpgs_%=_done\n"
+      ".Lpgs_%=_a2:\n\t"                        // (no work in the first two phases)
+      "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
+      "s_cbranch_scc1 .Lpgs_%=_p2\n"            // (else: nothing pending at the start of a sweep - converged)
+      ".Lpgs_%=_done:\n\t"
+      : [v] "+v"(v), [lam] "+v"(lam), [cand] "+v"(cand), [dl] "+v"(dl), [lo] "+v"(lo), [hi] "+v"(hi), [pend] "+s"(pend),
+        [thr] "=&v"(thr), [x1] "=&v"(x1), [x2] "=&v"(x2),
+        [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [sd] "=&s"(sd), [it] "=&s"(it)
+#ifdef SOLO_STAMPS
+        , [nch] "+s"(n_changed)
+#endif
+      : [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
+        [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes), "{v[64:95]}"(A.a0), "{v[96:127]}"(A.a1)
+      : "vcc", "scc");
   // (s_set_gpr_idx_on overwrites M0.  M0 is a RESERVED register for the AMDGPU backend - naming it in the clobber
   // list draws "reserved registers on the clobber list may not be preserved ... undefined behaviour" from clang -
   // and the backend never keeps a value live in it across statements: it (re)writes M0 immediately before each
   // of its own uses - LDS-direct, s_movrel, sendmsg.  `make asm`: no m0 reference in the generated code.)
-  (void)n_changed; (void)lam0;
+  (void)n_changed;
   return it + iters;
 }
 
@@ -241,87 +216,69 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
   "v_add_f64 v[118:119], v[116:117], -v[114:115]\n\t"                                              \
   "v_cmp_gt_f64_e64 %[pend], |v[118:119]|, %[thr]\n\t"
 
-// (the f64 loop's asm statement as a macro of the same three pieces as SOLO_PGS_F32_ASM)
-#define SOLO_PGS_F64_ASM(FILL, SWEEP_TOP, SWEEP_END) \
-  asm volatile( \
-      "s_branch .Lpgs64_%=_entry\n\t" \
-      ".p2align 6\n\t" \
-      FILL \
-      ".Lpgs64_%=_entry:\n\t" \
-      "s_sub_u32 %[it], 0, %[iters]\n\t" \
-      "s_cbranch_scc0 .Lpgs64_%=_done\n" \
-      ".Lpgs64_%=_sweep:\n\t" \
-      SWEEP_TOP \
-      "s_and_b64 %[todo], %[pend], %[ph0]\n\t" \
-      "s_cbranch_scc0 .Lpgs64_%=_a1\n" \
-      SOLO_PGS_WALK64("p0", "%[ph0]") \
-      "s_and_b64 %[todo], %[pend], %[ph1]\n\t" \
-      "s_cbranch_scc0 .Lpgs64_%=_b2\n" \
-      SOLO_PGS_WALK64("p1", "%[ph1]") \
-      SOLO_PGS_LIMITS64 \
-      "s_branch .Lpgs64_%=_b2\n" \
-      ".Lpgs64_%=_a1:\n\t" \
-      "s_and_b64 %[todo], %[pend], %[ph1]\n\t" \
-      "s_cbranch_scc0 .Lpgs64_%=_a2\n" \
-      SOLO_PGS_WALK64("q1", "%[ph1]") \
-      SOLO_PGS_LIMITS64 \
-      ".Lpgs64_%=_b2:\n\t" \
-      "s_and_b64 %[todo], %[pend], %[ph2]\n\t" \
-      "s_cbranch_scc0 .Lpgs64_%=_next\n" \
-      ".Lpgs64_%=_p2:\n" \
-      SOLO_PGS_WALK64("p2", "%[ph2]") \
-      ".Lpgs64_%=_next:\n\t" \
-      SWEEP_END \
-      ".Lpgs64_%=_a2:\n\t" \
-      "s_and_b64 %[todo], %[pend], %[ph2]\n\t" \
-      "s_cbranch_scc1 .Lpgs64_%=_p2\n" \
-      ".Lpgs64_%=_done:\n\t" \
-      : [v] "+v"(v), "={v[114:115]}"(lam_o), "={v[116:117]}"(cand_o), "={v[118:119]}"(dl_o), "={v[120:121]}"(lo_o), "={v[122:123]}"(hi_o), \
-        "={v[124:125]}"(x1), "={v[126:127]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr), [lam0] "=&v"(lam0), \
-        [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [ri] "=&s"(ri), [it] "=&s"(it) \
-        SOLO_PGS_NCH_OPERAND \
-      : "{v[114:115]}"(lam), "{v[116:117]}"(cand), "{v[118:119]}"(dl), "{v[120:121]}"(lo), "{v[122:123]}"(hi), \
-        [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2), \
-        [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes), [diag] "v"(diag), [rthr] "v"(resid_thr), \
-        "{v[128:159]}"(A.a0), "{v[160:191]}"(A.a1), "{v[192:223]}"(A.a2), "{v[224:255]}"(A.a3) \
-      : "vcc", "scc", "s94", "s95");
-
-template <bool kResid>
 __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, double& v, double& lam, double& cand, double& dl,
                                                 unsigned long long& pend, double& lo, double& hi, double tol, int lane, double mu,
                                                 unsigned long long tan1_lanes, unsigned long long tangent_lanes,
                                                 unsigned long long phase0, unsigned long long phase1, unsigned long long phase2,
-                                                int iters, int& n_changed, double diag, double resid_thr) {
-  double thr, lam_o, cand_o, dl_o, lo_o, hi_o, x1, x2, lam0;
+                                                int iters, int& n_changed) {
+  double thr, lam_o, cand_o, dl_o, lo_o, hi_o, x1, x2;
   unsigned long long w, t, todo;
   int rs, ri, it;
-  if constexpr (kResid) {
-    SOLO_PGS_F64_ASM(".fill 11, 4, 0xbf800000\n", "v_mov_b64 %[lam0], v[114:115]\n\t",
-      "s_add_u32 %[it], %[it], 1\n\t"                                                              \
-      "s_cbranch_scc1 .Lpgs64_%=_done\n\t"       /* (carry: the sweep cap) */                         \
-      "v_add_f64 v[124:125], v[114:115], -%[lam0]\n\t"                                                \
-      "v_mul_f64 v[124:125], v[124:125], %[diag]\n\t"                                                 \
-      "v_mul_f64 v[124:125], v[124:125], v[124:125]\n\t"                                              \
-      "v_cmp_gt_f64_e64 %[w], v[124:125], %[rthr]\n\t"                                                \
-      "s_cmp_lg_u64 %[w], 0\n\t"                                                                      \
-      "s_cbranch_scc1 .Lpgs64_%=_sweep\n\t"                                                           \
-      "s_branch .Lpgs64_%=_done\n")
-  } else {
-    SOLO_PGS_F64_ASM(".fill 12, 4, 0xbf800000\n", "",
-      "s_add_u32 %[it], %[it], 1\n\t"                                                              \
-      "s_cbranch_scc0 .Lpgs64_%=_sweep\n\t"      /* (no carry: below the sweep cap) */                \
-      "s_branch .Lpgs64_%=_done\n")
-  }
+  asm volatile(
+      "s_branch .Lpgs64_%=_entry\n\t"
+      ".p2align 6\n\t"
+      ".fill 12, 4, 0xbf800000\n"              // (s_nop 0: the loops at a fixed position within the 64-byte instruction lines)
+      ".Lpgs64_%=_entry:\n\t"
+      "s_sub_u32 %[it], 0, %[iters]\n\t"       // counts up to zero: the carry of the increment is "cap reached"
+      "s_cbranch_scc0 .Lpgs64_%=_done\n"        // (no sweeps allowed)
+      ".Lpgs64_%=_sweep:\n\t"
+      // ---- the non-contact rows (joint motors, joint limits), leg by leg
+      "s_and_b64 %[todo], %[pend], %[ph0]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_a1\n"
+      SOLO_PGS_WALK64("p0", "%[ph0]")
+      // ---- all normal rows, then the friction limits
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_b2\n"          // no normal row moves in this sweep: the friction limits stand
+      SOLO_PGS_WALK64("p1", "%[ph1]")
+      SOLO_PGS_LIMITS64
+      "s_branch .Lpgs64_%=_b2\n"
+      ".Lpgs64_%=_a1:\n\t"                      // (the same phase for a sweep that has found no work so far)
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_a2\n"
+      SOLO_PGS_WALK64("q1", "%[ph1]")
+      SOLO_PGS_LIMITS64
+      // ---- all friction rows
+      ".Lpgs64_%=_b2:\n\t"
+      "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_next\n"
+      ".Lpgs64_%=_p2:\n"
+      SOLO_PGS_WALK64("p2", "%[ph2]")
+      ".Lpgs64_%=_next:\n\t"
+      "s_add_u32 %[it], %[it], 1\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_sweep\n\t"     // (no carry: below the sweep cap)
+      "s_branch .Lpgs64_%=_done\n"
+      ".Lpgs64_%=_a2:\n\t"                      // (no work in the first two phases)
+      "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
+      "s_cbranch_scc1 .Lpgs64_%=_p2\n"          // (else: nothing pending at the start of a sweep - converged)
+      ".Lpgs64_%=_done:\n\t"
+      : [v] "+v"(v), "={v[114:115]}"(lam_o), "={v[116:117]}"(cand_o), "={v[118:119]}"(dl_o), "={v[120:121]}"(lo_o), "={v[122:123]}"(hi_o),
+        "={v[124:125]}"(x1), "={v[126:127]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
+        [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [ri] "=&s"(ri), [it] "=&s"(it)
+#ifdef SOLO_STAMPS
+        , [nch] "+s"(n_changed)
+#endif
+      : "{v[114:115]}"(lam), "{v[116:117]}"(cand), "{v[118:119]}"(dl), "{v[120:121]}"(lo), "{v[122:123]}"(hi),
+        [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
+        [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes),
+        "{v[128:159]}"(A.a0), "{v[160:191]}"(A.a1), "{v[192:223]}"(A.a2), "{v[224:255]}"(A.a3)
+      : "vcc", "scc", "s94", "s95");
   lam = lam_o; cand = cand_o; dl = dl_o; lo = lo_o; hi = hi_o;
-  (void)n_changed; (void)x1; (void)x2; (void)lam0;
+  (void)n_changed; (void)x1; (void)x2;
   return it + iters;
 }
 
 #undef SOLO_PGS_LIMITS64
 #undef SOLO_PGS_WALK64
 #undef SOLO_PGS_COUNT_ROW
-#undef SOLO_PGS_F32_ASM
-#undef SOLO_PGS_F64_ASM
-#undef SOLO_PGS_NCH_OPERAND
 
 }  // namespace solo

@@ -126,7 +126,7 @@ constexpr int kLegSlots = 20;
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
 // constraint impulse; physics_finish writes s_state (new).
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool kResid>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
                                            const RowConst<T>& rc, const T* s_state, T my_target, T (*s_rowvec)[8], T (*s_hext)[8],
                                            T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps, int& prio_rot) {
@@ -539,8 +539,10 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // change of the row, what [recalled] btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric returns - is
   // <= the threshold.  A row is updated at most once per sweep, so its delta is lam - lam at the start of the sweep:
   // ONE test per sweep for all 64 rows.  Threshold 0 (the host default): off - the iteration runs to its fixed point.
+  // It is a compile-time property of the kernel (kResid; the engine launches solo_step_kernel<T, kFull, true> when the
+  // configuration asks for it): the default kernels carry none of it.
   const T resid_thr = C.resid_thr;
-  const bool use_resid = wave_uniform((int)(resid_thr > T(0))) != 0;
+  constexpr bool use_resid = kResid;
   // rows of one sweep, in solver order ([recalled] btMultiBodyConstraintSolver::solveSingleIteration):
   // the non-contact rows (joint motors, joint limits), then ALL normal contact rows, then ALL friction rows
   constexpr unsigned long long kPhaseLanes[3] = {0xc003c003c003c003ull,    // motors k = 0, 1 and joint limits k = 14, 15, leg by leg
@@ -557,21 +559,23 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #ifdef SOLO_PGS_GFX950
   // on the GPU: the loop below, written in assembly (solo_pgs_gfx950.h, f32 and f64) - same rows, same order, same
   // arithmetic; this C++ form stays the definition (the CPU emulator, and the -DSOLO_PGS_NO_ASM test
-  // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py)
-  {
+  // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py).  The kernels with pybullet's
+  // residual threshold (kResid, an opt-in) run the C++ form on the GPU as well: two attempts to carry the per-sweep
+  // test into the assembly path - a second copy of the loop with the test inside, and the loop entered one sweep at a
+  // time from a C++ loop - computed WAVE-DEPENDENT GARBAGE at 2+ waves per SIMD in some builds (identical robots
+  // diverged, wild addresses faulted; it moved with register allocation and was not understood): the assembly loop is
+  // used exactly as rounds 2-3 validated it, as ONE straight-line call per step, and
+  // tests/test_gpu_physics.py::test_identical_robots_stay_identical guards that class of failure since.
+  if constexpr (!kResid) {
     int rows_updated = 0;
-    const unsigned long long tan1_lanes = wave_ballot(type == ROW_TAN1), tangent_lanes = wave_ballot(is_tangent);
-    if (use_resid)   // (two copies of the loop: the default path carries no residual test)
-      it = pgs_solve_gfx950<true>(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes,
-                                  kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2], iters, rows_updated, diag, resid_thr);
-    else
-      it = pgs_solve_gfx950<false>(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes,
-                                   kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2], iters, rows_updated, diag, resid_thr);
+    it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu,
+                          wave_ballot(type == ROW_TAN1), wave_ballot(is_tangent), kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2],
+                          iters, rows_updated);
 #ifdef SOLO_STAMPS
     n_changed = rows_updated;
 #endif
-  }
-#else
+  } else
+#endif
 #pragma unroll 1
   for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
     // (the register banks of the matrix are walked one after the other - static bank per loop - which
@@ -619,7 +623,6 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     const T dvel = (lamv - lam_sweep_start) * diag;
     if (use_resid && wave_ballot(dvel * dvel > resid_thr) == 0ull) { ++it; break; }  // the residual threshold (see above)
   }
-#endif
 #ifdef SOLO_STAMPS
   if (lane == 0) {
     // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28
@@ -734,7 +737,7 @@ template <typename T, bool kFull> constexpr bool kInlineOutputs = kFull && sizeo
 constexpr int kRobotsPerGroup = 1;
 #endif
 
-template <typename T, bool kFull>
+template <typename T, bool kFull, bool kResid = false>
 __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(const KParams<T>* __restrict__ Pin, KBuffers<T> Bin) {
   KBuffers<T> B = Bin;
   if (!kFull) B.flags = SOLO_STEP_PHYSICS;
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
       group_sync();  // ... and its factors / unconstrained velocities from the dynamics wave
 #endif
       const T my_target = raw_target * target_scale;
-      const T lam = physics_solve<T>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, prio_sweeps, prio_steps, prio_rot);
+      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, prio_sweeps, prio_steps, prio_rot);
       physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, s_math, lam, lane);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted

@@ -98,7 +98,11 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   const KParams<T>* Pp = &P;
   // the step kernel, output epilogue included: one emulated wavefront per robot (as Engine::launch_chain launches it)
   for (int b = 0; b < n; ++b)
-    WaveEmu::get().run_block(b, n, [&]() { solo_step_kernel<T, true>(Pp, B); });
+    WaveEmu::get().run_block(b, n, [&]() {
+      // (as Engine::launch_chain: pybullet's residual threshold is a kernel instantiation of its own)
+      if (cfg->solver_residual_threshold > 0) solo_step_kernel<T, true, true>(Pp, B);
+      else solo_step_kernel<T, true, false>(Pp, B);
+    });
   for (size_t i = 0; i < st.size(); ++i) state[i] = (double)st[i];
   for (size_t i = 0; i < tg.size(); ++i) targets[i] = (double)tg[i];
   if (flags & SOLO_STEP_OBS) for (size_t i = 0; i < (size_t)steps * n * D; ++i) obs[i] = (double)ob[i];

@@ -158,3 +158,42 @@ def test_passive_rest_pose_reproduces_the_reference_vector_gpu():
   home = so.OraclePhysics(ca, ma).settle(1)
   np.testing.assert_allclose(snap[:, :29], np.tile(home[:, :29], (4, 1)), rtol=0, atol=1e-8)
   eng.close()
+
+
+@pytest.mark.parametrize('resid', [0.0, 1e-7])
+@pytest.mark.parametrize('dtype,n', [('float32', 4096), ('float32', 8192), ('float64', 4096)])
+def test_identical_robots_stay_identical(torch, dtype, n, resid):
+  """Every robot of a batch starts in the same state and receives the same actions: whatever the number of
+  waves per SIMD, all of them must end in the SAME bits, and in the bits of a 64-robot batch (one wave per
+  SIMD).  A wave that reads anything of another wave's - registers or LDS beyond its allocation, a stale scalar -
+  shows up here as robots that differ; this is the test that caught the round-3 assembly loop computing
+  wave-dependent garbage at 2+ waves per SIMD (solo_pgs_gfx950.h).  20 fused steps with observations, rewards
+  and terminations, the settle loop (physics-only kernel) before them; default solver and pybullet's residual
+  threshold (the second copy of the assembly loop)."""
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
+  from gym_solo_amd.workloads import register_benchmark_workload
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  g = torch.Generator(device='cuda').manual_seed(8)
+  one = (torch.rand(20, 1, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
+  ref = None
+  for count in (64, n):
+    cfg = Solo8VanillaConfig()
+    cfg.dtype, cfg.num_envs, cfg.auto_reset, cfg.steps_per_launch = dtype, count, True, 20
+    cfg.solver_residual_threshold = resid
+    env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
+    register_benchmark_workload(env, max_steps=13)   # an episode end (and restore) inside the launch
+    env._ensure_program()
+    eng = env.engine
+    snap = eng.snapshot.cpu().numpy()
+    assert (snap == snap[0]).all(), 'the settle loop left different robots'
+    out = eng.rollout(one.expand(20, count, 12).contiguous(), abi.STEP_ALL, record=True)
+    eng.synchronize()
+    got = [eng.state.cpu().numpy(), eng.cost.cpu().numpy()] + [t.cpu().numpy() for t in out]
+    assert all((x == x[0:1]).all() for x in got[:2]), 'robots of one batch differ'
+    assert all((x == x[:, 0:1]).all() for x in got[2:]), 'recorded outputs of one batch differ'
+    if ref is None:
+      ref = [got[0][0], got[1][0]] + [x[:, 0] for x in got[2:]]
+    else:
+      for a, b in zip(ref, [got[0][0], got[1][0]] + [x[:, 0] for x in got[2:]]):
+        np.testing.assert_array_equal(a, b)
+    env._close()

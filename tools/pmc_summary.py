@@ -10,7 +10,8 @@ import collections, csv, glob, json, os, sys
 
 
 def family(name):
-  if 'solo_step_kernel' in name and ('true' in name or 'Lb1' in name):
+  # solo_step_kernel<T, kFull, kResid>: the full-step instantiations (kFull = true), not the physics-only ones
+  if 'solo_step_kernel' in name and (', true,' in name or 'Lb1ELb' in name or name.rstrip('>').endswith('true') and name.count(',') == 1):
     return 'step'
   if 'solo_outputs_kernel' in name:
     return 'outputs'

@@ -10,7 +10,7 @@ def main(prof_dir, out_path, label):
     out['kernel_stats_top'].append({'name': r['Name'][:110], 'calls': int(r['Calls']),
                                     'total_ns': int(r['TotalDurationNs']), 'avg_ns': float(r['AverageNs']),
                                     'pct': float(r['Percentage']), 'min_ns': int(r['MinNs']), 'max_ns': int(r['MaxNs'])})
-  tr = [r for r in csv.DictReader(open(trace)) if 'solo_step_kernel' in r['Kernel_Name'] and 'true' in r['Kernel_Name']]
+  tr = [r for r in csv.DictReader(open(trace)) if 'solo_step_kernel' in r['Kernel_Name'] and (', true,' in r['Kernel_Name'] or (r['Kernel_Name'].count(',') == 1 and 'true' in r['Kernel_Name']))]
   # only full-size fused launches (the timed workload): the largest grid and the modal duration class
   if tr:
     gmax = max(int(r['Grid_Size_X']) for r in tr)
