@@ -451,14 +451,14 @@ def main():
       extra['episodes_f64'] = summarize(s64.cpu().numpy())
       e64._close()
     # pybullet's documented default solverResidualThreshold (1e-7 [recalled]) as an OPT-IN: off in `value`
-    for key, dt_ in (('value_residual_1e-7', args.dtype),) + ((('value_f64_residual_1e-7', 'float64'),) if args.dtype == 'float32' else ()):
-      tr, _, _, er, _, _, _ = timed(dt_, ke, False, 0.3, 10, residual_threshold=1e-7)
-      extra[key] = world * n * ke / statistics.median(tr)
-      er._close()
+    tr, _, _, er, _, _, _ = timed(args.dtype, ke, False, 0.3, 10, residual_threshold=1e-7)
+    extra['value_residual_1e-7'] = world * n * ke / statistics.median(tr)
+    er._close()
     extra['value_residual_note'] = ('the same rollout with SoloConfig.solver_residual_threshold = 1e-7 (pybullet\'s documented default; the '
-                                    'Gauss-Seidel iteration ends after a sweep whose largest squared velocity-level change is below it); NOT '
-                                    'the configuration of `value`: without warm starting it leaves a resting robot jittering at 5e-5 rad/s, '
-                                    'where the reference\'s recorded rest state has 1e-11')
+                                    'Gauss-Seidel iteration ends after a sweep whose largest squared velocity-level change is below it; its '
+                                    'kernels run the C++ form of the solver loop, not the assembly one); NOT the configuration of `value`: '
+                                    'without warm starting it leaves a resting robot jittering at 5e-5 rad/s, where the reference\'s recorded '
+                                    'rest state has 1e-11')
     tcl, _, _, ecl, _, _, _ = timed(args.dtype, ke, True, 0.3, 10)
     extra['value_closed_loop'] = world * n * ke / statistics.median(tcl)
     extra['value_closed_loop_note'] = ('one solo_engine_step launch per env step (outputs evaluated in that launch), the '
