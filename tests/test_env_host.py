@@ -127,3 +127,19 @@ def test_make_and_vector_adapter(monkeypatch):
 
 def test_host_termination_with_auto_reset_restarts_the_episode():
   cases.case_host_termination_auto_reset(make_env)
+
+
+def test_residual_threshold_is_validated():
+  """SoloConfig.solver_residual_threshold (pybullet's solverResidualThreshold, opt-in): 0 by default, negative and NaN
+  values are rejected on the host like the other solver knobs."""
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  from gym_solo_amd.model import JOINT_NAMES
+  cfg = Solo8VanillaConfig()
+  assert cfg.solver_residual_threshold == 0.0
+  assert config_to_abi(cfg, cfg.starting_joint_pos, JOINT_NAMES).solver_residual_threshold == 0.0
+  cfg.solver_residual_threshold = 1e-7
+  assert config_to_abi(cfg, cfg.starting_joint_pos, JOINT_NAMES).solver_residual_threshold == 1e-7
+  for bad in (-1e-9, float('nan')):
+    cfg.solver_residual_threshold = bad
+    with pytest.raises(ValueError):
+      config_to_abi(cfg, cfg.starting_joint_pos, JOINT_NAMES)
