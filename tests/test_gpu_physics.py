@@ -161,15 +161,17 @@ def test_passive_rest_pose_reproduces_the_reference_vector_gpu():
 
 
 @pytest.mark.parametrize('resid', [0.0, 1e-7])
-@pytest.mark.parametrize('dtype,n', [('float32', 4096), ('float32', 8192), ('float64', 4096)])
-def test_identical_robots_stay_identical(torch, dtype, n, resid):
+@pytest.mark.parametrize('dtype,n,spl,streams,terrain', [('float32', 4096, 20, 1, None), ('float32', 8192, 20, 1, None), ('float64', 4096, 20, 1, None),
+                                                         ('float32', 4096, 10, 2, 'stairs'), ('float32', 4096, 1, 1, None), ('float64', 4096, 5, 2, 'incline')])
+def test_identical_robots_stay_identical(torch, dtype, n, spl, streams, terrain, resid):
   """Every robot of a batch starts in the same state and receives the same actions: whatever the number of
   waves per SIMD, all of them must end in the SAME bits, and in the bits of a 64-robot batch (one wave per
   SIMD).  A wave that reads anything of another wave's - registers or LDS beyond its allocation, a stale scalar -
   shows up here as robots that differ; this is the test that caught the round-3 assembly loop computing
-  wave-dependent garbage at 2+ waves per SIMD (solo_pgs_gfx950.h).  20 fused steps with observations, rewards
-  and terminations, the settle loop (physics-only kernel) before them; default solver and pybullet's residual
-  threshold (the second copy of the assembly loop)."""
+  wave-dependent garbage at 2+ waves per SIMD.  20 steps with observations, rewards and
+  terminations - fused, in stream slices, one launch per step (in-place outputs), on heightfields -, the settle loop
+  (physics-only kernel) before them; default solver and pybullet's residual threshold (its own kernels)."""
+  import helpers
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
   tdt = torch.float32 if dtype == 'float32' else torch.float64
@@ -178,8 +180,10 @@ def test_identical_robots_stay_identical(torch, dtype, n, resid):
   ref = None
   for count in (64, n):
     cfg = Solo8VanillaConfig()
-    cfg.dtype, cfg.num_envs, cfg.auto_reset, cfg.steps_per_launch = dtype, count, True, 20
+    cfg.dtype, cfg.num_envs, cfg.auto_reset, cfg.steps_per_launch, cfg.rollout_streams = dtype, count, True, spl, streams
     cfg.solver_residual_threshold = resid
+    if terrain is not None:
+      cfg.terrain = getattr(helpers, terrain + '_terrain')()
     env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
     register_benchmark_workload(env, max_steps=13)   # an episode end (and restore) inside the launch
     env._ensure_program()
