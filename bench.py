@@ -455,8 +455,8 @@ def main():
     extra['value_residual_1e-7'] = world * n * ke / statistics.median(tr)
     er._close()
     extra['value_residual_note'] = ('the same rollout with SoloConfig.solver_residual_threshold = 1e-7 (pybullet\'s documented default; the '
-                                    'Gauss-Seidel iteration ends after a sweep whose largest squared velocity-level change is below it; its '
-                                    'kernels run the C++ form of the solver loop, not the assembly one); NOT the configuration of `value`: '
+                                    'Gauss-Seidel iteration ends after a sweep whose largest squared velocity-level change is below it); NOT the '
+                                    'configuration of `value`: '
                                     'without warm starting it leaves a resting robot jittering at 5e-5 rad/s, where the reference\'s recorded '
                                     'rest state has 1e-11')
     tcl, _, _, ecl, _, _, _ = timed(args.dtype, ke, True, 0.3, 10)

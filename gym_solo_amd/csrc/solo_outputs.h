@@ -137,38 +137,28 @@ __device__ __forceinline__ T eval_reward(const KParams<T>* P, const T* rec, T ro
 // One robot's episodic bookkeeping over the `steps` steps of a launch, in step order: the
 // return / length accumulators live in the robot's state record (SOLO_S_RETURN / SOLO_S_EPLEN);
 // a restart closes them (and, when the episode really ended, adds it to the statistics shard).
-// Rewards and event bytes are fetched kChunk steps at a time (independent loads in flight) and
-// then consumed in order: the additions stay sequential, only the memory latency is overlapped.
+// The rewards and event bytes of a pass sit in LDS (the output epilogue) or are a single step's (the in-place
+// path): a plain loop in step order - no local arrays, which the compiler indexes dynamically through
+// s_set_gpr_idx_on (rounds 1-2 prefetched 16 steps at a time from global memory for the returns kernel).
 template <typename T, typename AddFn>
 __device__ __forceinline__ void accumulate_returns(T* state_rec, const uint8_t* events, long long events_stride, const T* reward,
                                                    long long reward_stride, int steps, double* stats, AddFn add) {
-  constexpr int kChunk = 16;
   T ret = state_rec[SOLO_S_RETURN], len = state_rec[SOLO_S_EPLEN];
-  for (int k0 = 0; k0 < steps; k0 += kChunk) {
-    T r[kChunk];
-    int ev[kChunk];
-#pragma unroll
-    for (int j = 0; j < kChunk; ++j) {
-      const int k = (k0 + j < steps) ? k0 + j : steps - 1;  // (clamped: the tail re-reads the last step, unused)
-      r[j] = reward[(size_t)k * reward_stride];
-      ev[j] = events[(size_t)k * events_stride];
-    }
-#pragma unroll
-    for (int j = 0; j < kChunk; ++j) {
-      if (k0 + j >= steps) break;
-      ret += r[j];
-      len += T(1);
-      if (ev[j] & kEventRestart) {
-        if (ev[j] & kEventDone) {
-          const double x = (double)ret;
-          add(&stats[0], x);
-          add(&stats[1], x * x);
-          add(&stats[2], 1.0);
-          add(&stats[3], (double)len);
-        }
-        ret = T(0);
-        len = T(0);
+#pragma unroll 1
+  for (int k = 0; k < steps; ++k) {
+    const int ev = events[(size_t)k * events_stride];
+    ret += reward[(size_t)k * reward_stride];
+    len += T(1);
+    if (ev & kEventRestart) {
+      if (ev & kEventDone) {
+        const double x = (double)ret;
+        add(&stats[0], x);
+        add(&stats[1], x * x);
+        add(&stats[2], 1.0);
+        add(&stats[3], (double)len);
       }
+      ret = T(0);
+      len = T(0);
     }
   }
   state_rec[SOLO_S_RETURN] = ret;

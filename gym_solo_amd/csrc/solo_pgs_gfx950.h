@@ -26,6 +26,19 @@
 //    multiplies), with no "anything pending?" test in the loop.  The slowest robot of a closed-loop
 //    step or a short launch runs all 50 sweeps with ~3 rows moving in each: one instruction per sweep
 //    is 1 % of such a step, one per row 1.5 % (measured);
+//  * s_set_gpr_idx_on / s_set_gpr_idx_off are each FOLLOWED BY A SCALAR INSTRUCTION before the next vector instruction
+//    (round 3).  With the indexed v_fma directly behind s_set_gpr_idx_on (and the v_cndmask directly behind
+//    s_set_gpr_idx_off) the loop computed WAVE-DEPENDENT GARBAGE at two or more waves per SIMD in some builds - the
+//    vector instruction saw the old index / mode: identical robots diverged, wild addresses faulted at 4096 robots,
+//    a 64-robot batch (one wave per SIMD) was always right, and which build broke moved with the code around the
+//    loop (rounds 2-3's product builds happened to be spared, bit for bit against the C++ loop; the first build
+//    that re-entered the loop per sweep was not).  Four probes on the failing build, same call: s_nop after the
+//    compare that writes `pend` - still faults; s_nop after the v_readlane - still faults; s_nop between
+//    s_set_gpr_idx_on and the v_fma - clean; that plus the others - clean.  The fix costs nothing: the two scalar
+//    instructions of the row update that do not depend on the vector pipe (s_lshl_b64 for the cursor, s_and_b64 for
+//    the rows beyond it) sit in the two shadows.  tests/test_gpu_physics.py::test_identical_robots_stay_identical
+//    guards it.  (The compiler's own s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off sequences - dynamically indexed
+//    local arrays - have the same shape: the kernel no longer contains any.)
 //  * the manual wait states of gfx940-class hardware are respected by construction (>= 2 instructions
 //    between a VALU write of an SGPR / VCC and a VALU read of it, >= 2 between a VALU write and a DPP
 //    read, >= 1 before a v_readlane of a freshly written VGPR) - the assembler does not check them
@@ -57,15 +70,15 @@ namespace solo {
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
   "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
   "v_readlane_b32 %[sd], %[dl], %[rs]\n\t"    /* the change of its impulse */                      \
-  "s_lshl_b64 %[t], -2, %[rs]\n\t"                                                                 \
   "s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n\t"                                                      \
+  "s_lshl_b64 %[t], -2, %[rs]\n\t"            /* (a scalar instruction BETWEEN the mode switch and the indexed VALU instruction: see above) */ \
   "v_fma_f32 %[v], v64, %[sd], %[v]\n\t"      /* v += column * change; the column is v[64 + row]: source 0, register-indexed */ \
   "s_set_gpr_idx_off\n\t"                                                                          \
+  "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor (and the wait state after the mode switch) */ \
   "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n\t"                                             \
   "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n\t"                                                     \
   "v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n\t"                                                     \
   "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"                                                       \
-  "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor */             \
   "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"                                                  \
   SOLO_PGS_COUNT_ROW                                                                               \
   "s_and_b64 %[todo], %[pend], %[w]\n\t"                                                           \
@@ -182,17 +195,17 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
   "v_readlane_b32 s94, v118, %[rs]\n\t"       /* the change of its impulse */                      \
   "v_readlane_b32 s95, v119, %[rs]\n\t"                                                            \
   "s_lshl_b32 %[ri], %[rs], 1\n\t"            /* register index of the column: 2 x row */          \
-  "s_lshl_b64 %[t], -2, %[rs]\n\t"                                                                 \
   "s_set_gpr_idx_on %[ri], gpr_idx(SRC0)\n\t"                                                      \
+  "s_lshl_b64 %[t], -2, %[rs]\n\t"            /* (a scalar instruction between the mode switch and the indexed VALU instruction) */ \
   "v_fma_f64 %[v], v[128:129], s[94:95], %[v]\n\t"  /* v += column * change (source 0 register-indexed) */ \
   "s_set_gpr_idx_off\n\t"                                                                          \
+  "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor (and the wait state after the mode switch) */ \
   "v_cndmask_b32_e32 v114, v114, v116, vcc\n\t"   /* lam[row] = cand[row] */                       \
   "v_cndmask_b32_e32 v115, v115, v117, vcc\n\t"                                                    \
   "v_max_f64 v[116:117], %[v], v[120:121]\n\t"                                                     \
   "v_min_f64 v[116:117], v[116:117], v[122:123]\n\t"                                               \
   "v_mul_f64 %[thr], %[tol], |v[114:115]|\n\t"                                                     \
   "v_add_f64 v[118:119], v[116:117], -v[114:115]\n\t"                                              \
-  "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor */             \
   "v_cmp_gt_f64_e64 %[pend], |v[118:119]|, %[thr]\n\t"                                             \
   SOLO_PGS_COUNT_ROW                                                                               \
   "s_and_b64 %[todo], %[pend], %[w]\n\t"                                                           \

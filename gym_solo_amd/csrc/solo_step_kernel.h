@@ -559,23 +559,34 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #ifdef SOLO_PGS_GFX950
   // on the GPU: the loop below, written in assembly (solo_pgs_gfx950.h, f32 and f64) - same rows, same order, same
   // arithmetic; this C++ form stays the definition (the CPU emulator, and the -DSOLO_PGS_NO_ASM test
-  // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py).  The kernels with pybullet's
-  // residual threshold (kResid, an opt-in) run the C++ form on the GPU as well: two attempts to carry the per-sweep
-  // test into the assembly path - a second copy of the loop with the test inside, and the loop entered one sweep at a
-  // time from a C++ loop - computed WAVE-DEPENDENT GARBAGE at 2+ waves per SIMD in some builds (identical robots
-  // diverged, wild addresses faulted; it moved with register allocation and was not understood): the assembly loop is
-  // used exactly as rounds 2-3 validated it, as ONE straight-line call per step, and
-  // tests/test_gpu_physics.py::test_identical_robots_stay_identical guards that class of failure since.
-  if constexpr (!kResid) {
+  // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py).
+  {
     int rows_updated = 0;
-    it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu,
-                          wave_ballot(type == ROW_TAN1), wave_ballot(is_tangent), kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2],
-                          iters, rows_updated);
+    const unsigned long long tan1_lanes = wave_ballot(type == ROW_TAN1), tangent_lanes = wave_ballot(is_tangent);
+    if constexpr (!kResid) {
+      // the default configuration: ONE straight-line call runs all the sweeps
+      it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes,
+                            kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2], iters, rows_updated);
+    } else {
+      // pybullet's residual threshold (opt-in; kernel instantiations of their own, so that the default kernels keep
+      // their code): the loop is entered for ONE sweep at a time and the test - one for all 64 rows - sits between
+      // the calls: ~15 instructions of entry / exit per sweep, paid only by that configuration
+#pragma unroll 1
+      for (;;) {
+        const T lam_sweep_start = lamv;
+        const int n = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes,
+                                       kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2], 1, rows_updated);
+        it += n;
+        if (n == 0 || it >= iters) break;   // (n == 0: nothing was pending at the start of the sweep)
+        const T dvel = (lamv - lam_sweep_start) * diag;
+        if (wave_ballot(dvel * dvel > resid_thr) == 0ull) break;
+      }
+    }
 #ifdef SOLO_STAMPS
     n_changed = rows_updated;
 #endif
-  } else
-#endif
+  }
+#else
 #pragma unroll 1
   for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
     // (the register banks of the matrix are walked one after the other - static bank per loop - which
@@ -623,6 +634,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     const T dvel = (lamv - lam_sweep_start) * diag;
     if (use_resid && wave_ballot(dvel * dvel > resid_thr) == 0ull) { ++it; break; }  // the residual threshold (see above)
   }
+#endif
 #ifdef SOLO_STAMPS
   if (lane == 0) {
     // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28
