@@ -39,6 +39,9 @@
 //    the rows beyond it) sit in the two shadows.  tests/test_gpu_physics.py::test_identical_robots_stay_identical
 //    guards it.  (The compiler's own s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off sequences - dynamically indexed
 //    local arrays - have the same shape: the kernel no longer contains any.)
+//    A stand-alone loop of this shape does NOT reproduce the failure (tools/microbench/gpr_idx_hazard.hip: 3.5e9 row
+//    updates, every order / context / alignment clean): the adjacency is necessary on the failing build, not sufficient
+//    in general, and the mechanism is not established - the regression test is what the product relies on.
 //  * the manual wait states of gfx940-class hardware are respected by construction (>= 2 instructions
 //    between a VALU write of an SGPR / VCC and a VALU read of it, >= 2 between a VALU write and a DPP
 //    read, >= 1 before a v_readlane of a freshly written VGPR) - the assembler does not check them
