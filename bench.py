@@ -213,7 +213,7 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
   instruction count per env-step measured with rocprofv3 --pmc SQ_INSTS_VALU (profiles/)."""
   valu = pmc.get('valu_insts_per_env_step')
   if not valu:
-    return 'dependent-issue-latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype'
+    return 'dependent-issue-latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype', None
   cyc = VALU_CYCLES_SHARED if waves_per_simd >= 2 else VALU_CYCLES_ALONE
   clock = pmc.get('effective_clock_hz') or SHADER_CLOCK_HZ  # measured (GRBM_GUI_ACTIVE / 8 / wall) when profiled
   simd_cycles = NUM_SIMDS * kern_ms * 1e-3 * clock
@@ -225,7 +225,10 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
           '6.2 per instruction of the solver\'s serial row-update chain (tools/microbench/simd_rate.hip), %s instructions per '
           'env-step - and the launch waiting for its slowest robot (DESIGN.md section 4)'
           % (valu, cyc, waves_per_simd, env_steps_per_launch, chains, util, NUM_SIMDS, clock / 1e9,
-             ('%.0f' % pmc['insts_per_env_step']) if pmc.get('insts_per_env_step') else '~2300'))
+             ('%.0f' % pmc['insts_per_env_step']) if pmc.get('insts_per_env_step') else '~2300'),
+          {'bound': 'valu-issue', 'frac': util, 'valu_insts_per_env_step': valu, 'insts_per_env_step': pmc.get('insts_per_env_step'),
+           'cycles_per_valu_inst': cyc, 'simds': NUM_SIMDS, 'clock_hz': clock, 'concurrent_launch_chains': chains,
+           'unit': 'share of the SIMDs\' VALU issue slots over the launch (SURVEY.md §8d: the secondary, practical bound)'})
 
 
 def free_port():
@@ -420,17 +423,18 @@ def main():
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     pmc = pmc_profile(dtype, spl, slices)
     traffic = pmc['hbm_bytes_per_env_step'] * env_steps_per_launch if pmc.get('hbm_bytes_per_env_step') else None
+    note, secondary = secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, n / NUM_SIMDS)
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
             'traffic_note': pmc.get('traffic_note'),
             'traffic_profile': None if not pmc else {'entry': pmc.get('profile_key'), 'measured_on_this_launch_geometry': pmc.get('geometry_match')},
             'kernel': eng.kernel_name, 'kernel_ms': kern_ms,
             'kernel_ms_note': 'HIP events around the launch chain of every slice, on the stream it is launched on; mean per '
-                              'launch over slices and launches; the step kernel alone (the output kernels are separate, short launches)',
+                              'launch over slices and launches (the step kernel is the only kernel of a launch: its epilogue writes the outputs)',
             'bytes_per_env_step': BYTES_PER_ENV_STEP[dtype],
             'algorithmic_bytes_per_launch': bytes_per_launch, 'env_steps_per_launch': env_steps_per_launch,
             'concurrent_launch_chains': slices, 'achieved_all_chains': achieved * slices,
-            'note': secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, n / NUM_SIMDS)}, slices
+            'note': note, 'secondary': secondary}, slices
 
   times, stats, eng, env, action_pool, spl, streams = timed(args.dtype, k, False, args.min_seconds, args.max_repeats)
   log('timed region done: %d repeats, stats all-reduce ok (episodes %.0f)' % (len(times), float(stats[2])))

@@ -9,8 +9,8 @@ run (roofline.traffic = hbm_bytes_per_env_step x env_steps_per_launch of that ru
 WRITE_SIZE come from SEPARATE --pmc passes (TCC slots), rocprofv3 reports them in KB.
 MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE under-reports WIDE (16 B/lane) streaming
 reads by exactly 2x, WRITE_SIZE is exact for 16 B/lane stores, other widths are uncalibrated.  The
-step kernel loads one dword per lane (uncalibrated: raw value kept); the outputs kernel streams its
-records and rows coalesced (dword per lane as well).  The raw figures are reported, with the
+step kernel loads one dword per lane (uncalibrated: raw value kept); its output epilogue (round 3; before: the
+outputs kernel) re-reads its own records and writes the rows with dword stores.  The raw figures are reported, with the
 2x-on-reads upper bound next to them."""
 import json, os, sys
 src, cfg = sys.argv[1], (sys.argv[2:] or ['f32'])[0]
@@ -59,8 +59,8 @@ out = {key: {
                   'KB x 1024, every solo kernel of one fused launch of %d robots x %d steps - since round 3 the step kernel alone, its output epilogue included) x this run\'s '
                   'env-steps per launch; raw FETCH_SIZE (dword-per-lane loads: uncalibrated width; with the guide\'s 2x '
                   'correction for wide reads the total would be %.0f B/env-step); algorithmic figure of the whole path: %d '
-                  'B/env-step (a fused launch neither re-reads nor re-writes the state record per step, and the returns '
-                  'kernel reads one reward + one event byte per env-step)' % (meta['robots_per_launch'], meta['steps_per_launch'], 2 * rd + wr, BYTES_PER_ENV_STEP),
+                  'B/env-step (a fused launch neither re-reads nor re-writes the state record per step; it writes one 128-B record '
+                  'per robot-step, which its output epilogue reads back - L2-resident - to write the observation / reward / done rows)' % (meta['robots_per_launch'], meta['steps_per_launch'], 2 * rd + wr, BYTES_PER_ENV_STEP),
   'how': 'tools/refresh_profiles.sh: tools/prof_driver.py (bench workload, every step recorded) under rocprofv3 --pmc, one '
          'pass per counter group; tools/pmc_summary.py averages the last 6 full-size dispatches per kernel'}}
 path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
