@@ -132,7 +132,7 @@ struct Engine final : EngineBase {
     b.state = state; b.snapshot = snapshot; b.targets = targets; b.actions = actions;
     b.params = params; b.traj = nullptr; b.obs_inline = b.reward_inline = nullptr; b.done = done; b.term_count = term_count;
     b.obs_rec = b.reward_rec = b.view_obs = b.view_reward = nullptr; b.view_done = nullptr; b.obs_rec_stride = b.reward_rec_stride = 0; b.obs_from = 0;
-    b.stats = stats; b.terrain = terrain; b.order = use_order ? order : nullptr; b.cost = cost; b.num_envs = n; b.flags = flags; b.env_base = 0; b.steps = 1;
+    b.stats = stats; b.terrain = terrain; b.order = use_order ? order : nullptr; b.cost = cost; b.num_envs = n; b.flags = flags; b.env_base = 0; b.count = n; b.steps = 1;
     b.action_stride = b.done_stride = 0;
 #ifdef SOLO_STAMPS
     b.stamps = stamps;
@@ -223,10 +223,9 @@ struct Engine final : EngineBase {
   }
 
   // one chain of launches covering steps [0, k) for robots [lo, lo+count): per launch the step
-  // kernel (one wave per robot, S fused steps), then - on the same stream - the output kernels
-  // over the S x count step records it left behind (one thread per robot-step / per robot)
-  // final_chunk: this chain ends the caller's rollout - a RECORDING rollout then has its last launch's output
-  // kernel also leave the last step's observation / reward / done in the engine's view (what three
+  // kernel (one wave per robot, S fused steps; its output epilogue evaluates the S step records the robot left)
+  // final_chunk: this chain ends the caller's rollout - a RECORDING rollout then has its last launch's epilogue
+  // also leave the last step's observation / reward / done in the engine's view (what three
   // device-to-device copies after the chain used to do: ~15 us of a 0.4 ms 20-step rollout)
   int launch_chain(const T* act, long long act_stride, int k, uint32_t flags, T* obs_out, T* reward_out,
                    uint8_t* done_out, hipStream_t s, int lo, int count, bool final_chunk = true) {
@@ -236,6 +235,7 @@ struct Engine final : EngineBase {
       const int steps = (k - i < S) ? (k - i) : S;
       solo::KBuffers<T> b = buffers(act ? act + (size_t)i * act_stride : nullptr, flags);
       b.env_base = lo;
+      b.count = count;
       b.steps = steps;
       b.action_stride = act_stride;
       if (done_out) { b.done = done_out + (size_t)i * n; b.done_stride = n; }

@@ -96,6 +96,16 @@ struct KParams {
   RewardInstrK<T> reward[SOLO_MAX_REWARD_OPS];
 };
 
+// Workgroup -> robot map of a launch with no explicit order (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement":
+// workgroups are dealt round-robin over the 8 XCDs - b and b + 8 share one - and every XCD has its own L2).  The
+// robots an XCD steps are made a CONTIGUOUS range of the batch: the per-step rows the waves write ([step][robot][.]
+// arrays: 84-B observation rows, 48-B action rows - two or three robots per 128-B line) then meet their neighbours'
+// in ONE L2 instead of leaving three of them as partial lines.  Bijective for any count (the guide's T1 remap).
+// Speed / traffic only: robots are independent, any map gives the same results bit for bit.
+__host__ __device__ constexpr int xcd_contiguous(int b, int count) {
+  return ((b & 7) < (count & 7) ? (b & 7) * ((count >> 3) + 1) : (count & 7) * ((count >> 3) + 1) + ((b & 7) - (count & 7)) * (count >> 3)) + (b >> 3);
+}
+
 template <typename T>
 struct KBuffers {
   T* state;           // [N][32]
@@ -124,10 +134,12 @@ struct KBuffers {
   int32_t num_envs;    // total robots of the engine
   uint32_t flags;
   int32_t env_base;    // first robot of this launch (grid = robots of this launch)
+  int32_t count;       // robots of this launch (the XCD-aware workgroup -> robot map needs it: see xcd_contiguous)
   int32_t steps;       // env steps per launch (>= 1)
   // element strides between consecutive steps of a multi-step launch (0: reuse the buffer)
   long long action_stride, done_stride;
 #ifdef SOLO_STAMPS
+  int32_t stamp_row;           // (set by the kernel: the robot this wave steps)
   unsigned long long* stamps;  // [N][32] s_memtime stamps, DIAGNOSTIC builds only (make stamps):
                                // [0..15] absolute stamps of the launch's last step, [16+i] = ticks
                                // spent before stamp i summed over the launch's steps

@@ -50,14 +50,14 @@
 #define SOLO_STAMP(B, i)                                                                          \
   do {                                                                                            \
     if (((i) == 0 || (i) == 14) && solo::lane_id() == 0)                                          \
-      (B).stamps[(size_t)(solo::block_id() + (B).env_base) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+      (B).stamps[(size_t)(B).stamp_row * 32 + (i)] = __builtin_amdgcn_s_memtime();             \
   } while (0)
 #elif defined(SOLO_STAMPS)
 #define SOLO_STAMP(B, i)                                                                          \
   do {                                                                                            \
     if (solo::lane_id() == 0) {                                                                   \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                 \
-      (B).stamps[(size_t)(solo::block_id() + (B).env_base) * 32 + (i)] = t_;                      \
+      (B).stamps[(size_t)(B).stamp_row * 32 + (i)] = t_;                                            \
       (B).acc[(i)] += t_ - (B).acc[16];                                                           \
       (B).acc[16] = t_;                                                                           \
     }                                                                                             \
@@ -639,7 +639,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   if (lane == 0) {
     // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28
     const unsigned long long hw = (unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xfffff), xcc = (unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf);
-    B.stamps[(size_t)(block_id() + B.env_base) * 32 + 15] = (unsigned long long)(it & 0xffff) | ((unsigned long long)__builtin_popcountll(touching) << 16) | (xcc << 24) | (hw << 28);
+    B.stamps[(size_t)B.stamp_row * 32 + 15] = (unsigned long long)(it & 0xffff) | ((unsigned long long)__builtin_popcountll(touching) << 16) | (xcc << 24) | (hw << 28);
     B.acc[15] += (unsigned long long)it;
     B.acc[0] += (unsigned long long)n_changed;
   }
@@ -801,15 +801,24 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
   const int slot = block_id() * kG8 + wave_in_group + B.env_base;  // (the engine launches whole groups only)
 #else
   const int lane0 = lane_id();
-  // workgroup -> robot: the identity, or the cost-balanced launch order (solo_engine_set_order)
   const int slot = block_id() + B.env_base;
   if (slot >= B.num_envs) return;
 #endif
   // (wave_cold_args assumes the kernel's parameter layout - one pointer, then this block: checked on
   // two fields, so that a changed signature traps instead of reading garbage)
   if (wave_cold_args(Bin)->num_envs != B.num_envs || wave_cold_args(Bin)->steps != B.steps) __builtin_trap();
+  // workgroup -> robot: the cost-balanced launch order if one is set (solo_engine_set_order: dispatch position ->
+  // robot), else the XCD-contiguous map (xcd_contiguous, solo_kernel_params.h: the robots whose waves share an L2 are
+  // neighbours in the batch, so their rows of the [step][robot][.] arrays complete each other's cache lines there)
   const int32_t* order = wave_cold_args(Bin)->order;
+#ifdef SOLO_GROUP8
   const int env = order != nullptr ? wave_uniform(order[slot]) : slot;
+#else
+  const int env = order != nullptr ? wave_uniform(order[slot]) : B.env_base + xcd_contiguous(block_id(), B.count);
+#endif
+#ifdef SOLO_STAMPS
+  B.stamp_row = env;
+#endif
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
 #ifdef SOLO_STAMPS
   __shared__ unsigned long long s_acc[17];

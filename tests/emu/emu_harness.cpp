@@ -39,6 +39,9 @@ extern "C" int solo_emu_last_cost(int32_t* out, int n) {
   return m;
 }
 
+// the step kernel's workgroup -> robot map (solo_kernel_params.h), for tests/test_emu_kernel.py
+extern "C" int solo_emu_xcd_contiguous(int b, int count) { return solo::xcd_contiguous(b, count); }
+
 // steps > 1: one fused multi-step "launch" per robot (actions [steps][n][12], outputs [steps][n][.])
 template <typename T>
 static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* prog, int n,
@@ -93,7 +96,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   B.obs_rec_stride = (long long)n * D; B.reward_rec_stride = n; B.obs_from = 0;
   B.view_obs = B.view_reward = nullptr; B.view_done = nullptr;
   B.done = done; B.term_count = term_count; B.stats = stats;
-  B.num_envs = n; B.flags = flags; B.env_base = 0; B.steps = steps;
+  B.num_envs = n; B.flags = flags; B.env_base = 0; B.count = n; B.steps = steps;
   B.action_stride = (long long)n * SOLO_NUM_JOINTS; B.done_stride = n;
   const KParams<T>* Pp = &P;
   // the step kernel, output epilogue included: one emulated wavefront per robot (as Engine::launch_chain launches it)

@@ -244,3 +244,16 @@ def test_residual_threshold_exit_matches_oracle(dtype, tol):
   assert out[1e9][1] == n * len(acts)              # one sweep per robot-step
   assert out[1e-7][1] < 0.6 * out[0.0][1]          # far fewer sweeps than the fixed-point iteration ...
   assert np.abs(out[1e-7][0][:, :29] - out[0.0][0][:, :29]).max() < 5e-2   # ... for a nearby result
+
+
+def test_workgroup_to_robot_map_is_a_bijection_with_contiguous_ranges_per_xcd():
+  """xcd_contiguous (solo_kernel_params.h): workgroups b, b + 8, b + 16 ... - the ones that share an XCD - step a
+  contiguous range of robots, and every robot of the launch is stepped exactly once, for any launch size."""
+  import emu_kernel
+  lib = emu_kernel.load()
+  for count in (1, 2, 7, 8, 9, 13, 64, 100, 2048, 4096, 4097):
+    got = [lib.solo_emu_xcd_contiguous(b, count) for b in range(count)]
+    assert sorted(got) == list(range(count)), count
+    for x in range(min(8, count)):
+      mine = got[x::8]
+      assert mine == list(range(mine[0], mine[0] + len(mine))), (count, x)
