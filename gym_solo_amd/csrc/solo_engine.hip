@@ -412,7 +412,7 @@ struct Engine final : EngineBase {
   int set_order(const int32_t* o, hipStream_t s) override {
     HIP_TRY(hipSetDevice(device));
     if (o == nullptr) { use_order = false; return SOLO_OK; }
-    // The step kernel uses order[slot] as the robot index of every buffer it addresses, and the output kernels
+    // The step kernel uses order[slot] as the robot index of every buffer it addresses, and the output epilogues
     // of a rollout slice read the records of that slice's robots: the table is validated here, once per upload
     // (a rare call; blocking) - a permutation of [0, N) that maps every rollout slice onto itself.
     std::vector<int32_t> h((size_t)n);

@@ -972,9 +972,9 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
         B.traj[(unsigned)(env * B.steps + step) * (unsigned)SOLO_STATE_STRIDE + (unsigned)lane] = lane == SOLO_S_SPARE ? ev : word;
     }
     // closed-loop step() = a single-step launch: its outputs are evaluated right here with the
-    // same per-item functions the output kernels use (no second launch on the critical path of a
+    // same per-item functions the output epilogue uses (no second launch on the critical path of a
     // policy loop) - lane i takes observation element i / reward leaf i, lane 0 folds the reward
-    // (f32 only: in f64 - the parity path - every launch leaves records for the output kernels.  The library
+    // (f32 only: in f64 - the parity path - every launch leaves records for the output epilogue.  The library
     // atan2 / asin / exp of the f64 outputs need ~40 f64 constants, which the compiler kept live across the whole
     // step loop - and spilled: 36 scratch stores per lane at the top of every launch, 900 B of HBM writes per
     // env-step of a 20-step launch - for a code path fused launches never take.)

@@ -301,7 +301,9 @@ int solo_engine_set_params(SoloEngine* eng, int32_t which, const void* per_env_d
  * settle loop (the reset snapshot depends on the ground).  Synchronises the device. */
 int solo_engine_set_terrain(SoloEngine* eng, const SoloTerrain* terrain, void* stream);
 /* Launch order of the robots (cost-balanced scheduling): order_dev int32 [N], a permutation of 0..N-1
- * that maps workgroup b of a launch to robot order[b]; NULL = identity.  With cfg.rollout_streams = G
+ * that maps workgroup b of a launch to robot order[b]; NULL = the engine's own map (each of the 8 XCDs of the
+ * chip steps a contiguous eighth of the launch's robots, so that neighbouring robots' rows of the [K][N][.]
+ * arrays meet in one L2: HBM traffic, not results).  With cfg.rollout_streams = G
  * the positions [N g / G, N (g+1) / G) must hold a permutation of the same robot range (every slice
  * keeps its robots).  Results do not depend on the order (robots are independent); it matters when
  * N exceeds the 4096 resident waves of the chip: dispatching the costliest robots first (view.cost,
@@ -312,7 +314,7 @@ int solo_engine_set_order(SoloEngine* eng, const int32_t* order_dev, void* strea
 /* name of the dominant kernel (for rocprof cross-checks) and its last launch geometry */
 const char* solo_engine_kernel_name(SoloEngine* eng);
 /* Times a rollout of reps * steps_per_launch steps exactly as solo_engine_rollout runs it (same
- * slicing, same fused launches; the step kernel alone, without the output kernels) with hipEvents
+ * slicing, same fused launches; the step kernel, its output epilogue included) with hipEvents
  * recorded ON THE STREAMS THE KERNELS ARE LAUNCHED ON (every slice's internal stream when
  * rollout_streams > 1, else `stream`) and returns the mean milliseconds per LAUNCH over all slices;
  * one launch covers N / max(1, rollout_streams) robots x steps_per_launch steps.

@@ -119,7 +119,7 @@ def test_bad_arguments_raise(torch):
 def test_ragged_recording_rollout_with_slices_equals_single_steps(torch):
   """Everything at once: 777 robots on 3 stream slices, 23 steps in fused launches of 7 (the last
   one of 2), auto-reset inside a launch, every step's observation / reward / done recorded by the
-  output kernels - identical to 23 single-step launches (which evaluate their outputs in place)."""
+  output epilogue - identical to 23 single-step launches (which evaluate their outputs in place)."""
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
   out = {}
