@@ -352,7 +352,7 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
-  def timed(dtype, k, closed_loop, min_seconds, max_repeats, residual_threshold=0.0):
+  def timed(dtype, k, closed_loop, min_seconds, max_repeats, residual_threshold=0.0, steady=True):
     """Repeats of the K-step timed region on a fresh engine; returns per-repeat seconds (max over
     ranks), the summed episodic statistics of the timed repeats and the engine."""
     tdtype = torch.float32 if dtype == 'float32' else torch.float64
@@ -375,7 +375,8 @@ def main():
       else:
         eng.rollout(acts, abi.STEP_ALL, out=out)
 
-    desynchronise_episodes(eng, gen)
+    if steady:
+      desynchronise_episodes(eng, gen)
     out = None if closed_loop else eng.rollout_buffers(k)  # every step's obs / reward / done goes to HBM
     if w > 0:
       run(action_pool(w), None if closed_loop else eng.rollout_buffers(w))
@@ -463,6 +464,13 @@ def main():
                                     'configuration of `value`: '
                                     'without warm starting it leaves a resting robot jittering at 5e-5 rad/s, where the reference\'s recorded '
                                     'rest state has 1e-11')
+    # rounds 1-2 timed the first steps of 4096 synchronised episodes (every robot freshly reset, nobody terminating):
+    # the same kernels under that lighter regime, so that this round's line can be compared with theirs
+    tsy, _, _, esy, _, _, _ = timed(args.dtype, ke, False, 0.3, 10, steady=False)
+    extra['value_synchronised_start'] = world * n * ke / statistics.median(tsy)
+    extra['value_synchronised_start_note'] = ('the regime rounds 1-2 reported as `value`: all robots at the start of an episode (no steady-state '
+                                              'preparation, no episode ends inside the window); NOT the configuration of `value`')
+    esy._close()
     tcl, _, _, ecl, _, _, _ = timed(args.dtype, ke, True, 0.3, 10)
     extra['value_closed_loop'] = world * n * ke / statistics.median(tcl)
     extra['value_closed_loop_note'] = ('one solo_engine_step launch per env step (outputs evaluated in that launch), the '
