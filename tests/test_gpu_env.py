@@ -161,7 +161,7 @@ def test_fused_rollout_equals_single_steps(dtype):
 @pytest.mark.parametrize('spl,streams,k', [(1, 1, 5), (7, 1, 30), (7, 1, 21), (7, 2, 30), (20, 1, 20), (6, 2, 13)])
 def test_view_holds_the_last_step_of_a_recorded_rollout(dtype, spl, streams, k):
   """After solo_engine_rollout_record the engine's view (obs / reward / done) holds the LAST step's outputs,
-  whatever the launch geometry: the last launch's output kernel writes them (no copies after the chain),
+  whatever the launch geometry: the last launch's output epilogue writes them (no copies after the chain),
   a single-step f32 launch evaluates them in place and the rollout copies."""
   import torch
   from gym_solo_amd import abi
@@ -186,6 +186,51 @@ def test_view_holds_the_last_step_of_a_recorded_rollout(dtype, spl, streams, k):
   np.testing.assert_array_equal(eng.done.cpu().numpy(), done[-1].cpu().numpy())
   assert bool(done[-1].all()) and not bool(done[:-1].any())
   env._close()
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_step_is_capturable_in_a_hip_graph(dtype):
+  """The engine enqueues everything on the caller's stream and never synchronises inside step(): an RL library can
+  capture Solo8VanillaEnv.step() - next to its policy - in a torch.cuda.CUDAGraph.  Replays of the captured step
+  (actions read from a static buffer) equal eager step() calls bit for bit, auto-resets included (TimeBased(6): every
+  robot ends an episode inside the 10 steps).  (Measured with tools/gpu_graph_step.py: no time gained - the closed
+  loop is bound by the step kernel's slowest robot, not by launches.)"""
+  import torch
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  from gym_solo_amd.workloads import register_benchmark_workload
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  envs = []
+  for _ in range(2):
+    cfg = Solo8VanillaConfig()
+    cfg.dtype, cfg._dtype_pinned, cfg.auto_reset = dtype, True, True
+    env = make_env(config=cfg, copy_outputs=False)
+    register_benchmark_workload(env, max_steps=6)
+    env._ensure_program()
+    envs.append(env)
+  eager, captured = envs
+  n = eager.num_envs
+  g = torch.Generator(device='cuda').manual_seed(3)
+  acts = (torch.rand(10, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.28
+  static = torch.zeros(n, 12, device='cuda', dtype=tdt)
+  warm = torch.zeros(n, 12, device='cuda', dtype=tdt)
+  for env in envs:   # (first use of the launch outside the capture, the same step on both sides)
+    env.step(warm)
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):   # (capture does not execute: the engine's state is untouched)
+    obs_g, rew_g, done_g, _ = captured.step(static)
+  episodes = 0
+  for k in range(10):
+    obs_e, rew_e, done_e, _ = eager.step(acts[k])
+    static.copy_(acts[k])
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(obs_e, obs_g) and torch.equal(rew_e, rew_g) and torch.equal(done_e, done_g), k
+    assert torch.equal(eager.engine.state, captured.engine.state), k
+    episodes += int(done_e.sum())
+  assert episodes == n
+  for env in envs:
+    env._close()
 
 
 def test_domain_randomisation_matches_oracle():
