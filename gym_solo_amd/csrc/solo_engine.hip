@@ -387,15 +387,16 @@ struct Engine final : EngineBase {
   }
 
   int set_terrain(const SoloTerrain* t, hipStream_t s) override {
+    // (validated before anything is touched: a rejected call leaves the previous ground in force)
+    if (t && (t->nx < 2 || t->ny < 2 || !(t->cell > 0) || !t->heights || (long long)t->nx * t->ny > (1ll << 26))) {
+      err = "terrain needs nx, ny >= 2, cell > 0 and a heights array";
+      return SOLO_ERR_INVALID_ARG;
+    }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipDeviceSynchronize());
     if (terrain) { (void)hipFree(terrain); terrain = nullptr; }
     hparams.c.terr_nx = hparams.c.terr_ny = 0;
     if (t) {
-      if (t->nx < 2 || t->ny < 2 || !(t->cell > 0) || !t->heights || (long long)t->nx * t->ny > (1ll << 26)) {
-        err = "terrain needs nx, ny >= 2, cell > 0 and a heights array";
-        return SOLO_ERR_INVALID_ARG;
-      }
       const size_t cnt = (size_t)t->nx * t->ny;
       std::vector<T> h(cnt);
       for (size_t i = 0; i < cnt; ++i) h[i] = (T)t->heights[i];
@@ -487,7 +488,7 @@ extern "C" {
 // DIAGNOSTIC build only: copies the [N][32] s_memtime stamps of the last launch to the host.
 int solo_engine_debug_stamps(SoloEngine* eng, unsigned long long* host, int is_f32) {
   if (!eng || !eng->impl) return SOLO_ERR_INVALID_ARG;
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   if (is_f32) { auto* e = static_cast<Engine<float>*>(eng->impl); return hipMemcpy(host, e->stamps, (size_t)e->n * 256, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SOLO_ERR_HIP; }
   auto* e = static_cast<Engine<double>*>(eng->impl);
   return hipMemcpy(host, e->stamps, (size_t)e->n * 256, hipMemcpyDeviceToHost) == hipSuccess ? 0 : SOLO_ERR_HIP;

@@ -269,6 +269,37 @@ def test_invalid_launch_order_is_rejected(torch, streams):
   eng.close()
 
 
+def test_rejected_terrain_leaves_the_previous_ground_in_force(torch):
+  """solo_engine_set_terrain validates its argument BEFORE it touches anything: a degenerate grid or a non-positive
+  cell size is SOLO_ERR_INVALID_ARG (ValueError) and the engine keeps the heightfield - and the settle snapshot - it
+  had: it goes on stepping exactly like a twin that never saw the bad call."""
+  import helpers
+  engines = []
+  for _ in range(2):
+    eng, ca, ma = _engine(8, 'float64')
+    eng.set_terrain(helpers.incline_terrain())
+    engines.append(eng)
+  good = helpers.incline_terrain()
+  for field, value in (('nx', 1), ('ny', 1), ('cell', 0.0), ('cell', -1.0)):
+    bad = helpers.incline_terrain()
+    setattr(bad, field, value)
+    with pytest.raises(ValueError):
+      engines[0].set_terrain(bad)
+  acts = random_actions(np.random.default_rng(5), 8)
+  for eng in engines:
+    for _ in range(20):
+      eng.step(torch.as_tensor(acts, device='cuda'), abi.STEP_PHYSICS)
+    eng.synchronize()
+  np.testing.assert_array_equal(engines[0].state.cpu().numpy(), engines[1].state.cpu().numpy())
+  np.testing.assert_array_equal(engines[0].snapshot.cpu().numpy(), engines[1].snapshot.cpu().numpy())
+  flat, _, _ = _engine(8, 'float64')
+  assert not np.array_equal(engines[0].snapshot.cpu().numpy(), flat.snapshot.cpu().numpy())   # (the incline IS in force)
+  flat.close()
+  del good
+  for eng in engines:
+    eng.close()
+
+
 def test_fast_spin_takes_the_library_rotation_path(torch):
   """The f32 rotation update uses even Taylor polynomials in (|w| dt / 2)^2 and falls back to the
   library sincos above 1/16 (|w| > 500 rad/s): a base spinning at 300 / 700 rad/s in the air, one
