@@ -26,6 +26,14 @@
 //    multiplies), with no "anything pending?" test in the loop.  The slowest robot of a closed-loop
 //    step or a short launch runs all 50 sweeps with ~3 rows moving in each: one instruction per sweep
 //    is 1 % of such a step, one per row 1.5 % (measured);
+//  * few TAKEN branches on the slow robots' path (round 3): a taken branch costs a lone wave the refetch of its
+//    instruction stream (~27 cycles) on top of its issue slot.  Replayed on the emulator, the robot-steps that run to
+//    the sweep cap have, beyond their fifth sweep, work in (non-contact, normal, friction) rows = (no, yes, yes) in
+//    91 % of the sweeps, and their walks update 1 / 2 / 3 / 4 / 6 rows in 30 / 37 / 9 / 14 / 8 % of the cases.  So
+//    the sweep FALLS THROUGH into the normal rows when no motor / limit row moves (those rows are walked out of line)
+//    and the row update is unrolled twice with the odd exit in the middle: ~2.7 taken branches per such sweep instead
+//    of ~5.  Same-call A/B (profiles/round3_pgs_layout_ab.log): the driver's 20-step launch +1.9 % (kernel 0.383 ->
+//    0.373 ms), one launch per step +3.1 %, f64 20-step kernel -2 %, 250-step rollouts +0.5 %;
 //  * s_set_gpr_idx_on / s_set_gpr_idx_off are each FOLLOWED BY A SCALAR INSTRUCTION before the next vector instruction
 //    (round 3).  With the indexed v_fma directly behind s_set_gpr_idx_on (and the v_cndmask directly behind
 //    s_set_gpr_idx_off) the loop computed WAVE-DEPENDENT GARBAGE at two or more waves per SIMD in some builds - the
@@ -68,8 +76,7 @@ namespace solo {
 // register to initialise per phase.  Between a VALU write of an SGPR / VCC and the VALU read of it sit two
 // other instructions (the manual wait states of gfx940-class hardware; the assembler does not check
 // inline asm).
-#define SOLO_PGS_WALK(P, PH)                                                                       \
-  ".Lpgs_%=_" P "_row:\n\t"                                                                        \
+#define SOLO_PGS_ROW(PH)                                                                           \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
   "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
   "v_readlane_b32 %[sd], %[dl], %[rs]\n\t"    /* the change of its impulse */                      \
@@ -84,8 +91,22 @@ namespace solo {
   "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"                                                       \
   "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"                                                  \
   SOLO_PGS_COUNT_ROW                                                                               \
-  "s_and_b64 %[todo], %[pend], %[w]\n\t"                                                           \
-  "s_cbranch_scc1 .Lpgs_%=_" P "_row\n\t"
+  "s_and_b64 %[todo], %[pend], %[w]\n\t"
+
+
+// the walk over a phase's pending rows.  A TAKEN branch costs a lone wave ~27 cycles of instruction refetch on top of
+// its issue slot (tools/microbench/loop_align.hip: the 15-instruction row loop takes 120 ... 132 cycles per iteration,
+// the same instructions in a straight line 93), a branch that falls through ~4: the row update is therefore unrolled
+// twice, with the exit after an odd number of rows in the middle (walks of the robots that decide the length of a
+// launch - replayed on the emulator, tools/analyse_slow_steps.py - update 1 / 2 / 3 / 4 / 6 rows in 30 / 37 / 9 / 14 /
+// 8 % of the cases: 0.8 taken branches per walk instead of 1.5)
+#define SOLO_PGS_WALK(P, PH)                                                                       \
+  ".Lpgs_%=_" P "_row:\n\t"                                                                        \
+  SOLO_PGS_ROW(PH)                                                                                 \
+  "s_cbranch_scc0 .Lpgs_%=_" P "_out\n\t"                                                          \
+  SOLO_PGS_ROW(PH)                                                                                 \
+  "s_cbranch_scc1 .Lpgs_%=_" P "_row\n"                                                            \
+  ".Lpgs_%=_" P "_out:\n\t"
 
 // friction limits = mu x the normal impulse their contact holds NOW (the normal row sits one lane below its
 // first friction row, two below the second: DPP row shifts folded into the multiply; %[thr] is the
@@ -122,28 +143,26 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
       // jumped over): a loop whose head lies 0..4 dwords past a 32-byte boundary takes 120 cycles per
       // iteration, 5..7 dwords past it 128..132 (tools/microbench/loop_align.hip: instructions are fetched
       // in 32-byte blocks, and a taken branch into the tail of a block gets little from its first fetch).
-      // From this entry the row loops of the paths a slow robot takes start 0, 4 and 1 dwords past a boundary
-      // (p0, q1, p2; p1: 6).  Sixteen entry positions measured on the closed loop: 1.10 ... 1.15e8
-      // env-steps/s - without the pinning, every edit of the code in front of the loop moved all timings
+      // From this entry the branch targets of the path a slow robot takes - the sweep head and the row loops of the
+      // normal and the friction rows - lie 4, 0 and 1 dwords past a boundary, the out-of-line non-contact walk starts
+      // on one (its padding is never executed) and the normal rows behind it 4 dwords past one.  (Round 2 measured
+      // sixteen entry positions on the closed loop: 1.10 ... 1.15e8 env-steps/s - without the pinning, every edit of
+      // the code in front of the loop moved all timings.)
       "s_branch .Lpgs_%=_entry\n\t"
       ".p2align 6\n\t"
-      ".fill 12, 4, 0xbf800000\n"              // (s_nop 0)
+      ".fill 2, 4, 0xbf800000\n"               // (s_nop 0)
       ".Lpgs_%=_entry:\n\t"
       "s_sub_u32 %[it], 0, %[iters]\n\t"       // counts up to zero: the carry of the increment is "cap reached"
       "s_cbranch_scc0 .Lpgs_%=_done\n"          // (no sweeps allowed)
       ".Lpgs_%=_sweep:\n\t"
-      // ---- the non-contact rows (joint motors, joint limits), leg by leg
+      // The FALL-THROUGH path is the one the slow robots take: in the late sweeps of a creeping robot the non-contact
+      // rows (joint motors, joint limits) stand still and normal + friction rows move (91 % of the sweeps beyond the
+      // fifth of the robot-steps that run to the cap; all three phases: 8 %), so a sweep that finds no work there
+      // falls through both tests into the normal rows, and a sweep whose non-contact rows move takes that phase out
+      // of line (p0 ... below): one taken branch per sweep - the way back - instead of two.
       "s_and_b64 %[todo], %[pend], %[ph0]\n\t"
-      "s_cbranch_scc0 .Lpgs_%=_a1\n"
-      SOLO_PGS_WALK("p0", "%[ph0]")
-      // ---- all normal rows, then the friction limits
-      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
-      "s_cbranch_scc0 .Lpgs_%=_b2\n"            // no normal row moves in this sweep: the friction limits stand
-      SOLO_PGS_WALK("p1", "%[ph1]")
-      SOLO_PGS_LIMITS
-      "s_branch .Lpgs_%=_b2\n"
-      // (the same phase for a sweep that has found no work so far)
-      ".Lpgs_%=_a1:\n\t"
+      "s_cbranch_scc1 .Lpgs_%=_p0\n\t"
+      // ---- all normal rows, then the friction limits (a sweep that has found no work so far)
       "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
       "s_cbranch_scc0 .Lpgs_%=_a2\n"
       SOLO_PGS_WALK("q1", "%[ph1]")
@@ -160,7 +179,18 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
       "s_branch .Lpgs_%=_done\n"
       ".Lpgs_%=_a2:\n\t"                        // (no work in the first two phases)
       "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
-      "s_cbranch_scc1 .Lpgs_%=_p2\n"            // (else: nothing pending at the start of a sweep - converged)
+      "s_cbranch_scc1 .Lpgs_%=_p2\n\t"
+      "s_branch .Lpgs_%=_done\n"                 // (nothing pending at the start of a sweep: converged)
+      // ---- out of line: the non-contact rows (joint motors, joint limits), leg by leg, then the normal rows of
+      //      a sweep that has found work
+      ".p2align 5\n"                            // (never executed: behind an unconditional branch)
+      ".Lpgs_%=_p0:\n"
+      SOLO_PGS_WALK("p0", "%[ph0]")
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs_%=_b2\n"            // no normal row moves in this sweep: the friction limits stand
+      SOLO_PGS_WALK("p1", "%[ph1]")
+      SOLO_PGS_LIMITS
+      "s_branch .Lpgs_%=_b2\n"
       ".Lpgs_%=_done:\n\t"
       : [v] "+v"(v), [lam] "+v"(lam), [cand] "+v"(cand), [dl] "+v"(dl), [lo] "+v"(lo), [hi] "+v"(hi), [pend] "+s"(pend),
         [thr] "=&v"(thr), [x1] "=&v"(x1), [x2] "=&v"(x2),
@@ -181,6 +211,7 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 
 #undef SOLO_PGS_LIMITS
 #undef SOLO_PGS_WALK
+#undef SOLO_PGS_ROW
 
 // ---- the same loop in f64 (round 3): the reference's precision, the parity path ---------------------------
 // Columns: 64 doubles per lane in v[128:255] (ColumnBank<double>: four 16-wide tuples), column r = v[128 + 2 r :
@@ -191,8 +222,7 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 // 19 instructions per updated row (the compiler's loop over LDS-evaluated columns: ~40), no v_med3 in f64:
 // v_max_f64 + v_min_f64, exactly Real<double>::clamp.  Same rows, same order, same arithmetic as the C++ loop
 // (tests/test_gpu_pgs_asm.py compares the two bit for bit in f64 too).
-#define SOLO_PGS_WALK64(P, PH)                                                                     \
-  ".Lpgs64_%=_" P "_row:\n\t"                                                                      \
+#define SOLO_PGS_ROW64(PH)                                                                         \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
   "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
   "v_readlane_b32 s94, v118, %[rs]\n\t"       /* the change of its impulse */                      \
@@ -211,8 +241,16 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
   "v_add_f64 v[118:119], v[116:117], -v[114:115]\n\t"                                              \
   "v_cmp_gt_f64_e64 %[pend], |v[118:119]|, %[thr]\n\t"                                             \
   SOLO_PGS_COUNT_ROW                                                                               \
-  "s_and_b64 %[todo], %[pend], %[w]\n\t"                                                           \
-  "s_cbranch_scc1 .Lpgs64_%=_" P "_row\n\t"
+  "s_and_b64 %[todo], %[pend], %[w]\n\t"
+
+
+#define SOLO_PGS_WALK64(P, PH)                                                                     \
+  ".Lpgs64_%=_" P "_row:\n\t"                                                                      \
+  SOLO_PGS_ROW64(PH)                                                                               \
+  "s_cbranch_scc0 .Lpgs64_%=_" P "_out\n\t"                                                        \
+  SOLO_PGS_ROW64(PH)                                                                               \
+  "s_cbranch_scc1 .Lpgs64_%=_" P "_row\n"                                                          \
+  ".Lpgs64_%=_" P "_out:\n\t"
 
 // friction limits = mu x the normal impulse their contact holds now (DPP row shifts of the two dwords)
 #define SOLO_PGS_LIMITS64                                                                          \
@@ -243,22 +281,19 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, dou
   asm volatile(
       "s_branch .Lpgs64_%=_entry\n\t"
       ".p2align 6\n\t"
-      ".fill 12, 4, 0xbf800000\n"              // (s_nop 0: the loops at a fixed position within the 64-byte instruction lines)
+      ".fill 6, 4, 0xbf800000\n"               // (s_nop 0: the loops at a fixed position within the 64-byte instruction lines)
       ".Lpgs64_%=_entry:\n\t"
       "s_sub_u32 %[it], 0, %[iters]\n\t"       // counts up to zero: the carry of the increment is "cap reached"
       "s_cbranch_scc0 .Lpgs64_%=_done\n"        // (no sweeps allowed)
       ".Lpgs64_%=_sweep:\n\t"
-      // ---- the non-contact rows (joint motors, joint limits), leg by leg
+      // The FALL-THROUGH path is the one the slow robots take: in the late sweeps of a creeping robot the non-contact
+      // rows (joint motors, joint limits) stand still and normal + friction rows move (91 % of the sweeps beyond the
+      // fifth of the robot-steps that run to the cap; all three phases: 8 %), so a sweep that finds no work there
+      // falls through both tests into the normal rows, and a sweep whose non-contact rows move takes that phase out
+      // of line (p0 ... below): one taken branch per sweep - the way back - instead of two.
       "s_and_b64 %[todo], %[pend], %[ph0]\n\t"
-      "s_cbranch_scc0 .Lpgs64_%=_a1\n"
-      SOLO_PGS_WALK64("p0", "%[ph0]")
-      // ---- all normal rows, then the friction limits
-      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
-      "s_cbranch_scc0 .Lpgs64_%=_b2\n"          // no normal row moves in this sweep: the friction limits stand
-      SOLO_PGS_WALK64("p1", "%[ph1]")
-      SOLO_PGS_LIMITS64
-      "s_branch .Lpgs64_%=_b2\n"
-      ".Lpgs64_%=_a1:\n\t"                      // (the same phase for a sweep that has found no work so far)
+      "s_cbranch_scc1 .Lpgs64_%=_p0\n\t"
+      // ---- all normal rows, then the friction limits (a sweep that has found no work so far)
       "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
       "s_cbranch_scc0 .Lpgs64_%=_a2\n"
       SOLO_PGS_WALK64("q1", "%[ph1]")
@@ -271,11 +306,22 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, dou
       SOLO_PGS_WALK64("p2", "%[ph2]")
       ".Lpgs64_%=_next:\n\t"
       "s_add_u32 %[it], %[it], 1\n\t"
-      "s_cbranch_scc0 .Lpgs64_%=_sweep\n\t"     // (no carry: below the sweep cap)
+      "s_cbranch_scc0 .Lpgs64_%=_sweep\n\t"       // (no carry: below the sweep cap)
       "s_branch .Lpgs64_%=_done\n"
-      ".Lpgs64_%=_a2:\n\t"                      // (no work in the first two phases)
+      ".Lpgs64_%=_a2:\n\t"                        // (no work in the first two phases)
       "s_and_b64 %[todo], %[pend], %[ph2]\n\t"
-      "s_cbranch_scc1 .Lpgs64_%=_p2\n"          // (else: nothing pending at the start of a sweep - converged)
+      "s_cbranch_scc1 .Lpgs64_%=_p2\n\t"
+      "s_branch .Lpgs64_%=_done\n"                 // (nothing pending at the start of a sweep: converged)
+      // ---- out of line: the non-contact rows (joint motors, joint limits), leg by leg, then the normal rows of
+      //      a sweep that has found work
+      ".p2align 5\n"                            // (never executed: behind an unconditional branch)
+      ".Lpgs64_%=_p0:\n"
+      SOLO_PGS_WALK64("p0", "%[ph0]")
+      "s_and_b64 %[todo], %[pend], %[ph1]\n\t"
+      "s_cbranch_scc0 .Lpgs64_%=_b2\n"            // no normal row moves in this sweep: the friction limits stand
+      SOLO_PGS_WALK64("p1", "%[ph1]")
+      SOLO_PGS_LIMITS64
+      "s_branch .Lpgs64_%=_b2\n"
       ".Lpgs64_%=_done:\n\t"
       : [v] "+v"(v), "={v[114:115]}"(lam_o), "={v[116:117]}"(cand_o), "={v[118:119]}"(dl_o), "={v[120:121]}"(lo_o), "={v[122:123]}"(hi_o),
         "={v[124:125]}"(x1), "={v[126:127]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
@@ -295,6 +341,7 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, dou
 
 #undef SOLO_PGS_LIMITS64
 #undef SOLO_PGS_WALK64
+#undef SOLO_PGS_ROW64
 #undef SOLO_PGS_COUNT_ROW
 
 }  // namespace solo
