@@ -36,6 +36,28 @@ def test_physics_matches_oracle(dtype, tol):
   np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=tol)
 
 
+@pytest.mark.parametrize('seed', range(4))
+def test_random_configurations_match_oracle(seed):
+  """Every configuration field the reference exposes (configs.py:8-38: dt, torque limit, start pose, gravity,
+  damping, friction) and the engine's own knobs at a random point of their ranges (tests/config_space.py): the
+  kernel source on the emulator against the oracle, from the oracle's post-settle state, 25 random-action steps
+  (the GPU twin of this test also runs the settle loop from the tilted start pose: tests/test_gpu_physics.py)."""
+  from config_space import random_config
+  kw = random_config(seed)
+  ca, ma = make_abi('float64', **kw)
+  ph = so.OraclePhysics(ca, ma)
+  n = 2
+  st = np.tile(ph.settle(1), (n, 1))
+  e = EmuEngine(ca, ma, n)
+  e.state[:] = st
+  rng = np.random.default_rng(100 + seed)
+  for k in range(25):
+    a = random_actions(rng, n)
+    ph.step(st, a)
+    e.step(a, abi.STEP_PHYSICS)
+  np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=1e-10, err_msg=str(kw))
+
+
 def test_fused_rollout_equals_single_steps():
   """steps_per_launch > 1 is the same arithmetic: bit-identical trajectories and outputs,
   including an auto-reset in the middle of the fused launch."""

@@ -60,6 +60,31 @@ def test_random_rollout_matches_oracle_f64(torch):
   eng.close()
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_random_configurations_match_oracle_f64(torch, seed):
+  """Every configuration field the reference exposes (configs.py:8-38: dt, torque limit, start pose, gravity,
+  damping, friction) and the engine's own knobs, at a random point of their ranges (tests/config_space.py): the settle
+  loop from the tilted start pose under the tilted gravity, then 30 random-action steps - f64 engine vs oracle."""
+  from gym_solo_amd.engine import Engine
+  from oracle import solo_oracle as so
+  from config_space import random_config
+  kw = random_config(seed)
+  ca, ma = make_abi('float64', **kw)
+  n = 32
+  eng = Engine(ca, ma, n)
+  ph = so.OraclePhysics(ca, ma)
+  ref = ph.settle(1)
+  np.testing.assert_allclose(eng.snapshot.cpu().numpy()[:, :29], np.tile(ref[:, :29], (n, 1)), rtol=0, atol=1e-9, err_msg=str(kw))
+  st = eng.state.cpu().numpy().copy()
+  rng = np.random.default_rng(100 + seed)
+  for k in range(30):
+    a = random_actions(rng, n)
+    ph.step(st, a)
+    eng.step(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+  np.testing.assert_allclose(eng.state.cpu().numpy()[:, :29], st[:, :29], rtol=0, atol=1e-9, err_msg=str(kw))
+  eng.close()
+
+
 def test_single_step_f32(torch):
   from gym_solo_amd.engine import Engine
   from oracle import solo_oracle as so
