@@ -85,6 +85,39 @@ def test_random_configurations_match_oracle_f64(torch, seed):
   eng.close()
 
 
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_random_configuration_terrain_and_parameters_together_f64(torch, seed):
+  """The extensions TOGETHER with a non-default configuration: a random point of the configuration space
+  (tests/config_space.py), a bumpy heightfield and per-robot friction / base-mass scale (BASELINE configs[3] + [4] on
+  one engine) - settle on the terrain with the randomised robots, then 25 random-action steps, f64 engine vs oracle."""
+  import helpers
+  from gym_solo_amd.engine import Engine
+  from oracle import solo_oracle as so
+  from config_space import random_config
+  kw = random_config(seed)
+  ca, ma = make_abi('float64', **kw)
+  n = 16
+  rng = np.random.default_rng(200 + seed)
+  terrain = helpers.bumpy_terrain(seed=seed)
+  params = np.zeros((n, 4))
+  params[:, 0] = rng.uniform(0.3, 1.0, n)
+  params[:, 1] = rng.uniform(0.8, 1.2, n)
+  eng = Engine(ca, ma, n)
+  eng.set_params(abi.PARAM_FRICTION, torch.as_tensor(params[:, 0], device='cuda').contiguous())
+  eng.set_params(abi.PARAM_BASE_MASS_SCALE, torch.as_tensor(params[:, 1], device='cuda').contiguous())
+  eng.set_terrain(terrain)   # (re-runs the settle loop: on the new ground, with the per-robot parameters)
+  ph = so.OraclePhysics(ca, ma, terrain=terrain)
+  st = ph.settle(n, params=params)
+  np.testing.assert_allclose(eng.snapshot.cpu().numpy()[:, :29], st[:, :29], rtol=0, atol=1e-8, err_msg=str(kw))
+  st = eng.state.cpu().numpy().copy()
+  for k in range(25):
+    a = random_actions(rng, n)
+    ph.step(st, a, params=params)
+    eng.step(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+  np.testing.assert_allclose(eng.state.cpu().numpy()[:, :29], st[:, :29], rtol=0, atol=3e-8, err_msg=str(kw))
+  eng.close()
+
+
 def test_single_step_f32(torch):
   from gym_solo_amd.engine import Engine
   from oracle import solo_oracle as so
