@@ -141,6 +141,36 @@ def test_single_step_f32(torch):
   eng.close()
 
 
+@pytest.mark.parametrize('seed', range(8))
+def test_single_step_f32_over_random_configurations(torch, seed):
+  """The f32 kernel - the throughput headline - at random points of the configuration space (tests/config_space.py):
+  one step of the f32 engine against the f64 oracle from the engine's own state after 40 decorrelating steps.
+  Measured over the 8 points: positions / quaternion / joint angles 1.2e-7 ... 2.8e-7, velocities 2e-5 ... 1.5e-4
+  (they see the solver's round-off scaled by 1 / dt); the bounds are ~10x that."""
+  from gym_solo_amd.engine import Engine
+  from oracle import solo_oracle as so
+  from config_space import random_config
+  kw = random_config(seed)
+  ca, ma = make_abi('float32', **kw)
+  ca64, _ = make_abi('float64', **kw)
+  n = 256
+  eng = Engine(ca, ma, n)
+  ph = so.OraclePhysics(ca64, ma)
+  rng = np.random.default_rng(seed)
+  for k in range(40):
+    eng.step(torch.as_tensor(random_actions(rng, n), device='cuda', dtype=torch.float32), abi.STEP_PHYSICS)
+  st = eng.state.cpu().numpy().astype(np.float64)
+  a = random_actions(rng, n).astype(np.float32)
+  ph.step(st, a.astype(np.float64))
+  eng.step(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+  got = eng.state.cpu().numpy().astype(np.float64)
+  assert np.isfinite(got[:, :29]).all()
+  err = np.abs(got[:, :29] - st[:, :29])
+  assert err[:, :15].max() < 3e-6, (kw, err[:, :15].max())
+  assert err[:, 15:29].max() < 2e-3, (kw, err[:, 15:29].max())
+  eng.close()
+
+
 def _sway_actions(k, n):
   """Smooth stand-up and sway (contact-rich, not chaotic: a 1e-9 perturbation of the start state
   stays below 1e-6 over the 1000 steps on the f64 oracle; larger / faster sways turn into a
