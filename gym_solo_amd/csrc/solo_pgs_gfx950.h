@@ -47,9 +47,14 @@
 //    the rows beyond it) sit in the two shadows.  tests/test_gpu_physics.py::test_identical_robots_stay_identical
 //    guards it.  (The compiler's own s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off sequences - dynamically indexed
 //    local arrays - have the same shape: the kernel no longer contains any.)
-//    A stand-alone loop of this shape does NOT reproduce the failure (tools/microbench/gpr_idx_hazard.hip: 3.5e9 row
-//    updates, every order / context / alignment clean): the adjacency is necessary on the failing build, not sufficient
-//    in general, and the mechanism is not established - the regression test is what the product relies on.
+//    Probed on the step kernel itself (tools/gpu_hazard_probe.py, -DSOLO_PGS_HAZARD_PROBE=n builds of this file: the
+//    ROW variants below; profiles/round3_hazard_probe.log): only the adjacency s_set_gpr_idx_on -> indexed v_fma
+//    matters (s_nop or the cursor shift behind s_set_gpr_idx_on cure it; s_nop in front of it or behind
+//    s_set_gpr_idx_off do not); the compiler's shape - an indexed v_mov_b32 behind the switch - passes; and with the
+//    accumulator of `v_fma_f32 vD, v[64 + idx], s, vD` pinned, vD = v6 / v8 pass and v7 / v9 / v11 FAIL, in every
+//    kernel: round 2's product was right because the allocator had picked v8.  Stand-alone loops of the same shape,
+//    down to the register numbers (tools/microbench/gpr_idx_hazard*.hip), never fail: the mechanism is not established.
+//    The rule here is the conservative one - no vector instruction in the shadow of either mode switch.
 //  * the manual wait states of gfx940-class hardware are respected by construction (>= 2 instructions
 //    between a VALU write of an SGPR / VCC and a VALU read of it, >= 2 between a VALU write and a DPP
 //    read, >= 1 before a v_readlane of a freshly written VGPR) - the assembler does not check them
@@ -76,6 +81,59 @@ namespace solo {
 // register to initialise per phase.  Between a VALU write of an SGPR / VCC and the VALU read of it sit two
 // other instructions (the manual wait states of gfx940-class hardware; the assembler does not check
 // inline asm).
+#if defined(SOLO_PGS_HAZARD_PROBE) && SOLO_PGS_HAZARD_PROBE > 0
+// DIAGNOSTIC builds only (tools/gpu_hazard_probe.py; never the product): round 2's order of the row update - the indexed
+// v_fma directly behind s_set_gpr_idx_on, the v_cndmask directly behind s_set_gpr_idx_off - with an s_nop in the first
+// (probe 2), the second (probe 3) or neither shadow (probe 1), to see on the step kernel itself which adjacency matters
+// probes: 1 = round 2's order; 2 = + s_nop behind s_set_gpr_idx_on; 3 = + s_nop behind s_set_gpr_idx_off; 4 = + s_nop IN FRONT
+// of s_set_gpr_idx_on; 5 = the cursor shift behind s_set_gpr_idx_on (the product's first shadow), the second shadow
+// empty; 6 = the compiler's own shape - s_set_gpr_idx_on / indexed v_mov_b32 / s_set_gpr_idx_off - and the v_fma on the
+// moved value; 7 = as 6 with s_nop behind s_set_gpr_idx_on
+#if SOLO_PGS_HAZARD_PROBE == 8      /* round 2's order with the accumulator / the broadcast pinned to the registers of the kernels that PASS */
+#define SOLO_PGS_V_CONSTRAINT "+{v8}"
+#define SOLO_PGS_SD_CONSTRAINT "=&{s66}"
+#elif SOLO_PGS_HAZARD_PROBE == 9    /* ... and to the registers of the kernels that FAIL */
+#define SOLO_PGS_V_CONSTRAINT "+{v7}"
+#define SOLO_PGS_SD_CONSTRAINT "=&{s64}"
+#elif SOLO_PGS_HAZARD_PROBE >= 10   /* -DSOLO_PGS_PROBE_V=... -DSOLO_PGS_PROBE_SD=...: any pair */
+#define SOLO_PGS_STR2(x) #x
+#define SOLO_PGS_STR(x) SOLO_PGS_STR2(x)
+#define SOLO_PGS_V_CONSTRAINT "+{" SOLO_PGS_STR(SOLO_PGS_PROBE_V) "}"
+#define SOLO_PGS_SD_CONSTRAINT "=&{" SOLO_PGS_STR(SOLO_PGS_PROBE_SD) "}"
+#endif
+#define SOLO_PGS_PROBE_SHIFT "s_lshl_b64 %[t], -2, %[rs]\n\t"
+#define SOLO_PGS_PROBE_IDX_ON "s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n\t"
+#define SOLO_PGS_PROBE_FMA "v_fma_f32 %[v], v64, %[sd], %[v]\n\ts_set_gpr_idx_off\n\t"
+#define SOLO_PGS_PROBE_MOV_FMA "v_mov_b32_e32 %[thr], v64\n\ts_set_gpr_idx_off\n\tv_fma_f32 %[v], %[thr], %[sd], %[v]\n\t"
+#if SOLO_PGS_HAZARD_PROBE == 2
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_IDX_ON "s_nop 0\n\t" SOLO_PGS_PROBE_FMA
+#elif SOLO_PGS_HAZARD_PROBE == 3
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_IDX_ON SOLO_PGS_PROBE_FMA "s_nop 0\n\t"
+#elif SOLO_PGS_HAZARD_PROBE == 4
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT "s_nop 0\n\t" SOLO_PGS_PROBE_IDX_ON SOLO_PGS_PROBE_FMA
+#elif SOLO_PGS_HAZARD_PROBE == 5
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_IDX_ON SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_FMA
+#elif SOLO_PGS_HAZARD_PROBE == 6
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_IDX_ON SOLO_PGS_PROBE_MOV_FMA
+#elif SOLO_PGS_HAZARD_PROBE == 7
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_IDX_ON "s_nop 0\n\t" SOLO_PGS_PROBE_MOV_FMA
+#else
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_IDX_ON SOLO_PGS_PROBE_FMA
+#endif
+#define SOLO_PGS_ROW(PH)                                                                           \
+  "s_ff1_i32_b64 %[rs], %[todo]\n\t"                                                               \
+  "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
+  "v_readlane_b32 %[sd], %[dl], %[rs]\n\t"                                                         \
+  SOLO_PGS_PROBE_CORE                                                                              \
+  "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n\t"                                             \
+  "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n\t"                                                     \
+  "v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n\t"                                                     \
+  "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"                                                       \
+  "s_and_b64 %[w], " PH ", %[t]\n\t"                                                               \
+  "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"                                                  \
+  SOLO_PGS_COUNT_ROW                                                                               \
+  "s_and_b64 %[todo], %[pend], %[w]\n\t"
+#else
 #define SOLO_PGS_ROW(PH)                                                                           \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
   "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
@@ -92,7 +150,7 @@ namespace solo {
   "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"                                                  \
   SOLO_PGS_COUNT_ROW                                                                               \
   "s_and_b64 %[todo], %[pend], %[w]\n\t"
-
+#endif
 
 // the walk over a phase's pending rows.  A TAKEN branch costs a lone wave ~27 cycles of instruction refetch on top of
 // its issue slot (tools/microbench/loop_align.hip: the 15-instruction row loop takes 120 ... 132 cycles per iteration,
@@ -121,6 +179,10 @@ namespace solo {
   "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"                                                       \
   "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"
 
+#ifndef SOLO_PGS_V_CONSTRAINT
+#define SOLO_PGS_V_CONSTRAINT "+v"
+#define SOLO_PGS_SD_CONSTRAINT "=&s"
+#endif
 // Runs the sweeps.  In: v (candidates at lam = 0), lam = 0, cand = clamp(v), dl = cand - lam, pend = rows
 // above the tolerance, lo / hi (friction rows: refreshed here from their normal row's impulse), the
 // resident columns.  Out: lam (the impulses), returns the number of sweeps.
@@ -192,9 +254,9 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
       SOLO_PGS_LIMITS
       "s_branch .Lpgs_%=_b2\n"
       ".Lpgs_%=_done:\n\t"
-      : [v] "+v"(v), [lam] "+v"(lam), [cand] "+v"(cand), [dl] "+v"(dl), [lo] "+v"(lo), [hi] "+v"(hi), [pend] "+s"(pend),
+      : [v] SOLO_PGS_V_CONSTRAINT(v), [lam] "+v"(lam), [cand] "+v"(cand), [dl] "+v"(dl), [lo] "+v"(lo), [hi] "+v"(hi), [pend] "+s"(pend),
         [thr] "=&v"(thr), [x1] "=&v"(x1), [x2] "=&v"(x2),
-        [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [sd] "=&s"(sd), [it] "=&s"(it)
+        [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [sd] SOLO_PGS_SD_CONSTRAINT(sd), [it] "=&s"(it)
 #ifdef SOLO_STAMPS
         , [nch] "+s"(n_changed)
 #endif

@@ -585,6 +585,15 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #ifdef SOLO_STAMPS
     n_changed = rows_updated;
 #endif
+#if defined(SOLO_PGS_HAZARD_PROBE)
+    // DIAGNOSTIC builds only: is the register-index mode still ON behind the loop?  (MODE[27] = gpr_idx_en; counted in
+    // slot 7 of the statistics row, and switched off so that nothing behind the loop computes with it)
+    {
+      const unsigned stuck = __builtin_amdgcn_s_getreg((0 << 11) | (27 << 6) | 1);
+      asm volatile("s_set_gpr_idx_off\n\ts_nop 1");
+      if (stuck != 0 && lane == 0) stats_add(&B.stats[7], 1.0);
+    }
+#endif
   }
 #else
 #pragma unroll 1

@@ -32,6 +32,18 @@
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 
+// the register of the accumulator - destination and third source of the indexed v_fma - can be pinned:
+//   hipcc ... -DACC_REG=v7    (default: the compiler's choice; the kernels below happen to get an EVEN register)
+#define HZ_STR2(x) #x
+#define HZ_STR(x) HZ_STR2(x)
+#ifdef ACC_REG
+#define ACC_CONSTRAINT "+{" HZ_STR(ACC_REG) "}"
+#define ACC_NAME HZ_STR(ACC_REG)
+#else
+#define ACC_CONSTRAINT "+v"
+#define ACC_NAME "compiler's choice"
+#endif
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 
 enum Order { kOld, kNew, kNopOn, kNopOff, kNopBoth, kOrders };
@@ -67,7 +79,7 @@ static const char* kOrderName[kOrders] = {
       "s_and_b64 %[todo], %[pend], %[w]\n\t"                                                       \
       "s_sub_u32 %[it], %[it], 1\n\t"                                                              \
       "s_cbranch_scc0 .Lhz_%=_loop\n\t"           /* (borrow set when it goes below zero) */       \
-      : [acc] "+v"(acc), [chk] "+v"(chk), [keep] "+v"(keep), [rs] "+s"(rs), [it] "+s"(it), [sd] "=&s"(sd), [t] "=&s"(t), \
+      : [acc] ACC_CONSTRAINT(acc), [chk] "+v"(chk), [keep] "+v"(keep), [rs] "+s"(rs), [it] "+s"(it), [sd] "=&s"(sd), [t] "=&s"(t), \
         [w] "=&s"(w), [pend] "=&s"(pend), [todo] "=&s"(todo), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3) \
       : [lanef] "v"(lanef), [lane] "v"(lane), [keep2] "v"(keep2), [lo] "v"(lo), [hi] "v"(hi), [ph] "s"(ph), [pad] "i"(PAD), \
         "{v[64:95]}"(a0), "{v[96:127]}"(a1)                                                        \
@@ -178,6 +190,7 @@ int main() {
   CHECK(hipMalloc(&d_src, 4096 * sizeof(float)));
   CHECK(hipMemset(d_src, 0, 4096 * sizeof(float)));
   std::vector<float> h((size_t)max_blocks * 64 * 4);
+  printf("accumulator register of the indexed v_fma: %s\n", ACC_NAME);
   printf("every measured wave: %d row updates; expected acc = %lld, chk = 0, keep = 7 in every lane; 128 VGPRs per wave "
          "(4 waves per SIMD resident)\n", iters, (long long)(iters / 64) * 85344ll);
   for (int ctx = 0; ctx < 2; ++ctx) {
