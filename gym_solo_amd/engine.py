@@ -263,6 +263,29 @@ class Engine:
   def synchronize(self):
     self._torch.cuda.synchronize(self.device)
 
+  # ---- checkpoint / resume (the reference has none - reset() rebuilds the world; here the
+  #      whole simulation is a handful of device tensors) --------------------------------------------------------
+  _CHECKPOINT = ('state', 'targets', 'term_count', 'params', 'stats_shards', 'cost')
+
+  def get_state(self):
+    """Everything a run continues from, as clones on the device: the robots' state records (episodic return / length
+    accumulators included), the commanded motor targets, the TimeBased counters, the per-robot parameters, the
+    episodic statistics and the per-robot solver cost (which decides a closed-loop launch's wave priorities, not
+    results).  The reset snapshot is NOT part of it: it is a function of configuration, parameters and terrain."""
+    self._torch.cuda.current_stream(self.device).synchronize()
+    return {name: getattr(self, name).clone() for name in self._CHECKPOINT}
+
+  def set_state(self, checkpoint):
+    """Restores a get_state() checkpoint (of an engine with the same number of robots and precision): the next step
+    continues bit for bit where the checkpointed run would have."""
+    for name in self._CHECKPOINT:
+      src, dst = checkpoint[name], getattr(self, name)
+      if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
+        raise ValueError('checkpoint field {!r} has shape {} / dtype {}, the engine has {} / {}'.format(
+          name, tuple(src.shape), src.dtype, tuple(dst.shape), dst.dtype))
+    for name in self._CHECKPOINT:
+      getattr(self, name).copy_(checkpoint[name])
+
   def close(self):
     """solo_engine_destroy: frees every device buffer.  Tensors handed out earlier dangle."""
     if getattr(self, '_h', None):

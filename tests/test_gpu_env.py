@@ -233,6 +233,50 @@ def test_step_is_capturable_in_a_hip_graph(dtype):
     env._close()
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_checkpoint_and_resume_continue_bit_for_bit(dtype):
+  """Engine.get_state() / set_state() (checkpoint / resume): a run checkpointed after 30 steps -
+  mid-episode, with per-robot parameters and non-trivial counters - and restored into a FRESH engine continues exactly
+  like the original: states, observations, rewards, done flags and the episodic statistics of 40 more steps (an
+  episode end and its auto-reset among them)."""
+  import torch
+  from gym_solo_amd import abi
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  from gym_solo_amd.workloads import register_benchmark_workload
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  def build():
+    cfg = Solo8VanillaConfig()
+    cfg.dtype, cfg._dtype_pinned, cfg.auto_reset, cfg.steps_per_launch = dtype, True, True, 10
+    env = make_env(config=cfg, copy_outputs=False)
+    register_benchmark_workload(env, max_steps=50)
+    env._ensure_program()
+    return env
+  g = torch.Generator(device='cuda').manual_seed(4)
+  first, second = build(), build()
+  n = first.num_envs
+  acts = (torch.rand(70, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.28
+  mu = torch.rand(n, device='cuda', dtype=tdt, generator=g) * 0.7 + 0.3
+  for env in (first, second):   # (parameters and terrain belong to the configuration of an engine, not to the checkpoint)
+    env.engine.set_params(abi.PARAM_FRICTION, mu)
+  first.engine.rollout(acts[:30], abi.STEP_ALL)
+  ck = first.engine.get_state()
+  want = first.engine.rollout(acts[30:], abi.STEP_ALL, record=True)
+  first.engine.synchronize()
+  want_state, want_stats = first.engine.state.clone(), first.engine.stats.clone()
+  assert int(want[2].sum()) == n                 # every robot ended an episode in the continued part
+  second.engine.set_state(ck)
+  got = second.engine.rollout(acts[30:], abi.STEP_ALL, record=True)
+  second.engine.synchronize()
+  for a, b in zip(want, got):
+    assert torch.equal(a, b)
+  assert torch.equal(want_state, second.engine.state) and torch.equal(want_stats, second.engine.stats)
+  with pytest.raises(ValueError):
+    bad = dict(ck); bad['state'] = ck['state'][:-1]
+    second.engine.set_state(bad)
+  for env in (first, second):
+    env._close()
+
+
 def test_domain_randomisation_matches_oracle():
   """BASELINE config 4: per-env lateral friction and base-mass scale (changeDynamics per env,
   solo8v2vanilla.py:158-163) — engine.set_params + re-settle vs the oracle with the same params."""
