@@ -289,7 +289,9 @@ def main():
   ap.add_argument('--steps', type=int, default=3000)
   ap.add_argument('--warmup', type=int, default=250)
   ap.add_argument('--envs-per-gpu', type=int, default=4096)
-  ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
+  ap.add_argument('--dtype', default='float64', choices=['float32', 'float64'],
+                  help='arithmetic of the headline `value`: float64 is the reference\'s precision (PyBullet computes in double: '
+                       'solo8v2vanilla.py:91) and the default; float32 is the opt-in fast mode, reported next to it as value_f32')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extra', action='store_true', help='skip the value_f64 / value_closed_loop legs')
   ap.add_argument('--steps-per-launch', type=int, default=250,
@@ -450,25 +452,36 @@ def main():
 
   extra = {}
   if not args.no_extra:
-    ke = min(k, 500)  # (bounded intervals: f64 is ~3x, single-step launches ~4x slower per step)
-    if args.dtype == 'float32':
-      t64, s64, g64, e64, pool64, spl64, streams64 = timed('float64', ke, False, 0.3, 10)
-      extra['value_f64'] = world * n * ke / statistics.median(t64)
-      extra['value_f64_note'] = ('same workload and rollout path in float64 (the reference\'s precision, SURVEY.md §8; the '
-                                 'parity instantiation of the kernel), median of %d repeats of %d steps' % (len(t64), ke))
-      # the reference-precision kernel's own roofline block: 765 algorithmic bytes per env-step
-      extra['roofline_f64'] = roofline('float64', g64, pool64, ke, spl64, streams64)[0]
-      extra['episodes_f64'] = summarize(s64.cpu().numpy())
-      e64._close()
-    # pybullet's documented default solverResidualThreshold (1e-7 [recalled]) as an OPT-IN: off in `value`
-    tr, _, _, er, _, _, _ = timed(args.dtype, ke, False, 0.3, 10, residual_threshold=1e-7)
-    extra['value_residual_1e-7'] = world * n * ke / statistics.median(tr)
-    er._close()
+    ke = min(k, 500)  # (bounded intervals: f64 is ~2x, single-step launches ~2-4x slower per step)
+    other = 'float32' if args.dtype == 'float64' else 'float64'
+    tag = {'float32': 'f32', 'float64': 'f64'}
+    # the OTHER precision on the same workload and rollout path, with its own roofline block (f64 is the reference's
+    # precision - PyBullet computes in double - and the kernel of `value` by default; f32 is the opt-in fast mode)
+    to, so_, go, eo, poolo, splo, streamso = timed(other, ke, False, 0.3, 10)
+    extra['value_' + tag[other]] = world * n * ke / statistics.median(to)
+    extra['value_%s_note' % tag[other]] = ('same workload and rollout path in %s (%s), median of %d repeats of %d steps'
+                                           % (other, 'the opt-in fast mode; NOT the reference\'s precision' if other == 'float32'
+                                              else 'the reference\'s precision, SURVEY.md §8', len(to), ke))
+    extra['roofline_' + tag[other]] = roofline(other, go, poolo, ke, splo, streamso)[0]
+    extra['episodes_' + tag[other]] = summarize(so_.cpu().numpy())
+    eo._close()
+    for dt in (args.dtype, other):
+      sfx = '' if dt == args.dtype else '_' + tag[dt]
+      # pybullet's documented default solverResidualThreshold (1e-7 [recalled]) as an OPT-IN: off in `value`
+      tr, _, _, er, _, _, _ = timed(dt, ke, False, 0.3, 10, residual_threshold=1e-7)
+      extra['value_residual_1e-7' + sfx] = world * n * ke / statistics.median(tr)
+      er._close()
+      tcl, _, _, ecl, _, _, _ = timed(dt, ke, True, 0.3, 10)
+      extra['value_closed_loop' + sfx] = world * n * ke / statistics.median(tcl)
+      ecl._close()
     extra['value_residual_note'] = ('the same rollout with SoloConfig.solver_residual_threshold = 1e-7 (pybullet\'s documented default; the '
-                                    'Gauss-Seidel iteration ends after a sweep whose largest squared velocity-level change is below it); NOT the '
-                                    'configuration of `value`: '
+                                    'Gauss-Seidel iteration ends after a sweep whose largest squared velocity-level change is below it), in the '
+                                    'headline precision and (suffix) the other one; NOT the configuration of `value`: '
                                     'without warm starting it leaves a resting robot jittering at 5e-5 rad/s, where the reference\'s recorded '
                                     'rest state has 1e-11')
+    extra['value_closed_loop_note'] = ('one solo_engine_step launch per env step (outputs evaluated in that launch), the '
+                                       'granularity of Solo8VanillaEnv.step (solo8v2vanilla.py:72-102), actions pre-generated, '
+                                       'no host synchronisation between steps; median over repeats of %d steps; headline precision and (suffix) the other one' % ke)
     # rounds 1-2 timed the first steps of 4096 synchronised episodes (every robot freshly reset, nobody terminating):
     # the same kernels under that lighter regime, so that this round's line can be compared with theirs
     tsy, _, _, esy, _, _, _ = timed(args.dtype, ke, False, 0.3, 10, steady=False)
@@ -476,12 +489,6 @@ def main():
     extra['value_synchronised_start_note'] = ('the regime rounds 1-2 reported as `value`: all robots at the start of an episode (no steady-state '
                                               'preparation, no episode ends inside the window); NOT the configuration of `value`')
     esy._close()
-    tcl, _, _, ecl, _, _, _ = timed(args.dtype, ke, True, 0.3, 10)
-    extra['value_closed_loop'] = world * n * ke / statistics.median(tcl)
-    extra['value_closed_loop_note'] = ('one solo_engine_step launch per env step (outputs evaluated in that launch), the '
-                                       'granularity of Solo8VanillaEnv.step (solo8v2vanilla.py:72-102), actions pre-generated, '
-                                       'no host synchronisation between steps; median of %d repeats of %d steps' % (len(tcl), ke))
-    ecl._close()
 
   if rank == 0:
     value = world * n * k / elapsed

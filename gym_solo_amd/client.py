@@ -54,6 +54,16 @@ class BatchedBulletClient:
     self._joint_info = pybullet_joint_info(solo_model)
     self.state_version = 0
     self._gravity = tuple(engine.cfg.gravity)
+    # Engine.set_state() replaces the simulation under the env: whatever was evaluated on the old state is stale
+    # (a weak reference: the engine must not keep its client alive)
+    if hasattr(engine, 'on_restore'):
+      import weakref
+      me = weakref.ref(self)
+      def _bump():
+        c = me()
+        if c is not None:
+          c.state_version += 1
+      engine.on_restore(_bump)
 
   # ---- configuration setters: validated against the engine's compiled configuration --------
   def setAdditionalSearchPath(self, path):

@@ -45,7 +45,10 @@ class Solo8BaseConfig:
   # ---- build extensions (not in the reference) -------------------------------------
   num_envs: int = 1
   device: int = 0
-  dtype: str = 'float32'          # arithmetic type of the engine: 'float32' | 'float64'
+  # arithmetic type of the engine.  'float64' is what the reference computes in (PyBullet steps in double:
+  # solo8v2vanilla.py:91) and the default of the drop-in; 'float32' is the documented OPT-IN fast mode (about 2x the
+  # throughput; one-step joint-rate error ~1e-4 rad/s against the f64 path: DESIGN.md section 6)
+  dtype: str = 'float64'
   solver_iterations: int = 50     # Bullet default [recalled]
   solver_ulp_tolerance: int = 2   # impulse changes of <= this many half-ulps (relative) count as converged (0 = exact)
   # pybullet's solverResidualThreshold: the Gauss-Seidel iteration ends after a sweep whose largest squared

@@ -289,7 +289,10 @@ struct Engine final : EngineBase {
     // in-place outputs (steps_per_launch = 1 in f32, or a one-step remainder) copy
     const int S = spl();
     const int last_steps = (k % S == 0) ? S : k % S;
-    if (!(last_steps == 1 && solo::kInlineOutputs<T, true>)) return SOLO_OK;
+    // ... and recording rollouts that asked for neither observations nor rewards: their launches leave no records (no
+    // epilogue runs), the step kernel writes the done flags straight into the caller's [K][N] buffer
+    const bool no_epilogue = (flags & (SOLO_STEP_OBS | SOLO_STEP_REWARD)) == 0;
+    if (!(no_epilogue || (last_steps == 1 && solo::kInlineOutputs<T, true>))) return SOLO_OK;
     if (obs_out && (flags & SOLO_STEP_OBS))
       HIP_TRY(hipMemcpyAsync(obs, (const T*)obs_out + (size_t)(k - 1) * n * obs_dim, (size_t)n * obs_dim * sizeof(T), hipMemcpyDeviceToDevice, s));
     if (reward_out && (flags & SOLO_STEP_REWARD))

@@ -386,7 +386,7 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, dou
       "s_branch .Lpgs64_%=_b2\n"
       ".Lpgs64_%=_done:\n\t"
       : [v] "+v"(v), "={v[114:115]}"(lam_o), "={v[116:117]}"(cand_o), "={v[118:119]}"(dl_o), "={v[120:121]}"(lo_o), "={v[122:123]}"(hi_o),
-        "={v[124:125]}"(x1), "={v[126:127]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
+        "=&{v[124:125]}"(x1), "=&{v[126:127]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
         [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [ri] "=&s"(ri), [it] "=&s"(it)
 #ifdef SOLO_STAMPS
         , [nch] "+s"(n_changed)

@@ -265,19 +265,25 @@ class Engine:
 
   # ---- checkpoint / resume (the reference has none - reset() rebuilds the world; here the
   #      whole simulation is a handful of device tensors) --------------------------------------------------------
-  _CHECKPOINT = ('state', 'targets', 'term_count', 'params', 'stats_shards', 'cost')
+  _CHECKPOINT = ('state', 'snapshot', 'targets', 'term_count', 'params', 'stats_shards', 'cost')
 
   def get_state(self):
     """Everything a run continues from, as clones on the device: the robots' state records (episodic return / length
-    accumulators included), the commanded motor targets, the TimeBased counters, the per-robot parameters, the
-    episodic statistics and the per-robot solver cost (which decides a closed-loop launch's wave priorities, not
-    results).  The reset snapshot is NOT part of it: it is a function of configuration, parameters and terrain."""
+    accumulators included), the reset snapshot every auto-reset restores (it reflects whatever parameters and terrain
+    were in force at the last settle() / set_terrain(), NOT the current ones: set_params does not re-settle), the
+    commanded motor targets, the TimeBased counters, the per-robot parameters, the episodic statistics and the
+    per-robot solver cost (which decides a closed-loop launch's wave priorities, not results).  Terrain and the
+    compiled configuration are NOT part of it: restore into an engine built with the same ones."""
     self._torch.cuda.current_stream(self.device).synchronize()
     return {name: getattr(self, name).clone() for name in self._CHECKPOINT}
 
   def set_state(self, checkpoint):
     """Restores a get_state() checkpoint (of an engine with the same number of robots and precision): the next step
-    continues bit for bit where the checkpointed run would have."""
+    continues bit for bit where the checkpointed run would have.  Listeners registered with on_restore() (the env's
+    client: its cached observations / rewards are those of the state before the restore) are told."""
+    missing = [name for name in self._CHECKPOINT if name not in checkpoint]
+    if missing:
+      raise ValueError('checkpoint lacks the field(s) {}: it was not written by Engine.get_state() of this version'.format(missing))
     for name in self._CHECKPOINT:
       src, dst = checkpoint[name], getattr(self, name)
       if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
@@ -285,6 +291,14 @@ class Engine:
           name, tuple(src.shape), src.dtype, tuple(dst.shape), dst.dtype))
     for name in self._CHECKPOINT:
       getattr(self, name).copy_(checkpoint[name])
+    for hook in getattr(self, '_restore_hooks', ()):
+      hook()
+
+  def on_restore(self, hook):
+    """hook() is called after every set_state()."""
+    if not hasattr(self, '_restore_hooks'):
+      self._restore_hooks = []
+    self._restore_hooks.append(hook)
 
   def close(self):
     """solo_engine_destroy: frees every device buffer.  Tensors handed out earlier dangle."""

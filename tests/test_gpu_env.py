@@ -188,6 +188,33 @@ def test_view_holds_the_last_step_of_a_recorded_rollout(dtype, spl, streams, k):
   env._close()
 
 
+@pytest.mark.parametrize('dtype,spl', [('float32', 1), ('float32', 7), ('float64', 1), ('float64', 7)])
+def test_view_holds_the_last_done_flags_of_a_physics_and_done_only_rollout(dtype, spl):
+  """A recording rollout that asks for PHYSICS | DONE only (no observations, no rewards) leaves no step records and
+  runs no output epilogue: the step kernel writes the flags into the caller's buffer, and the rollout brings the
+  last step's into the engine's view (include/solo_engine.h: "the view holds the last step's outputs")."""
+  import torch
+  from gym_solo_amd import abi
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  from gym_solo_amd.workloads import register_benchmark_workload
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  k = 15
+  cfg = Solo8VanillaConfig()
+  cfg.dtype, cfg._dtype_pinned, cfg.auto_reset, cfg.steps_per_launch = dtype, True, True, spl
+  env = make_env(config=cfg)
+  register_benchmark_workload(env, max_steps=k - 1)
+  env._ensure_program()
+  eng = env.engine
+  g = torch.Generator(device='cuda').manual_seed(12)
+  acts = (torch.rand(k, env.num_envs, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.28
+  eng.done.fill_(7)
+  _, _, done = eng.rollout(acts, abi.STEP_PHYSICS | abi.STEP_DONE, record=True)
+  eng.synchronize()
+  assert bool(done[-1].all()) and not bool(done[:-1].any())
+  np.testing.assert_array_equal(eng.done.cpu().numpy(), done[-1].cpu().numpy())
+  env._close()
+
+
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
 def test_step_is_capturable_in_a_hip_graph(dtype):
   """The engine enqueues everything on the caller's stream and never synchronises inside step(): an RL library can
@@ -256,7 +283,7 @@ def test_checkpoint_and_resume_continue_bit_for_bit(dtype):
   n = first.num_envs
   acts = (torch.rand(70, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.28
   mu = torch.rand(n, device='cuda', dtype=tdt, generator=g) * 0.7 + 0.3
-  for env in (first, second):   # (parameters and terrain belong to the configuration of an engine, not to the checkpoint)
+  for env in (first, second):   # (both engines get the parameters here; the checkpoint carries them as well)
     env.engine.set_params(abi.PARAM_FRICTION, mu)
   first.engine.rollout(acts[:30], abi.STEP_ALL)
   ck = first.engine.get_state()
@@ -273,6 +300,51 @@ def test_checkpoint_and_resume_continue_bit_for_bit(dtype):
   with pytest.raises(ValueError):
     bad = dict(ck); bad['state'] = ck['state'][:-1]
     second.engine.set_state(bad)
+  for env in (first, second):
+    env._close()
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_checkpoint_carries_the_reset_snapshot(dtype):
+  """The reset snapshot reflects the parameters in force at the last settle(), not the current ones (set_params does
+  not re-settle): a checkpoint of an engine prepared with set_params(base mass) + settle() restored into a FRESH engine
+  (default parameters, default snapshot) must bring the snapshot along, or every auto-reset after the restore puts the
+  robots into another pose.  Also: the env's cached outputs are invalidated by the restore."""
+  import torch
+  from gym_solo_amd import abi
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  from gym_solo_amd.workloads import register_benchmark_workload
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  def build():
+    cfg = Solo8VanillaConfig()
+    cfg.dtype, cfg._dtype_pinned, cfg.auto_reset, cfg.steps_per_launch = dtype, True, True, 10
+    env = make_env(config=cfg, copy_outputs=True)
+    register_benchmark_workload(env, max_steps=25)
+    env._ensure_program()
+    return env
+  g = torch.Generator(device='cuda').manual_seed(5)
+  first, second = build(), build()
+  n = first.num_envs
+  acts = (torch.rand(60, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.28
+  first.engine.set_params(abi.PARAM_BASE_MASS_SCALE, torch.rand(n, device='cuda', dtype=tdt, generator=g) * 0.4 + 0.8)
+  first.engine.settle()
+  assert not torch.equal(first.engine.snapshot, second.engine.snapshot)
+  first.engine.rollout(acts[:20], abi.STEP_ALL)
+  ck = first.engine.get_state()
+  want = first.engine.rollout(acts[20:], abi.STEP_ALL, record=True)   # (an episode end + auto-reset for every robot)
+  first.engine.synchronize()
+  assert int(want[2].sum()) >= n
+  stale_obs = second._evaluate_observations().clone()
+  second.engine.set_state(ck)
+  fresh_obs = second._evaluate_observations().clone()
+  assert not torch.equal(stale_obs, fresh_obs)          # the cached observation of the pre-restore state was dropped
+  got = second.engine.rollout(acts[20:], abi.STEP_ALL, record=True)
+  second.engine.synchronize()
+  for a, b in zip(want, got):
+    assert torch.equal(a, b)
+  assert torch.equal(first.engine.state, second.engine.state) and torch.equal(first.engine.snapshot, second.engine.snapshot)
+  with pytest.raises(ValueError):
+    second.engine.set_state({k: v for k, v in ck.items() if k != 'snapshot'})
   for env in (first, second):
     env._close()
 
