@@ -263,16 +263,14 @@ struct Engine final : EngineBase {
       }
       // stepSimulation-only calls (settle loop, client.stepSimulation()) run the physics-only
       // instantiation: no termination code, and a separate name in profiles
-      constexpr int kG = solo::kRobotsPerGroup;  // (1; 8 in the EXPERIMENT build `make group8`)
-      if (count % kG != 0) { err = "this build steps whole groups of robots"; return SOLO_ERR_INVALID_ARG; }
       // (pybullet's residual threshold, an opt-in, is a kernel instantiation of its own: the default kernels carry none of it)
       const bool resid = cfg.solver_residual_threshold > 0;
       if (flags == SOLO_STEP_PHYSICS) {
-        if (resid) hipLaunchKernelGGL((solo::solo_step_kernel<T, false, true>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
-        else hipLaunchKernelGGL((solo::solo_step_kernel<T, false, false>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
+        if (resid) hipLaunchKernelGGL((solo::solo_step_kernel<T, false, true>), dim3(count), dim3(64), 0, s, dparams, b);
+        else hipLaunchKernelGGL((solo::solo_step_kernel<T, false, false>), dim3(count), dim3(64), 0, s, dparams, b);
       } else {
-        if (resid) hipLaunchKernelGGL((solo::solo_step_kernel<T, true, true>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
-        else hipLaunchKernelGGL((solo::solo_step_kernel<T, true, false>), dim3(count / kG), dim3(64 * kG), 0, s, dparams, b);
+        if (resid) hipLaunchKernelGGL((solo::solo_step_kernel<T, true, true>), dim3(count), dim3(64), 0, s, dparams, b);
+        else hipLaunchKernelGGL((solo::solo_step_kernel<T, true, false>), dim3(count), dim3(64), 0, s, dparams, b);
       }
       HIP_TRY(hipGetLastError());
     }

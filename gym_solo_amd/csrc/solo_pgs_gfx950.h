@@ -275,33 +275,36 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 #undef SOLO_PGS_WALK
 #undef SOLO_PGS_ROW
 
-// ---- the same loop in f64 (round 3): the reference's precision, the parity path ---------------------------
-// Columns: 64 doubles per lane in v[128:255] (ColumnBank<double>: four 16-wide tuples), column r = v[128 + 2 r :
-// 129 + 2 r], read register-indexed as source 0 of the v_fma_f64 (index 2 r).  The 64-bit loop variables whose
-// HALVES are touched (v_cndmask_b32 / v_readlane_b32 / DPP moves work on dwords) sit in fixed registers - an
-// inline-asm operand cannot be sliced - : lam v[114:115], cand v[116:117], dl v[118:119], lo v[120:121],
-// hi v[122:123], x1 v[124:125], x2 v[126:127]; the impulse change of the updated row in s[94:95].
+// ---- the same loop in f64: the reference's precision, the parity path (round 3; slot space since round 4) ----
+// The f64 solver runs in SLOT space (ColumnBank<double>, solo_step_kernel.h: lane = slot, the live rows in lane order
+// on the lanes 0 .. L-1) and this loop only sees steps with L <= 32: 32 columns per lane in v[104:167]
+// (ColumnBank<double>: two 16-wide tuples), column r = v[104 + 2 r : 105 + 2 r], read register-indexed as source 0 of
+// the v_fma_f64 (index 2 r).  The phases are lane masks of the step (operands, as before).  The 64-bit loop variables
+// whose HALVES are touched (v_cndmask_b32 / v_readlane_b32 / DPP moves work on dwords) sit in fixed registers - an
+// inline-asm operand cannot be sliced - : lam v[90:91], cand v[92:93], dl v[94:95], lo v[96:97], hi v[98:99],
+// x1 v[100:101], x2 v[102:103]; the impulse change of the updated row in s[94:95].  The whole kernel then fits 168
+// VGPRs = three waves per SIMD (round 3: 64 columns in v[128:255], 256 VGPRs, two waves).
 // 19 instructions per updated row (the compiler's loop over LDS-evaluated columns: ~40), no v_med3 in f64:
 // v_max_f64 + v_min_f64, exactly Real<double>::clamp.  Same rows, same order, same arithmetic as the C++ loop
 // (tests/test_gpu_pgs_asm.py compares the two bit for bit in f64 too).
 #define SOLO_PGS_ROW64(PH)                                                                         \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
   "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
-  "v_readlane_b32 s94, v118, %[rs]\n\t"       /* the change of its impulse */                      \
-  "v_readlane_b32 s95, v119, %[rs]\n\t"                                                            \
+  "v_readlane_b32 s94, v94, %[rs]\n\t"       /* the change of its impulse */                      \
+  "v_readlane_b32 s95, v95, %[rs]\n\t"                                                            \
   "s_lshl_b32 %[ri], %[rs], 1\n\t"            /* register index of the column: 2 x row */          \
   "s_set_gpr_idx_on %[ri], gpr_idx(SRC0)\n\t"                                                      \
   "s_lshl_b64 %[t], -2, %[rs]\n\t"            /* (a scalar instruction between the mode switch and the indexed VALU instruction) */ \
-  "v_fma_f64 %[v], v[128:129], s[94:95], %[v]\n\t"  /* v += column * change (source 0 register-indexed) */ \
+  "v_fma_f64 %[v], v[104:105], s[94:95], %[v]\n\t"  /* v += column * change (source 0 register-indexed) */ \
   "s_set_gpr_idx_off\n\t"                                                                          \
   "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor (and the wait state after the mode switch) */ \
-  "v_cndmask_b32_e32 v114, v114, v116, vcc\n\t"   /* lam[row] = cand[row] */                       \
-  "v_cndmask_b32_e32 v115, v115, v117, vcc\n\t"                                                    \
-  "v_max_f64 v[116:117], %[v], v[120:121]\n\t"                                                     \
-  "v_min_f64 v[116:117], v[116:117], v[122:123]\n\t"                                               \
-  "v_mul_f64 %[thr], %[tol], |v[114:115]|\n\t"                                                     \
-  "v_add_f64 v[118:119], v[116:117], -v[114:115]\n\t"                                              \
-  "v_cmp_gt_f64_e64 %[pend], |v[118:119]|, %[thr]\n\t"                                             \
+  "v_cndmask_b32_e32 v90, v90, v92, vcc\n\t"   /* lam[row] = cand[row] */                       \
+  "v_cndmask_b32_e32 v91, v91, v93, vcc\n\t"                                                    \
+  "v_max_f64 v[92:93], %[v], v[96:97]\n\t"                                                     \
+  "v_min_f64 v[92:93], v[92:93], v[98:99]\n\t"                                               \
+  "v_mul_f64 %[thr], %[tol], |v[90:91]|\n\t"                                                     \
+  "v_add_f64 v[94:95], v[92:93], -v[90:91]\n\t"                                              \
+  "v_cmp_gt_f64_e64 %[pend], |v[94:95]|, %[thr]\n\t"                                             \
   SOLO_PGS_COUNT_ROW                                                                               \
   "s_and_b64 %[todo], %[pend], %[w]\n\t"
 
@@ -314,23 +317,26 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
   "s_cbranch_scc1 .Lpgs64_%=_" P "_row\n"                                                          \
   ".Lpgs64_%=_" P "_out:\n\t"
 
-// friction limits = mu x the normal impulse their contact holds now (DPP row shifts of the two dwords)
+// friction limits = mu x the normal impulse their contact holds now.  In slot space a contact's rows are three
+// consecutive SLOTS, which may straddle a 16-lane row: DPP wave_shr:1 of the two dwords (x1 = the slot below), and
+// again for the slot two below (two wait states between a VALU write and the DPP read of it)
 #define SOLO_PGS_LIMITS64                                                                          \
-  "v_mov_b32_dpp v124, v114 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
-  "v_mov_b32_dpp v125, v115 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
-  "v_mov_b32_dpp v126, v114 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
-  "v_mov_b32_dpp v127, v115 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
-  "v_cndmask_b32_e64 v124, v126, v124, %[tan1]\n\t"                                                \
-  "v_cndmask_b32_e64 v125, v127, v125, %[tan1]\n\t"                                                \
-  "v_mul_f64 v[124:125], %[mu], v[124:125]\n\t"                                                    \
-  "v_cndmask_b32_e64 v120, v120, v124, %[tang]\n\t"    /* lo = -lim (the sign lives in the high dword) */ \
-  "v_cndmask_b32_e64 v121, v121, -v125, %[tang]\n\t"                                               \
-  "v_cndmask_b32_e64 v122, v122, v124, %[tang]\n\t"    /* hi = lim */                              \
-  "v_cndmask_b32_e64 v123, v123, v125, %[tang]\n\t"                                                \
-  "v_max_f64 v[116:117], %[v], v[120:121]\n\t"                                                     \
-  "v_min_f64 v[116:117], v[116:117], v[122:123]\n\t"                                               \
-  "v_add_f64 v[118:119], v[116:117], -v[114:115]\n\t"                                              \
-  "v_cmp_gt_f64_e64 %[pend], |v[118:119]|, %[thr]\n\t"
+  "v_mov_b32_dpp v100, v90 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
+  "v_mov_b32_dpp v101, v91 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
+  "s_nop 0\n\t"                                                                                   \
+  "v_mov_b32_dpp v102, v100 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+  "v_mov_b32_dpp v103, v101 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+  "v_cndmask_b32_e64 v100, v102, v100, %[tan1]\n\t"                                                \
+  "v_cndmask_b32_e64 v101, v103, v101, %[tan1]\n\t"                                                \
+  "v_mul_f64 v[100:101], %[mu], v[100:101]\n\t"                                                    \
+  "v_cndmask_b32_e64 v96, v96, v100, %[tang]\n\t"    /* lo = -lim (the sign lives in the high dword) */ \
+  "v_cndmask_b32_e64 v97, v97, -v101, %[tang]\n\t"                                               \
+  "v_cndmask_b32_e64 v98, v98, v100, %[tang]\n\t"    /* hi = lim */                              \
+  "v_cndmask_b32_e64 v99, v99, v101, %[tang]\n\t"                                                \
+  "v_max_f64 v[92:93], %[v], v[96:97]\n\t"                                                     \
+  "v_min_f64 v[92:93], v[92:93], v[98:99]\n\t"                                               \
+  "v_add_f64 v[94:95], v[92:93], -v[90:91]\n\t"                                              \
+  "v_cmp_gt_f64_e64 %[pend], |v[94:95]|, %[thr]\n\t"
 
 __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, double& v, double& lam, double& cand, double& dl,
                                                 unsigned long long& pend, double& lo, double& hi, double tol, int lane, double mu,
@@ -385,16 +391,16 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, dou
       SOLO_PGS_LIMITS64
       "s_branch .Lpgs64_%=_b2\n"
       ".Lpgs64_%=_done:\n\t"
-      : [v] "+v"(v), "={v[114:115]}"(lam_o), "={v[116:117]}"(cand_o), "={v[118:119]}"(dl_o), "={v[120:121]}"(lo_o), "={v[122:123]}"(hi_o),
-        "=&{v[124:125]}"(x1), "=&{v[126:127]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
+      : [v] "+v"(v), "={v[90:91]}"(lam_o), "={v[92:93]}"(cand_o), "={v[94:95]}"(dl_o), "={v[96:97]}"(lo_o), "={v[98:99]}"(hi_o),
+        "=&{v[100:101]}"(x1), "=&{v[102:103]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
         [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [ri] "=&s"(ri), [it] "=&s"(it)
 #ifdef SOLO_STAMPS
         , [nch] "+s"(n_changed)
 #endif
-      : "{v[114:115]}"(lam), "{v[116:117]}"(cand), "{v[118:119]}"(dl), "{v[120:121]}"(lo), "{v[122:123]}"(hi),
+      : "{v[90:91]}"(lam), "{v[92:93]}"(cand), "{v[94:95]}"(dl), "{v[96:97]}"(lo), "{v[98:99]}"(hi),
         [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
         [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes),
-        "{v[128:159]}"(A.a0), "{v[160:191]}"(A.a1), "{v[192:223]}"(A.a2), "{v[224:255]}"(A.a3)
+        "{v[104:135]}"(A.a0), "{v[136:167]}"(A.a1)
       : "vcc", "scc", "s94", "s95");
   lam = lam_o; cand = cand_o; dl = dl_o; lo = lo_o; hi = hi_o;
   (void)n_changed; (void)x1; (void)x2;

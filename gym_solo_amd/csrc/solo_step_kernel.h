@@ -36,7 +36,7 @@
 // No MFMA: there is no dense contraction here (14 dofs, <= 64 rows per robot).
 //
 // The including translation unit must provide solo::lane_id/block_id/wave_sync/wave_readlane/
-// wave_sum_group16/wave_sum_all/wave_reduce_rows/wave_lane_below/wave_ballot/wave_cold_args/RowDot<T>/
+// wave_sum_group16/wave_sum_all/wave_reduce_rows/wave_lane_below/wave_slot_below/wave_count_below/wave_push/wave_pull/wave_ballot/wave_cold_args/RowDot<T>/
 // ColumnBank<T>/Real<T>/stats_add (solo_wave_ops.h on the GPU, tests/emu/wave_emu.h on the CPU emulator).
 #pragma once
 
@@ -112,15 +112,84 @@ template <typename T> __device__ __forceinline__ V3<T> from_lower(V3<T> v) { ret
 
 
 }  // namespace solo
-#ifdef SOLO_GROUP8
-#include "solo_step_kernel_g8.h"  // EXPERIMENT build (make group8): one wave computes the dynamics of 8 robots
-#endif
 namespace solo {
-#ifdef SOLO_GROUP8
-constexpr int kLegSlots = kG8LegSlots;
-#else
-constexpr int kLegSlots = 20;
-#endif
+constexpr int kLegSlots = 26;  // per-leg parking lot in LDS (see physics_solve): 0-11 K, 12-14 Lp factors, 15-16 unconstrained joint rates, 17-18 q, 19-22 cos / sin of the two link angles, 23-24 P^-1 h
+
+// one lane's constraint-row constants, as the step reads them from LDS (staged from KParams::row once per launch)
+template <typename T> struct RowView {
+  int type, body;   // RowType, BodyKind
+  const T* geo;     // sphere centre [3] in its body frame, radius
+};
+
+// rows of one sweep, in solver order ([recalled] btMultiBodyConstraintSolver::solveSingleIteration):
+// the non-contact rows (joint motors, joint limits), then ALL normal contact rows, then ALL friction rows -
+// as lane masks of the fixed lane = row layout (solo_kernel_params.h); the slot-space solver builds its own per step
+constexpr unsigned long long kPhaseLanes[3] = {0xc003c003c003c003ull,    // motors k = 0, 1 and joint limits k = 14, 15, leg by leg
+                                               0x0924092409240924ull,    // normals  k = 2, 5, 8, 11
+                                               0x36d836d836d836d8ull};   // friction k = 3, 4, 6, 7, 9, 10, 12, 13
+
+// The Gauss-Seidel iteration, C++ DEFINITION (see physics_solve for what the per-lane state means).  The CPU emulator
+// and the -DSOLO_PGS_NO_ASM test build run it; on the GPU the product runs solo_pgs_gfx950.h's assembly - same rows,
+// same order, same arithmetic, compared bit for bit by tests/test_gpu_pgs_asm.py - and this function only where the
+// assembly does not go: kFromLds, the OVERFLOW path of the slot-space solver (more live rows than the column bank has
+// slots: every column is evaluated from LDS when it is used - ColumnBank::column, the expression build() stores).
+// Returns the number of sweeps.
+template <typename T, bool kResid, bool kFromLds>
+__device__ __forceinline__ int pgs_solve_cpp(const ColumnBank<T>& A, T& v, T& lamv, T& cand, T& dl, unsigned long long& pend, T& lo, T& hi,
+                                             T tol_rel, int lane, T mu, bool is_tan1, bool is_tangent, unsigned long long ph0,
+                                             unsigned long long ph1, unsigned long long ph2, int iters, T diag, T resid_thr, int& n_changed) {
+  using R = Real<T>;
+  int it = 0;
+#pragma unroll 1
+  for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
+    // (the register banks of the matrix are walked one after the other - static bank per loop - which
+    // keeps the rows of a phase in ascending lane order)
+    const T lam_sweep_start = lamv;
+    bool normals_moved = false;  // (wave-uniform)
+#pragma unroll
+    for (int phase = 0; phase < 3; ++phase) {
+      const unsigned long long phase_lanes = phase == 0 ? ph0 : (phase == 1 ? ph1 : ph2);
+      if (phase == 2 && normals_moved) {
+        // the friction rows of a contact are limited by mu x the normal impulse it holds NOW: the
+        // normal rows are done for this sweep, so all limits are refreshed at once (a friction
+        // row's normal row sits one or two lanes below it: DPP shifts) instead of per moved row
+        // - and only in a sweep that moved a normal row (all limits start at mu x 0 = 0)
+        T n1, n2;
+        if constexpr (ColumnBank<T>::kCompact) { n1 = wave_slot_below<1>(lamv); n2 = wave_slot_below<2>(lamv); }
+        else { n1 = wave_lane_below<1>(lamv); n2 = wave_lane_below<2>(lamv); }
+        const T lim = mu * (is_tan1 ? n1 : n2);
+        lo = is_tangent ? -lim : lo;
+        hi = is_tangent ? lim : hi;
+        cand = R::clamp(v, lo, hi);
+        dl = cand - lamv;
+        pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
+      }
+      if ((pend & phase_lanes) == 0ull) continue;  // nothing of this phase moves: one test for its banks
+      if (phase == 1) normals_moved = true;
+#pragma unroll
+      for (int bank = 0; bank < (kFromLds ? 1 : ColumnBank<T>::kBanks); ++bank) {
+        unsigned long long window = kFromLds ? phase_lanes : (phase_lanes & ColumnBank<T>::bank_lanes(bank));
+#pragma unroll 1
+        while ((pend & window) != 0ull) {
+          const int r = __builtin_ctzll(pend & window);  // wave-uniform: the row to update
+          window &= ~((2ull << r) - 1ull);               // the cursor moves past it
+          const T col = kFromLds ? A.column(r) : A.get(bank, r);  // column r of the scaled matrix (0 for the row itself)
+          const T delta = wave_readlane(dl, r);
+          v = R::fma(col, delta, v);
+          lamv = (lane == r) ? cand : lamv;
+          cand = R::clamp(v, lo, hi);
+          dl = cand - lamv;
+          pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
+          ++n_changed;
+        }
+      }
+    }
+    SOLO_PGS_SWEEP_HOOK(it, pend, lamv, v);
+    const T dvel = (lamv - lam_sweep_start) * diag;
+    if (kResid && wave_ballot(dvel * dvel > resid_thr) == 0ull) { ++it; break; }  // pybullet's residual threshold (see physics_solve)
+  }
+  return it;
+}
 
 // ------------------------------------------------------------------------------------------
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
@@ -128,11 +197,15 @@ constexpr int kLegSlots = 20;
 // ------------------------------------------------------------------------------------------
 template <typename T, bool kResid>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
-                                           const RowConst<T>& rc, const T* s_state, T my_target, T (*s_rowvec)[8], T (*s_hext)[8],
-                                           T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& prio_sweeps, int& prio_steps, int& prio_rot) {
+                                           const RowView<T>& rc, const T* s_state, T my_target, T* s_rowvec, T (*s_hext)[8],
+                                           T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& row_at,
+                                           int& prio_sweeps, int& prio_steps, int& prio_rot) {
+  constexpr bool kCompact = ColumnBank<T>::kCompact;   // the solver runs in slot space (see "slot space" below)
+  constexpr int kRS = ColumnBank<T>::kRowStride;       // reals per row vector in s_rowvec
   using R = Real<T>;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = C.dt;
+  if constexpr (sizeof(T) == 8) mass_scale = s_keep[28];  // (staged by the kernel's prologue; the friction coefficient is fetched at the solver)
 
   // ---- base: rotation (body -> world), velocities and gravity in base coordinates ----------
   const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
@@ -148,15 +221,6 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   const V3<T> gb = {r00 * gw.x + r10 * gw.y + r20 * gw.z, r01 * gw.x + r11 * gw.y + r21 * gw.z, r02 * gw.x + r12 * gw.y + r22 * gw.z};
   const V3<T> nb = {r20, r21, r22};  // world z (ground normal) in base coordinates
 
-#ifdef SOLO_GROUP8
-  // (EXPERIMENT build: the dynamics phase ran in the group's dynamics wave - physics_dynamics_g8 - which parked
-  // its results in s_keep / s_leg; what the row phase reads of it besides those is re-derived here)
-  const T q1 = s_leg[leg][17], q2 = s_leg[leg][18];
-  const T c1 = s_leg[leg][19], s1 = s_leg[leg][20], c12 = s_leg[leg][21], s12 = s_leg[leg][22];
-  const V3<T> o1 = {L.hip[0], L.hip[1], L.hip[2]};
-  const V3<T> o2 = o1 + roty(c1, s1, V3<T>{L.knee[0], L.knee[1], L.knee[2]});
-  (void)om; (void)vb; (void)gb; (void)dt; (void)mass_scale;
-#else
   // ---- leg-local kinematics.  Each 16-lane row works on its own leg, and the two HALVES of the
   //      row on the leg's two links: lanes k < 8 carry the upper link, k >= 8 the lower link
   //      (+ welded foot) through the same instructions; per-leg quantities are the sum of the two
@@ -206,6 +270,22 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     K2[i] = W2[i] * iL22;
     K1[i] = (W1[i] - L21 * K2[i]) * iL11;
   }
+  // f64: PARK EARLY.  The register peak of the whole step is the 6x6 base factorisation below with everything the legs
+  // have produced still live (221 VGPRs when the compiler may have them; 168 = three waves per SIMD is the budget):
+  // what the legs computed for later phases goes to its place in LDS NOW - the two wave_syncs of the leg sum below lie
+  // between these stores and the loads that bring it back (so the compiler cannot forward the registers) - and the
+  // row phase re-derives the base rotation from the quaternion instead of keeping nine values across the factorisation.
+  // (f32 fits its 128 VGPRs without: it keeps the values and parks once, at the end of the dynamics phase.)
+  constexpr bool kPark = sizeof(T) == 8;
+  if constexpr (kPark) {
+    if (k == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { s_leg[leg][i] = K1[i]; s_leg[leg][6 + i] = K2[i]; }
+      s_leg[leg][12] = iL11; s_leg[leg][13] = L21; s_leg[leg][14] = iL22;
+      s_leg[leg][17] = q1; s_leg[leg][18] = q2;
+      s_leg[leg][19] = c1; s_leg[leg][20] = s1; s_leg[leg][21] = c12; s_leg[leg][22] = s12;
+    }
+  }
 
   SOLO_STAMP(B, 3);
   // ---- bias forces of the leg: Newton-Euler with classical accelerations in the frame that
@@ -236,6 +316,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // e = Lp^-1 h ; y = Lp^-T e = P^-1 h
   const T e1 = h1 * iL11, e2 = (h2 - L21 * e1) * iL22;
   const T y2 = e2 * iL22, y1 = (e1 - L21 * y2) * iL11;
+  if constexpr (kPark) { if (k == 0) { s_leg[leg][23] = y1; s_leg[leg][24] = y2; } }
 
   SOLO_STAMP(B, 4);
   // ---- base level: Schur complement S and right-hand side, summed over the four legs -------
@@ -261,7 +342,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // (~30 instructions; 27 in-register cross-row sums cost six each).  The row-vector array is
   // not live yet and serves as the scratch: part[4][28], tot[28].
   {
-    T* part = &s_rowvec[0][0];
+    T* part = s_rowvec;
     T* tot = part + 4 * 28;
     if (k == 0) {
       T* mine = part + leg * 28;
@@ -334,11 +415,21 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   }
   T kx1 = T(0), kx2 = T(0);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { kx1 += K1[i] * xb[i]; kx2 += K2[i] * xb[i]; }
+  for (int i = 0; i < 6; ++i) {
+    if constexpr (kPark) { kx1 += s_leg[leg][i] * xb[i]; kx2 += s_leg[leg][6 + i] * xb[i]; }
+    else { kx1 += K1[i] * xb[i]; kx2 += K2[i] * xb[i]; }
+  }
   // velocities after the unconstrained update (semi-implicit Euler)
   const T ub[6] = {om.x + dt * xb[0], om.y + dt * xb[1], om.z + dt * xb[2],
              vb.x + dt * xb[3], vb.y + dt * xb[4], vb.z + dt * xb[5]};
-  const T us1 = qd1 + dt * (-y1 - kx1), us2 = qd2 + dt * (-y2 - kx2);
+  T us1, us2;
+  if constexpr (kPark) {
+    us1 = s_state[SOLO_S_QD + 2 * leg] + dt * (-s_leg[leg][23] - kx1);
+    us2 = s_state[SOLO_S_QD + 2 * leg + 1] + dt * (-s_leg[leg][24] - kx2);
+  } else {
+    us1 = qd1 + dt * (-y1 - kx1);
+    us2 = qd2 + dt * (-y2 - kx2);
+  }
 
   // Park the factors and the unconstrained velocities in LDS NOW: the row phase below and the
   // post-solve phase read them back from there (wave-uniform / per-leg broadcasts), so that
@@ -354,34 +445,51 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     for (int i = 0; i < 6; ++i) { s_keep[15 + i] = iC[i]; s_keep[21 + i] = ub[i]; }
   }
   if (k == 0) {
+    if constexpr (!kPark) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { s_leg[leg][i] = K1[i]; s_leg[leg][6 + i] = K2[i]; }
-    s_leg[leg][12] = iL11; s_leg[leg][13] = L21; s_leg[leg][14] = iL22;
-    s_leg[leg][15] = us1; s_leg[leg][16] = us2; s_leg[leg][17] = q1; s_leg[leg][18] = q2;
+      for (int i = 0; i < 6; ++i) { s_leg[leg][i] = K1[i]; s_leg[leg][6 + i] = K2[i]; }
+      s_leg[leg][12] = iL11; s_leg[leg][13] = L21; s_leg[leg][14] = iL22;
+      s_leg[leg][17] = q1; s_leg[leg][18] = q2;
+    }
+    s_leg[leg][15] = us1; s_leg[leg][16] = us2;
   }
   wave_sync();
-#endif  // SOLO_GROUP8
 
   SOLO_STAMP(B, 6);
   // ---- constraint rows: one per lane --------------------------------------------------------
+  // what the row phase reads of the kinematics: kept in registers (f32) or brought back from LDS / re-derived (f64: above)
+  T m00 = r00, m01 = r01, m02 = r02, m10 = r10, m11 = r11, m12 = r12;
+  V3<T> nbr = nb, p1 = o1, p2 = o2;
+  T ck1 = c1, sk1 = s1, ck12 = c12, sk12 = s12, qa1 = q1, qa2 = q2;
+  if constexpr (kPark) {
+    const T ux = s_state[SOLO_S_QUAT], uy = s_state[SOLO_S_QUAT + 1], uz = s_state[SOLO_S_QUAT + 2], uw = s_state[SOLO_S_QUAT + 3];
+    m00 = T(1) - T(2) * (uy * uy + uz * uz); m01 = T(2) * (ux * uy - uw * uz); m02 = T(2) * (ux * uz + uw * uy);
+    m10 = T(2) * (ux * uy + uw * uz); m11 = T(1) - T(2) * (ux * ux + uz * uz); m12 = T(2) * (uy * uz - uw * ux);
+    nbr = V3<T>{T(2) * (ux * uz - uw * uy), T(2) * (uy * uz + uw * ux), T(1) - T(2) * (ux * ux + uy * uy)};
+    qa1 = s_leg[leg][17]; qa2 = s_leg[leg][18];
+    ck1 = s_leg[leg][19]; sk1 = s_leg[leg][20]; ck12 = s_leg[leg][21]; sk12 = s_leg[leg][22];
+    p1 = V3<T>{L.hip[0], L.hip[1], L.hip[2]};
+    p2 = p1 + roty(ck1, sk1, V3<T>{L.knee[0], L.knee[1], L.knee[2]});
+  }
   const int type = rc.type;
   const bool is_motor = type == ROW_MOTOR, is_contact = type >= ROW_NORMAL && type <= ROW_TAN2, is_limit = type == ROW_LIMIT;
-  V3<T> cb = {rc.center[0], rc.center[1], rc.center[2]};
-  if (rc.body == BODY_UPPER) cb = o1 + roty(c1, s1, cb);
-  else if (rc.body == BODY_LOWER) cb = o2 + roty(c12, s12, cb);
+  V3<T> cb = {rc.geo[0], rc.geo[1], rc.geo[2]};
+  const T radius = rc.geo[3];
+  if (rc.body == BODY_UPPER) cb = p1 + roty(ck1, sk1, cb);
+  else if (rc.body == BODY_LOWER) cb = p2 + roty(ck12, sk12, cb);
   // ground under the sphere: flat plane z = 0 (plane.urdf, solo8_base_env.py:47) or the tangent
   // plane of the heightfield under the sphere centre (SoloTerrain; wave-uniform choice)
   T dist;
-  V3<T> nloc = nb;                      // ground normal in base coordinates
-  V3<T> d = nb;                         // this row's direction in base coordinates
+  V3<T> nloc = nbr;                      // ground normal in base coordinates
+  V3<T> d = nbr;                         // this row's direction in base coordinates
   if (B.terrain == nullptr) {
-    dist = s_state[SOLO_S_POS + 2] + dot(nb, cb) - rc.radius;
-    if (type == ROW_TAN1) d = V3<T>{r00, r01, r02};
-    if (type == ROW_TAN2) d = V3<T>{r10, r11, r12};
+    dist = s_state[SOLO_S_POS + 2] + dot(nbr, cb) - radius;
+    if (type == ROW_TAN1) d = V3<T>{m00, m01, m02};
+    if (type == ROW_TAN2) d = V3<T>{m10, m11, m12};
   } else {
-    const T cwx = s_state[SOLO_S_POS] + r00 * cb.x + r01 * cb.y + r02 * cb.z;
-    const T cwy = s_state[SOLO_S_POS + 1] + r10 * cb.x + r11 * cb.y + r12 * cb.z;
-    const T cwz = s_state[SOLO_S_POS + 2] + r20 * cb.x + r21 * cb.y + r22 * cb.z;
+    const T cwx = s_state[SOLO_S_POS] + m00 * cb.x + m01 * cb.y + m02 * cb.z;
+    const T cwy = s_state[SOLO_S_POS + 1] + m10 * cb.x + m11 * cb.y + m12 * cb.z;
+    const T cwz = s_state[SOLO_S_POS + 2] + nbr.x * cb.x + nbr.y * cb.y + nbr.z * cb.z;
     const T gu = (cwx - C.terr_ox) * C.terr_inv_cell, gv = (cwy - C.terr_oy) * C.terr_inv_cell;
     int gi = (int)R::floor(gu), gj = (int)R::floor(gv);
     gi = gi < 0 ? 0 : (gi > C.terr_nx - 2 ? C.terr_nx - 2 : gi);
@@ -398,28 +506,28 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     const T itn = R::rsqrt(T(1) - nw.x * nw.x);
     const V3<T> t1w = {(T(1) - nw.x * nw.x) * itn, -nw.x * nw.y * itn, -nw.x * nw.z * itn};
     const V3<T> t2w = cross(nw, t1w);
-    dist = (cwz - hh0) * nw.z - rc.radius;
+    dist = (cwz - hh0) * nw.z - radius;
     V3<T> dw = nw;
     if (type == ROW_TAN1) dw = t1w;
     if (type == ROW_TAN2) dw = t2w;
-    nloc = V3<T>{r00 * nw.x + r10 * nw.y + r20 * nw.z, r01 * nw.x + r11 * nw.y + r21 * nw.z, r02 * nw.x + r12 * nw.y + r22 * nw.z};
-    d = V3<T>{r00 * dw.x + r10 * dw.y + r20 * dw.z, r01 * dw.x + r11 * dw.y + r21 * dw.z, r02 * dw.x + r12 * dw.y + r22 * dw.z};
+    nloc = V3<T>{m00 * nw.x + m10 * nw.y + nbr.x * nw.z, m01 * nw.x + m11 * nw.y + nbr.y * nw.z, m02 * nw.x + m12 * nw.y + nbr.z * nw.z};
+    d = V3<T>{m00 * dw.x + m10 * dw.y + nbr.x * dw.z, m01 * dw.x + m11 * dw.y + nbr.y * dw.z, m02 * dw.x + m12 * dw.y + nbr.z * dw.z};
   }
   // URDF joint limit of this lane's joint ([recalled] btMultiBodyJointLimitConstraint; k = 14: HFE,
   // k = 15: KFE): distance to the NEARER limit, and the direction (+1 lower, -1 upper) that opens it
   const int ldof = k & 1;
-  const T qlim = ldof == 0 ? q1 : q2;
+  const T qlim = ldof == 0 ? qa1 : qa2;
   const T c_lo = qlim - L.limit[ldof][0], c_hi = L.limit[ldof][1] - qlim;
   const T lim_dir = c_lo < c_hi ? T(1) : T(-1), lim_dist = c_lo < c_hi ? c_lo : c_hi;
   const bool live = is_motor || (is_contact && dist < C.margin) || (is_limit && lim_dist < C.limit_margin);
-  const V3<T> x = cb - rc.radius * nloc;  // contact point in base coordinates
+  const V3<T> x = cb - radius * nloc;  // contact point in base coordinates
   T jb[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   T jl1 = T(0), jl2 = T(0), bias = T(0);
   if (is_contact) {
     const V3<T> xd = cross(x, d);
     jb[0] = xd.x; jb[1] = xd.y; jb[2] = xd.z; jb[3] = d.x; jb[4] = d.y; jb[5] = d.z;
-    if (rc.body != BODY_BASE) jl1 = dot(d, ycross(x - o1));
-    if (rc.body == BODY_LOWER) jl2 = dot(d, ycross(x - o2));
+    if (rc.body != BODY_BASE) jl1 = dot(d, ycross(x - p1));
+    if (rc.body == BODY_LOWER) jl2 = dot(d, ycross(x - p2));
     if (type == ROW_NORMAL) bias = (dist > T(0)) ? -dist * C.inv_dt : -C.erp_over_dt * dist;
   } else if (is_motor) {
     // POSITION_CONTROL motor row ([recalled] btMultiBodyJointMotor): target velocity
@@ -465,17 +573,61 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     w = T(0);
     diag = T(0);
   }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) s_rowvec[lane][i] = gh[i];
-  s_rowvec[lane][6] = hh[0];
-  s_rowvec[lane][7] = hh[1];
-  // the joint-space part again, in the slot of this row's leg of a [64][4 legs x 2] array whose
-  // other slots stay zero: a lane reads the slot of ITS leg, so "same leg" needs no test
-  s_hext[lane][2 * leg] = hh[0];
-  s_hext[lane][2 * leg + 1] = hh[1];
   const unsigned long long touching = wave_ballot(live && type == ROW_NORMAL);
   const unsigned long long limited = wave_ballot(live && is_limit);
-  wave_sync();
+  // ---- into SOLVER space.  What a lane holds while the Gauss-Seidel iteration runs: sv_type (ROW_IDLE: nothing),
+  //      its whitened row (sg, sh), the candidate at zero impulse sv_v0 = w x nid, the column scale sv_nid = -1 / A_ss,
+  //      A_ss itself for the residual test; `row_at` = where THIS lane's row (the one it built above) sits in s_rowvec /
+  //      s_hext, for the post-solve phase.
+  //  * lane = row (f32): the lane keeps the row it built.
+  //  * SLOT space (f64, ColumnBank<T>::kCompact): the live rows are permuted, in lane order, to the lanes 0 .. L-1
+  //    (the dead ones, zeroed, behind them: dst is a permutation), so that the column bank needs slots for the rows
+  //    that can move only (solo_wave_ops.h).  Lane order is solver order within each phase, a sphere's three rows stay
+  //    neighbours (normal, tangent 1, tangent 2: live together), and the phases become lane masks of this step.  The
+  //    row vectors travel through LDS, where the column build needs them anyway; the per-lane scalars through the LDS
+  //    crossbar (ds_permute: no memory).
+  int sv_type = live ? type : (int)ROW_IDLE;
+  T sv_v0 = w * -inv_d, sv_nid = -inv_d, sv_diag = diag;  // (w = inv_d = 0 on a dead row)
+  T sg[6], sh[2];
+  int sv_leg = leg, n_live = 64;
+  if constexpr (!kCompact) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { s_rowvec[lane * kRS + i] = gh[i]; sg[i] = gh[i]; }
+    s_rowvec[lane * kRS + 6] = hh[0];
+    s_rowvec[lane * kRS + 7] = hh[1];
+    sh[0] = hh[0]; sh[1] = hh[1];
+    // the joint-space part again, in the slot of this row's leg of a [64][4 legs x 2] array whose
+    // other slots stay zero: a lane reads the slot of ITS leg, so "same leg" needs no test
+    s_hext[lane][2 * leg] = hh[0];
+    s_hext[lane][2 * leg + 1] = hh[1];
+    row_at = lane;
+    wave_sync();
+  } else {
+    const unsigned long long live_lanes = wave_ballot(live);
+    n_live = __builtin_popcountll(live_lanes);               // L (wave-uniform)
+    const int below = wave_count_below(live_lanes);          // live rows on the lanes below this one
+    const int dst = live ? below : n_live + (lane - below);   // a permutation of 0 .. 63
+    row_at = dst;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s_rowvec[dst * kRS + i] = gh[i];
+    // the joint-space part in the slot of the row's leg, zeros in the other three (the leg of a slot changes from step
+    // to step: all eight are written - zeros first, then the pair: the DS operations of a wave execute in order)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_hext[dst][i] = T(0);
+    s_hext[dst][2 * leg] = hh[0];
+    s_hext[dst][2 * leg + 1] = hh[1];
+    const int tl = wave_push_int(sv_type | (leg << 4), dst);
+    sv_v0 = wave_push(sv_v0, dst);
+    sv_nid = wave_push(sv_nid, dst);
+    if constexpr (kResid) sv_diag = wave_push(sv_diag, dst);
+    sv_type = tl & 15;
+    sv_leg = tl >> 4;
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sg[i] = s_rowvec[lane * kRS + i];
+    sh[0] = s_hext[lane][2 * sv_leg];
+    sh[1] = s_hext[lane][2 * sv_leg + 1];
+  }
 
   SOLO_STAMP(B, 7);
   // ---- the scaled Delassus matrix, column by column, RESIDENT IN REGISTERS -------------------
@@ -485,12 +637,12 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // static, the LDS broadcasts of many columns in flight at once).  The Gauss-Seidel loop below
   // then fetches the column of the row it updates with ONE register-indexed move
   // (s_set_gpr_idx_on + v_mov) instead of an LDS round trip and a dot product on its serial chain.
-  // (f64 since round 3 as well: 64 doubles per lane = v[128:255], half of the 256 VGPRs of a wave at two waves per
-  // SIMD - everything the rest of the step needs while they are live fits in the other half.)
-  const T nid = -inv_d;
+  // (f64: the columns of the first ColumnBank<double>::kSlots = 32 SLOTS, 64 VGPRs; a step with more live rows
+  // builds none and takes the overflow path below.)
   ColumnBank<T> A;
-  A.init(gh, hh, nid, lane, &s_rowvec[0][0], &s_hext[0][2 * leg]);  // (+ 8 r: row r's joint-space part if r is on this lane's leg, else 0)
-  if (ColumnBank<T>::kResident) {
+  A.init(sg, sh, sv_nid, lane, s_rowvec, &s_hext[0][2 * sv_leg]);  // (+ 8 r: row r's joint-space part if r is on this lane's leg, else 0)
+  const bool overflow = kCompact && n_live > ColumnBank<T>::kSlots;  // (wave-uniform)
+  if constexpr (!kCompact) {
 #pragma unroll
     for (int l2 = 0; l2 < 4; ++l2) {
 #pragma unroll
@@ -516,7 +668,22 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
         }
       }
     }
+  } else if (!overflow) {
+    // slots 0, 1 are the first leg's motor rows; behind them the live rows come in threes when no joint-limit row is
+    // live (L = 8 + 3 x touching spheres): one test per three columns, none built in vain (a slot beyond L holds a
+    // zero row: its column would be zero and is never fetched)
+    A.build(0);
+    A.build(1);
+#pragma unroll
+    for (int j = 2; j < ColumnBank<T>::kSlots; j += 3) {
+      if (n_live > j) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (j + q < ColumnBank<T>::kSlots) A.build(j + q);
+      }
+    }
   }
+  (void)touching; (void)limited;
   SOLO_STAMP(B, 8);
   // ---- projected Gauss-Seidel, sparse in the rows that still move ---------------------------
   // Per-lane solver state: candidate v, impulse lam, bounds lo/hi (friction bounds follow their
@@ -526,12 +693,15 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // pending rows in solver order (motor rows, normal rows, friction rows) with a scalar
   // find-first-set; only those rows cost anything, and after each change the set is re-evaluated,
   // so the decisions are the ones a dense sweep over every row would take.
+  const bool sv_motor = sv_type == ROW_MOTOR, sv_limit = sv_type == ROW_LIMIT, sv_normal = sv_type == ROW_NORMAL;
+  const bool is_tan1 = sv_type == ROW_TAN1, is_tangent = sv_type == ROW_TAN1 || sv_type == ROW_TAN2;
   const T imp = C.motor_impulse;
+  if constexpr (sizeof(T) == 8) mu = s_keep[27];
   T lo = T(0), hi = T(0);
-  if (is_motor) { lo = -imp; hi = imp; }
-  else if (live && (type == ROW_NORMAL || is_limit)) hi = R::big();
+  if (sv_motor) { lo = -imp; hi = imp; }
+  else if (sv_normal || sv_limit) hi = R::big();
   T lamv = T(0);
-  T v = live ? w * nid : T(0);  // lam = 0
+  T v = sv_v0;  // lam = 0
   const T tol_rel = T(wave_uniform(C.ulp_tol)) * R::half_ulp();
   const int iters = wave_uniform(C.iterations);  // scalar trip count
   // pybullet's solverResidualThreshold ([recalled] default 1e-7; SoloConfig::solver_residual_threshold): the iteration
@@ -542,31 +712,28 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // It is a compile-time property of the kernel (kResid; the engine launches solo_step_kernel<T, kFull, true> when the
   // configuration asks for it): the default kernels carry none of it.
   const T resid_thr = C.resid_thr;
-  constexpr bool use_resid = kResid;
-  // rows of one sweep, in solver order ([recalled] btMultiBodyConstraintSolver::solveSingleIteration):
-  // the non-contact rows (joint motors, joint limits), then ALL normal contact rows, then ALL friction rows
-  constexpr unsigned long long kPhaseLanes[3] = {0xc003c003c003c003ull,    // motors k = 0, 1 and joint limits k = 14, 15, leg by leg
-                                                 0x0924092409240924ull,    // normals  k = 2, 5, 8, 11
-                                                 0x36d836d836d836d8ull};   // friction k = 3, 4, 6, 7, 9, 10, 12, 13
-  const bool is_tangent = type == ROW_TAN1 || type == ROW_TAN2;
+  // rows of one sweep, in solver order (kPhaseLanes): constants of the lane = row layout, lane masks of this step
+  // in slot space
+  unsigned long long ph0 = kPhaseLanes[0], ph1 = kPhaseLanes[1], ph2 = kPhaseLanes[2];
+  if constexpr (kCompact) {
+    ph0 = wave_ballot(sv_motor || sv_limit);
+    ph1 = wave_ballot(sv_normal);
+    ph2 = wave_ballot(is_tangent);
+  }
   T cand = R::clamp(v, lo, hi);
   T dl = cand - lamv;
   unsigned long long pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
-#ifdef SOLO_STAMPS
   int n_changed = 0;
-#endif
   int it = 0;
 #ifdef SOLO_PGS_GFX950
-  // on the GPU: the loop below, written in assembly (solo_pgs_gfx950.h, f32 and f64) - same rows, same order, same
-  // arithmetic; this C++ form stays the definition (the CPU emulator, and the -DSOLO_PGS_NO_ASM test
+  // on the GPU: the loop written in assembly (solo_pgs_gfx950.h, f32 and f64) - same rows, same order, same
+  // arithmetic as pgs_solve_cpp, which stays the definition (the CPU emulator, and the -DSOLO_PGS_NO_ASM test
   // build the assembly is compared against bit for bit: tests/test_gpu_pgs_asm.py).
-  {
-    int rows_updated = 0;
-    const unsigned long long tan1_lanes = wave_ballot(type == ROW_TAN1), tangent_lanes = wave_ballot(is_tangent);
+  if (!overflow) {
+    const unsigned long long tan1_lanes = wave_ballot(is_tan1), tangent_lanes = wave_ballot(is_tangent);
     if constexpr (!kResid) {
       // the default configuration: ONE straight-line call runs all the sweeps
-      it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes,
-                            kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2], iters, rows_updated);
+      it = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes, ph0, ph1, ph2, iters, n_changed);
     } else {
       // pybullet's residual threshold (opt-in; kernel instantiations of their own, so that the default kernels keep
       // their code): the loop is entered for ONE sweep at a time and the test - one for all 64 rows - sits between
@@ -574,17 +741,13 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 #pragma unroll 1
       for (;;) {
         const T lam_sweep_start = lamv;
-        const int n = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes,
-                                       kPhaseLanes[0], kPhaseLanes[1], kPhaseLanes[2], 1, rows_updated);
+        const int n = pgs_solve_gfx950(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, tan1_lanes, tangent_lanes, ph0, ph1, ph2, 1, n_changed);
         it += n;
         if (n == 0 || it >= iters) break;   // (n == 0: nothing was pending at the start of the sweep)
-        const T dvel = (lamv - lam_sweep_start) * diag;
+        const T dvel = (lamv - lam_sweep_start) * sv_diag;
         if (wave_ballot(dvel * dvel > resid_thr) == 0ull) break;
       }
     }
-#ifdef SOLO_STAMPS
-    n_changed = rows_updated;
-#endif
 #if defined(SOLO_PGS_HAZARD_PROBE)
     // DIAGNOSTIC builds only: is the register-index mode still ON behind the loop?  (MODE[27] = gpr_idx_en; counted in
     // slot 7 of the statistics row, and switched off so that nothing behind the loop computes with it)
@@ -594,56 +757,15 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
       if (stuck != 0 && lane == 0) stats_add(&B.stats[7], 1.0);
     }
 #endif
-  }
+  } else
 #else
-#pragma unroll 1
-  for (; it < iters && pend != 0ull; ++it) {  // nothing pending at the start of a sweep: converged
-    // (the register banks of the matrix are walked one after the other - static bank per loop - which
-    // keeps the rows of a phase in ascending lane order)
-    const T lam_sweep_start = lamv;
-    bool normals_moved = false;  // (wave-uniform)
-#pragma unroll
-    for (int phase = 0; phase < 3; ++phase) {
-      if (phase == 2 && normals_moved) {
-        // the friction rows of a contact are limited by mu x the normal impulse it holds NOW: the
-        // normal rows are done for this sweep, so all limits are refreshed at once (a friction
-        // row's normal row sits one or two lanes below it: DPP row shifts) instead of per moved row
-        // - and only in a sweep that moved a normal row (all limits start at mu x 0 = 0)
-        const T n1 = wave_lane_below<1>(lamv), n2 = wave_lane_below<2>(lamv);
-        const T lim = mu * (type == ROW_TAN1 ? n1 : n2);
-        lo = is_tangent ? -lim : lo;
-        hi = is_tangent ? lim : hi;
-        cand = R::clamp(v, lo, hi);
-        dl = cand - lamv;
-        pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
-      }
-      if ((pend & kPhaseLanes[phase]) == 0ull) continue;  // nothing of this phase moves: one test for its banks
-      if (phase == 1) normals_moved = true;
-#pragma unroll
-      for (int bank = 0; bank < ColumnBank<T>::kBanks; ++bank) {
-        unsigned long long window = kPhaseLanes[phase] & ColumnBank<T>::bank_lanes(bank);
-#pragma unroll 1
-        while ((pend & window) != 0ull) {
-          const int r = __builtin_ctzll(pend & window);  // wave-uniform: the row to update
-          window &= ~((2ull << r) - 1ull);               // the cursor moves past it
-          const T col = A.get(bank, r);                  // column r of the scaled matrix (0 for the row itself)
-          const T delta = wave_readlane(dl, r);
-          v = R::fma(col, delta, v);
-          lamv = (lane == r) ? cand : lamv;
-          cand = R::clamp(v, lo, hi);
-          dl = cand - lamv;
-          pend = wave_ballot(R::abs(dl) > R::abs(lamv) * tol_rel);
-#ifdef SOLO_STAMPS
-          ++n_changed;
+  if (!overflow) it = pgs_solve_cpp<T, kResid, false>(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, is_tan1, is_tangent, ph0, ph1, ph2, iters, sv_diag, resid_thr, n_changed);
+  else
 #endif
-        }
-      }
-    }
-    SOLO_PGS_SWEEP_HOOK(it, pend, lamv, v);
-    const T dvel = (lamv - lam_sweep_start) * diag;
-    if (use_resid && wave_ballot(dvel * dvel > resid_thr) == 0ull) { ++it; break; }  // the residual threshold (see above)
+  {
+    // the overflow path of the slot-space solver (more live rows than column slots; never taken with lane = row)
+    if constexpr (kCompact) it = pgs_solve_cpp<T, kResid, true>(A, v, lamv, cand, dl, pend, lo, hi, tol_rel, lane, mu, is_tan1, is_tangent, ph0, ph1, ph2, iters, sv_diag, resid_thr, n_changed);
   }
-#endif
 #ifdef SOLO_STAMPS
   if (lane == 0) {
     // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28
@@ -653,6 +775,9 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     B.acc[0] += (unsigned long long)n_changed;
   }
 #endif
+  (void)n_changed;
+  // back to lane = row: the impulse of the row THIS lane built (the post-solve phase sums per leg over the 16 lanes of a leg)
+  if constexpr (kCompact) lamv = wave_pull(lamv, row_at);
   // Issue priority of this wave in its SIMD (s_setprio).  Two effects are countered (both measured
   // with per-wave start / end stamps, tools/gpu_tail.py):
   //  * a SIMD arbitrates its waves by priority, then AGE: at equal priority the oldest of the four
@@ -674,18 +799,24 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 // post-solve half: apply the impulses (du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam -
 // K du_b), go back to world-frame velocities and integrate.  Everything is re-read from LDS.
 template <typename T>
-__device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, const T (*s_rowvec)[8],
-                                               const T* s_keep, const T (*s_leg)[kLegSlots], const T* s_math, T lam, int lane) {
+__device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, const T* s_rowvec, const T (*s_hext)[8],
+                                               const T* s_keep, const T (*s_leg)[kLegSlots], const T* s_math, T lam, int lane, int row_at) {
   using R = Real<T>;
+  constexpr int kRS = ColumnBank<T>::kRowStride;
   const int leg = lane >> 4, k = lane & 15;
   const T dt = C.dt;
   // z = sum over all rows of ghat * lam (6 wave-wide sums), yl = per-leg sums of hhat * lam (2 sums over
   // the 16 lanes of a leg): eight reductions, interleaved stage by stage (wave_reduce_rows)
   T z[6], yl[2];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) z[i] = s_rowvec[lane][i] * lam;
-  yl[0] = s_rowvec[lane][6] * lam;
-  yl[1] = s_rowvec[lane][7] * lam;
+  for (int i = 0; i < 6; ++i) z[i] = s_rowvec[row_at * kRS + i] * lam;
+  if constexpr (ColumnBank<T>::kCompact) {  // (slot space: the row vectors carry no joint-space part; it sits in the slot of the row's leg)
+    yl[0] = s_hext[row_at][2 * leg] * lam;
+    yl[1] = s_hext[row_at][2 * leg + 1] * lam;
+  } else {
+    yl[0] = s_rowvec[row_at * kRS + 6] * lam;
+    yl[1] = s_rowvec[row_at * kRS + 7] * lam;
+  }
   wave_reduce_rows(z, yl);
   const T yl1 = yl[0], yl2 = yl[1];
   // C^T x = z (back substitution with the parked Cholesky factor)
@@ -747,72 +878,51 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
 // the fused kernel
 // ------------------------------------------------------------------------------------------
 // __launch_bounds__(64, W): W waves per SIMD -> 512/W VGPRs.  f32: 4 (128 VGPRs, a whole 4096-robot
-// batch resident on the 1024 SIMDs); f64: 2 (256 VGPRs: the resident columns alone are 128).
+// batch resident on the 1024 SIMDs); f64: 3 (168 VGPRs - the resident columns of the slot-space solver are 64 - and
+// 13.0 KB of LDS: twelve workgroups per CU; round 3: 2, with 128 VGPRs of columns).
 // kFull = false: physics-only instantiation (flags are treated as SOLO_STEP_PHYSICS).
 // single-step launches evaluate their outputs in the step kernel itself (see the step loop): f32 only
-#ifdef SOLO_GROUP8
-template <typename T, bool kFull> constexpr bool kInlineOutputs = false;  // (the experiment build leaves records)
-constexpr int kRobotsPerGroup = kG8;
-#else
 template <typename T, bool kFull> constexpr bool kInlineOutputs = kFull && sizeof(T) == 4;
-constexpr int kRobotsPerGroup = 1;
+#ifndef SOLO_F64_WAVES
+#define SOLO_F64_WAVES 3   // (-DSOLO_F64_WAVES=2: the A/B build of tools/gpu_occupancy_sweep.py, never the product)
 #endif
+template <typename T> constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : SOLO_F64_WAVES;
 
 template <typename T, bool kFull, bool kResid = false>
-__global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void solo_step_kernel(const KParams<T>* __restrict__ Pin, KBuffers<T> Bin) {
+__global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const KParams<T>* __restrict__ Pin, KBuffers<T> Bin) {
   KBuffers<T> B = Bin;
   if (!kFull) B.flags = SOLO_STEP_PHYSICS;
   using R = Real<T>;
-#ifdef SOLO_GROUP8
-  // EXPERIMENT build: 8 waves = 8 robots per workgroup; every robot's arrays are a slice of the group's
-  __shared__ T s_state_g[kG8][SOLO_STATE_STRIDE];
-  __shared__ T s_rows_g[kG8][2][64][8];
-  __shared__ T s_keep_g[kG8][32];
-  __shared__ T s_leg_g[kG8][4][kLegSlots];
-  __shared__ int s_cnt_g[kG8][64];
-  __shared__ int s_termlim_g[kG8][64];
-  __shared__ int s_termtick_g[kG8][64];
-  __shared__ T s_mass_g[kG8];
-  const int wave_in_group = (int)threadIdx.x >> 6;
-  T* const s_state = s_state_g[wave_in_group];
-  T (*const s_rows)[64][8] = s_rows_g[wave_in_group];
-  T (*const s_rowvec)[8] = s_rows[0];
-  T (*const s_hext)[8] = s_rows[1];
-  T* const s_keep = s_keep_g[wave_in_group];
-  T (*const s_leg)[kLegSlots] = s_leg_g[wave_in_group];
-  int* const s_cnt = s_cnt_g[wave_in_group];
-  int* const s_termlim = s_termlim_g[wave_in_group];
-  int* const s_termtick = s_termtick_g[wave_in_group];
-#else
   __shared__ T s_state[SOLO_STATE_STRIDE];
-  __shared__ T s_rows[2][64][8];   // ONE block: the output epilogue uses it as its 1024-value scratch
-  T (*const s_rowvec)[8] = s_rows[0];
-  T (*const s_hext)[8] = s_rows[1];   // joint-space parts by leg slot (see physics_solve); zero except the row's own leg
+  // ONE block: the whitened row vectors [64][kRS], their joint-space parts by leg slot [64][4 legs x 2] (see
+  // physics_solve; zero except the row's own leg) and the per-row geometry [64][centre 3, radius] - the output epilogue
+  // (where all three are dead) uses it as its 1024-value scratch
+  constexpr int kRS = ColumnBank<T>::kRowStride;
+  constexpr int kRowsReals = 64 * kRS + 64 * 8;
+  __shared__ T s_blk[kRowsReals + 64 * 4];
+  static_assert(kRowsReals + 64 * 4 >= SOLO_MAX_REWARD_OPS * 32, "the output epilogue's scratch");
+  T* const s_rowvec = s_blk;
+  T (*const s_hext)[8] = reinterpret_cast<T (*)[8]>(s_blk + 64 * kRS);
+  T (*const s_rowgeo)[4] = reinterpret_cast<T (*)[4]>(s_blk + kRowsReals);
+  __shared__ int32_t s_rowtype[64];  // RowConst::type | RowConst::body << 8
   __shared__ T s_keep[32];
-  __shared__ T s_leg[4][20];
+  __shared__ T s_leg[4][kLegSlots];
   // termination (termination.py:38-83), one lane per termination (lanes >= SOLO_MAX_TERMS: never fire):
   // s_cnt = TimeBased step counters, s_termlim = the count above which lane t fires (-1: always - a
   // Constant(True) -, INT_MAX: never), s_termtick = 1 for the lanes whose counter ticks (TimeBased)
   __shared__ int s_cnt[64];
   __shared__ int s_termlim[64];
   __shared__ int s_termtick[64];
-#endif
   // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
   // read them from LDS instead of paying a global-load latency each
   __shared__ LegConst<T> s_legc[4];
-  __shared__ RowConst<T> s_rowc[64];
   __shared__ StepConst<T> s_const;          // the scalars a step reads (see solo_kernel_params.h)
   // coefficient table of Real<T>'s polynomials (f64 only: see Real<double>::sincos; f32 uses instruction literals)
   __shared__ T s_math[Real<T>::kTabSize > 0 ? Real<T>::kTabSize : 1];
 
-#ifdef SOLO_GROUP8
-  const int lane0 = lane_id() & 63;
-  const int slot = block_id() * kG8 + wave_in_group + B.env_base;  // (the engine launches whole groups only)
-#else
   const int lane0 = lane_id();
   const int slot = block_id() + B.env_base;
   if (slot >= B.num_envs) return;
-#endif
   // (wave_cold_args assumes the kernel's parameter layout - one pointer, then this block: checked on
   // two fields, so that a changed signature traps instead of reading garbage)
   if (wave_cold_args(Bin)->num_envs != B.num_envs || wave_cold_args(Bin)->steps != B.steps) __builtin_trap();
@@ -820,11 +930,7 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
   // robot), else the XCD-contiguous map (xcd_contiguous, solo_kernel_params.h: the robots whose waves share an L2 are
   // neighbours in the batch, so their rows of the [step][robot][.] arrays complete each other's cache lines there)
   const int32_t* order = wave_cold_args(Bin)->order;
-#ifdef SOLO_GROUP8
-  const int env = order != nullptr ? wave_uniform(order[slot]) : slot;
-#else
   const int env = order != nullptr ? wave_uniform(order[slot]) : B.env_base + xcd_contiguous(block_id(), B.count);
-#endif
 #ifdef SOLO_STAMPS
   B.stamp_row = env;
 #endif
@@ -880,15 +986,18 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
     int32_t* const_dst = reinterpret_cast<int32_t*>(&s_const);
 #pragma unroll
     for (int j = 0; j < kLegLoads; ++j) if (lane0 + 64 * j < kLegWords) leg_dst[lane0 + 64 * j] = leg_w[j];
-    s_rowc[lane0] = row_w;
+    s_rowtype[lane0] = row_w.type | (row_w.body << 8);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s_rowgeo[lane0][i] = row_w.center[i];
+    s_rowgeo[lane0][3] = row_w.radius;
 #pragma unroll
     for (int j = 0; j < kConstLoads; ++j) if (lane0 + 64 * j < kConstWords) const_dst[lane0 + 64 * j] = const_w[j];
     if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = state_w;
     s_cnt[lane0] = count_w;
+    // f64: the robot's friction coefficient and base-mass scale wait in LDS, not in two register pairs held across the
+    // whole step loop (the f64 kernel lives on 168 VGPRs: see physics_solve, "PARK EARLY")
+    if constexpr (sizeof(T) == 8) { if (lane0 == 0) { s_keep[27] = mu; s_keep[28] = mass_scale; } }
     if constexpr (Real<T>::kTabSize > 0) { if (lane0 < Real<T>::kTabSize) s_math[lane0] = math_w; }
-#ifdef SOLO_GROUP8
-    if (lane0 == 0) s_mass_g[wave_in_group] = mass_scale;
-#endif
   }
   int prio_sweeps = wave_uniform(hist_w);
   const int hist_sweeps = prio_sweeps;
@@ -919,7 +1028,8 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
     const int lane = wave_opaque_lane(lane0);  // per-lane address arithmetic stays in the step instead of being
     // hoisted out of the fused step loop and kept live across it (spills)
     const LegConst<T>& L = s_legc[lane >> 4];
-    const RowConst<T>& rc = s_rowc[lane];
+    const int row_tb = s_rowtype[lane];
+    const RowView<T> rc = {row_tb & 255, row_tb >> 8, s_rowgeo[lane]};
     // setJointMotorControlArray (solo8v2vanilla.py:87-90): every motor lane fetches the target of ITS
     // joint straight from global memory.  The value is consumed when the motor rows are built,
     // thousands of cycles into the step, so the load's latency is never waited for (funnelled
@@ -938,15 +1048,10 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
     SOLO_STAMP(B, 1);
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
-#ifdef SOLO_GROUP8
-      group_sync();  // every robot of the group has its state of the previous step (or the prologue's) in LDS
-      if (wave_in_group == 0)
-        physics_dynamics_g8<T>(C, s_legc, &s_state_g[0][0], &s_keep_g[0][0], &s_leg_g[0][0][0], s_mass_g, s_math, lane);
-      group_sync();  // ... and its factors / unconstrained velocities from the dynamics wave
-#endif
       const T my_target = raw_target * target_scale;
-      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, prio_sweeps, prio_steps, prio_rot);
-      physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, s_math, lam, lane);
+      int row_at;  // where this lane's constraint row sits in s_rowvec / s_hext (its lane, or its slot: see physics_solve)
+      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, prio_sweeps, prio_steps, prio_rot);
+      physics_finish<T>(C, s_state, s_rowvec, s_hext, s_keep, s_leg, s_math, lam, lane, row_at);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted
       const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) || (motor_lane && !R::finite(my_target));
@@ -1059,7 +1164,7 @@ __global__ __launch_bounds__(64 * kRobotsPerGroup, sizeof(T) == 4 ? 4 : 2) void 
     const auto A = wave_cold_args(Bin);
     const int n_obs = wave_uniform(s_const.num_obs), n_rops = wave_uniform(s_const.num_reward_ops);
     constexpr int kPass = 32;
-    T* const val = &s_rows[0][0][0];                                 // [n_rops][kPass]
+    T* const val = s_blk;                                            // [n_rops][kPass]
     uint8_t* const ev_bytes = reinterpret_cast<uint8_t*>(s_termlim);  // (the termination tables are dead)
     const T* const my_traj = B.traj + (size_t)env * (size_t)B.steps * SOLO_STATE_STRIDE;
     const bool want_reward = (B.flags & SOLO_STEP_REWARD) != 0;

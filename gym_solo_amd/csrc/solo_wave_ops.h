@@ -13,14 +13,7 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x; }
 __device__ __forceinline__ int block_id() { return blockIdx.x; }
 
 // Orders this wave's LDS writes before the following LDS reads of other lanes.
-#ifdef SOLO_GROUP8
-// (EXPERIMENT build, 8 waves per workgroup: a wave-local fence - the DS operations of one wave execute in order -
-// and a real barrier of the group where the waves hand data to each other)
-__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void group_sync() { __syncthreads(); }
-#else
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
-#endif
 // orders this wave's global stores before its later global loads of the same lines by OTHER lanes of the wave
 // (the output epilogue re-reads the step records): release + acquire at workgroup scope = the waits, no cache operation
 __device__ __forceinline__ void wave_fence_global() {
@@ -100,6 +93,35 @@ template <typename T> __device__ __forceinline__ T wave_from_lower_half16(T x) {
 template <typename T> __device__ __forceinline__ T wave_from_upper_half16(T x) { return dpp_half_bcast<0xc>(x); }
 // the value of lane - N inside the caller's 16-lane row (DPP row_shr:N; the first N lanes of a row get 0)
 template <int N, typename T> __device__ __forceinline__ T wave_lane_below(T x) { return dpp_mov<0x110 + N>(x); }
+// the value of lane - N of the WHOLE wave (lanes < N get 0): DPP wave_shr:1 (a GFX9 control, like row_bcast), N times.
+// The slot-space solver (ColumnBank<T>::kCompact) keeps a contact's rows in three consecutive SLOTS, which may straddle
+// a 16-lane row: row_shr does not cross it.
+template <int N, typename T> __device__ __forceinline__ T wave_slot_below(T x) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) x = dpp_mov<0x138>(x);
+  return x;
+}
+// number of set bits of a wave-uniform lane mask BELOW this lane (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ int wave_count_below(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+// PUSH: lane l's value goes to lane dst[l] (dst: a permutation of 0..63) - ds_permute_b32: the LDS crossbar, no LDS
+// memory.  PULL: lane l gets the value of lane src[l] - ds_bpermute_b32.
+__device__ __forceinline__ int wave_push_int(int x, int dst) { return __builtin_amdgcn_ds_permute(dst << 2, x); }
+__device__ __forceinline__ float wave_push(float x, int dst) { return __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(x))); }
+__device__ __forceinline__ double wave_push(double x, int dst) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_ds_permute(dst << 2, (int)(b & 0xffffffffll));
+  const int hi = __builtin_amdgcn_ds_permute(dst << 2, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float wave_pull(float x, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(x))); }
+__device__ __forceinline__ double wave_pull(double x, int src) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int)(b & 0xffffffffll));
+  const int hi = __builtin_amdgcn_ds_bpermute(src << 2, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 // sum over the 16 lanes of the caller's row, result in every lane (row_ror 8,4,2,1 all-reduce)
 template <typename T> __device__ __forceinline__ T wave_sum_group16(T x) {
   x += dpp_mov<0x128>(x);
@@ -172,10 +194,12 @@ template <typename T> struct RowDot {
     for (int i = 0; i < 6; ++i) g[i] = gh[i];
     h[0] = hh[0]; h[1] = hh[1];
   }
+  // (explicit fused multiply-adds: the resident columns and the columns the overflow path of the slot-space solver
+  // evaluates on the fly are the same bits in every inlined copy, whatever -ffp-contract decides elsewhere)
   __device__ __forceinline__ T dot(const T* rg, const T* rh) const {
-    const T a1 = g[0] * rg[0] + g[1] * rg[1] + g[2] * rg[2];
-    const T a2 = g[3] * rg[3] + g[4] * rg[4] + g[5] * rg[5];
-    return (a1 + a2) + (h[0] * rh[0] + h[1] * rh[1]);
+    const T a1 = __builtin_fma(g[2], rg[2], __builtin_fma(g[1], rg[1], g[0] * rg[0]));
+    const T a2 = __builtin_fma(g[5], rg[5], __builtin_fma(g[4], rg[4], g[3] * rg[3]));
+    return (a1 + a2) + __builtin_fma(h[1], rh[1], h[0] * rh[0]);
   }
 };
 template <> struct RowDot<float> {
@@ -205,6 +229,8 @@ typedef float solo_f32x32 __attribute__((ext_vector_type(32)));
 template <typename T> struct ColumnBank;
 template <> struct ColumnBank<float> {
   static constexpr bool kResident = true;
+  static constexpr bool kCompact = false;    // lane = constraint row (fixed layout: solo_kernel_params.h)
+  static constexpr int kSlots = 64, kRowStride = 8;
   static constexpr int kBanks = 2;
   static __device__ __forceinline__ constexpr unsigned long long bank_lanes(int b) { return 0xffffffffull << (32 * b); }
   RowDot<float> own;
@@ -222,31 +248,39 @@ template <> struct ColumnBank<float> {
   __device__ __forceinline__ void build(int r) { const float x = column(r); if (r < 32) a0[r] = x; else a1[r - 32] = x; }
   __device__ __forceinline__ float get(int bank, int r) const { return bank == 0 ? a0[r & 31] : a1[r & 31]; }
 };
-// f64 (the reference's precision; round 3): resident as well - 64 doubles per lane in four 16-wide tuples = 128
-// VGPRs, half of the 256 a wave has at two waves per SIMD.  The rest of the step fits in the other half while
-// the columns are live (everything the post-solve phase needs is parked in LDS across the solver).
+// f64 (the reference's precision): resident as well, but only for the LIVE rows (round 4).  64 doubles per lane were
+// 128 VGPRs - half of a wave's registers at two waves per SIMD, and the reason for two waves per SIMD.  The rows that
+// can move in a step are the 8 motor rows, three per sphere within the contact margin and the rare joint-limit rows:
+// 8 + 3 x touching spheres - at most 32 in 99.97 % of the robot-steps of the benchmark workload, at most 44 on a
+// plane (profiles/round4_live_rows_histogram.log).  So the f64 solver runs in SLOT space (kCompact): the step kernel
+// permutes the live rows, in lane order, to the lanes 0 .. L-1 (solo_step_kernel.h), lane = slot holds slot's row,
+// and the bank holds the columns of slots 0 .. 31 only: 32 doubles per lane = 64 VGPRs -> the kernel fits the 168
+// VGPRs of THREE waves per SIMD.  A step with more than 32 live rows (a robot lying on everything it has) takes the
+// overflow path: the same iteration with every column evaluated from LDS when it is used (column(), the expression
+// build() stores) - slower per row, the same bits.  Row vectors in LDS: 6 doubles per row (the joint-space part
+// lives in the per-leg slots of s_hext only).
 typedef double solo_f64x16 __attribute__((ext_vector_type(16)));
 template <> struct ColumnBank<double> {
   static constexpr bool kResident = true;
-  static constexpr int kBanks = 4;
+  static constexpr bool kCompact = true;
+  static constexpr int kSlots = 32, kRowStride = 6;
+  static constexpr int kBanks = 2;
   static __device__ __forceinline__ constexpr unsigned long long bank_lanes(int b) { return 0xffffull << (16 * b); }
   RowDot<double> own;
   double nid;
   int lane;
   const double* rowvec;
   const double* hext;
-  solo_f64x16 a0, a1, a2, a3;
+  solo_f64x16 a0, a1;
   __device__ __forceinline__ void init(const double* gh, const double* hh, double nid_, int lane_, const double* rowvec_, const double* hext_) {
     own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; hext = hext_;
   }
-  __device__ __forceinline__ double column(int r) const { const double m = (lane == r) ? 0.0 : nid; return m * own.dot(rowvec + 8 * r, hext + 8 * r); }
+  __device__ __forceinline__ double column(int r) const { const double m = (lane == r) ? 0.0 : nid; return m * own.dot(rowvec + kRowStride * r, hext + 8 * r); }
   __device__ __forceinline__ void build(int r) {
     const double x = column(r);
-    if (r < 16) a0[r] = x; else if (r < 32) a1[r - 16] = x; else if (r < 48) a2[r - 32] = x; else a3[r - 48] = x;
+    if (r < 16) a0[r] = x; else a1[r - 16] = x;
   }
-  __device__ __forceinline__ double get(int bank, int r) const {
-    return bank == 0 ? a0[r & 15] : (bank == 1 ? a1[r & 15] : (bank == 2 ? a2[r & 15] : a3[r & 15]));
-  }
+  __device__ __forceinline__ double get(int bank, int r) const { return bank == 0 ? a0[r & 15] : a1[r & 15]; }
 };
 
 // The kernel's by-value buffer block, re-read from the kernarg segment (constant address space ->

@@ -139,9 +139,12 @@ template <typename T> struct RowDot {
   }
 };
 
-// the register-resident matrix of the GPU build (solo_wave_ops.h ColumnBank<float>) as a plain array
+// the register-resident matrix of the GPU build (solo_wave_ops.h ColumnBank<T>) as a plain array.  Like the GPU
+// build: f32 with lane = row, f64 in SLOT space with 32 resident column slots (the overflow path evaluates column()).
 template <typename T> struct ColumnBank {
   static constexpr bool kResident = true;
+  static constexpr bool kCompact = sizeof(T) == 8;
+  static constexpr int kSlots = kCompact ? 32 : 64, kRowStride = kCompact ? 6 : 8;
   static constexpr int kBanks = 1;
   static constexpr unsigned long long bank_lanes(int) { return ~0ull; }
   RowDot<T> own;
@@ -154,7 +157,7 @@ template <typename T> struct ColumnBank {
     own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; hext = hext_;
     for (int r = 0; r < 64; ++r) a[r] = std::nan("");  // a column that was never built must never be used
   }
-  T column(int r) const { const T m = (lane == r) ? T(0) : nid; return m * own.dot(rowvec + 8 * r, hext + 8 * r); }
+  T column(int r) const { const T m = (lane == r) ? T(0) : nid; return m * own.dot(rowvec + kRowStride * r, hext + 8 * r); }
   void build(int r) { a[r] = column(r); }
   T get(int, int r) const { return a[r]; }
 };
@@ -183,6 +186,32 @@ template <int N, typename T> inline T wave_lane_below(T x) {
   const T y = wave_readlane(x, (l & 15) >= N ? l - N : l);
   return (l & 15) >= N ? y : T(0);
 }
+// the value of lane - N of the whole wave (lanes < N get 0)
+template <int N, typename T> inline T wave_slot_below(T x) {
+  const int l = lane_id();
+  const T y = wave_readlane(x, l >= N ? l - N : l);
+  return l >= N ? y : T(0);
+}
+inline int wave_count_below(unsigned long long mask) { return __builtin_popcountll(mask & ((1ull << lane_id()) - 1ull)); }
+// PUSH: lane l's value goes to lane dst[l] (a permutation); PULL: lane l gets the value of lane src[l]
+inline uint64_t emu_push_bits(uint64_t bits, int dst) {
+  WaveEmu& e = WaveEmu::get();
+  e.post((uint64_t)(unsigned)dst);
+  e.yield();
+  int src = -1;
+  for (int l = 0; l < WaveEmu::W; ++l) if ((int)e.peek(l) == e.lane()) { if (src >= 0) { std::fprintf(stderr, "wave_push: not a permutation\n"); std::abort(); } src = l; }
+  if (src < 0) { std::fprintf(stderr, "wave_push: not a permutation\n"); std::abort(); }
+  e.yield();
+  e.post(bits);
+  e.yield();
+  const uint64_t v = e.peek(src);
+  e.yield();
+  return v;
+}
+inline int wave_push_int(int x, int dst) { return (int)(uint32_t)emu_push_bits((uint32_t)x, dst); }
+inline float wave_push(float x, int dst) { uint32_t b; std::memcpy(&b, &x, 4); b = (uint32_t)emu_push_bits(b, dst); std::memcpy(&x, &b, 4); return x; }
+inline double wave_push(double x, int dst) { uint64_t b; std::memcpy(&b, &x, 8); b = emu_push_bits(b, dst); std::memcpy(&x, &b, 8); return x; }
+template <typename T> inline T wave_pull(T x, int src) { return wave_readlane(x, src); }
 template <typename T> inline T wave_sum_group16(T x) {
   x += emu_shfl_xor(x, 8);
   x += emu_shfl_xor(x, 4);
