@@ -47,13 +47,14 @@ SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICR
 METRIC = 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X'
 
 
-def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1, residual_threshold=0.0):
+def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1, residual_threshold=0.0, migrate_steps=0):
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
   cfg = Solo8VanillaConfig()
   cfg.num_envs, cfg.device, cfg.dtype, cfg.auto_reset = num_envs, device, dtype, True
   cfg.steps_per_launch, cfg.rollout_streams = steps_per_launch, rollout_streams
   cfg.solver_residual_threshold = residual_threshold
+  cfg.migrate_steps = migrate_steps
   env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
   register_benchmark_workload(env, max_steps=max_steps)
   env._ensure_program()
@@ -300,6 +301,9 @@ def main():
   ap.add_argument('--rollout-streams', type=int, default=2,
                   help='batch slices advancing as independent launch chains on separate HIP streams '
                        '(only used when a rollout needs more than one launch per slice)')
+  ap.add_argument('--migrate-steps', type=int, default=-1,
+                  help='SoloConfig.migrate_steps of the rollouts: robots change waves every this many steps of a launch '
+                       '(0 = off; -1 = where it pays: half the launch for a single-launch f64 rollout, else off)')
   ap.add_argument('--min-seconds', type=float, default=0.5, help='repeat the K-step timed region until this much time ...')
   ap.add_argument('--max-repeats', type=int, default=30, help='... or this many repeats have accumulated')
   args = ap.parse_args()
@@ -362,7 +366,15 @@ def main():
     # chain is all there is to overlap: no stream slices)
     spl = 1 if closed_loop else max(1, min(args.steps_per_launch, k))
     streams = max(1, args.rollout_streams) if (k > spl and not closed_loop) else 1
-    env = build_env(n, local_rank, dtype, steps_per_launch=spl, rollout_streams=streams, residual_threshold=residual_threshold)
+    # robot migration inside a launch (SoloConfig.migrate_steps: scheduling only, results bit-identical): where it pays -
+    # f64 (4096 robots on 3072 wave slots) when the rollout is ONE launch, so that no other launch overlaps its tail
+    # (measured, tools/gpu_migrate_sweep.py + gpu_occupancy_sweep.py: K = 20 in two chunks +14 %; 250-step launches on
+    # two stream slices -5 ... -15 %; f32 - every robot resident from the first cycle - -5 %)
+    migrate = args.migrate_steps
+    if migrate < 0:
+      migrate = (spl + 1) // 2 if (dtype == 'float64' and not closed_loop and spl >= 8 and k == spl) else 0
+    env = build_env(n, local_rank, dtype, steps_per_launch=spl, rollout_streams=streams, residual_threshold=residual_threshold,
+                    migrate_steps=migrate)
     eng = env.engine
     gen = torch.Generator(device=dev).manual_seed(rank_seed(1234, rank))
 
@@ -500,7 +512,7 @@ def main():
       'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
                              'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
                              'TimeBasedTermination(1000)+auto-reset, steady state (episode phases spread uniformly by 1000 untimed steps), dt=1e-3, 50 PGS iterations' % n,
-                 'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': slices,
+                 'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': slices, 'migrate_steps': int(eng.cfg.migrate_steps),
                  'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'timing': {'repeats': len(times), 'statistic': 'median', 'min_ms_per_step': min(times) / k * 1e3,
                  'max_ms_per_step': max(times) / k * 1e3, 'value_best_repeat': world * n * k / min(times),

@@ -7,7 +7,7 @@ as DATA (``SoloModel``/``SoloConfig``).
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NUM_LEGS = 4
 NUM_DOF = 8
 NUM_JOINTS = 12
@@ -96,6 +96,8 @@ class SoloConfig(C.Structure):
     ('rollout_streams', C.c_int32),
     ('solver_ulp_tolerance', C.c_int32),
     ('solver_residual_threshold', C.c_double),
+    ('migrate_steps', C.c_int32),
+    ('reserved0', C.c_int32),
   ]
 
 

@@ -66,6 +66,10 @@ class Solo8BaseConfig:
   auto_reset: bool = False
   steps_per_launch: int = 1       # rollouts fuse this many env steps per kernel launch
   rollout_streams: int = 1        # rollouts advance this many batch slices on separate HIP streams
+  # c > 0: a fused launch of more than c steps hands its robots from wave to wave every c steps through a work queue
+  # in device memory, so that the launch ends when the work is done and not when the unluckiest SIMD's robots are
+  # (scheduling only, results bit-identical).  0 = off: one wave steps one robot through the launch
+  migrate_steps: int = 0
   # ground: None = pybullet_data's flat plane.urdf (solo8_base_env.py:47); or a heightfield
   # dict(heights=[ny, nx] array, cell=metres, origin=(x, y) of grid point (0, 0) or None = centred)
   terrain = None
@@ -141,4 +145,7 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
   c.auto_reset = 1 if config.auto_reset else 0
   c.steps_per_launch = max(1, int(getattr(config, 'steps_per_launch', 1)))
   c.rollout_streams = max(1, int(getattr(config, 'rollout_streams', 1)))
+  c.migrate_steps = int(getattr(config, 'migrate_steps', 0))
+  if c.migrate_steps < 0:
+    raise ValueError('migrate_steps must be >= 0')
   return c

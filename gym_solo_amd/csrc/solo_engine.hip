@@ -65,6 +65,7 @@ struct Engine final : EngineBase {
   bool use_order = false;
   double* stats = nullptr;
   T* terrain = nullptr;
+  int32_t* queue = nullptr;   // robot-migration queues of the launches in flight (one region per rollout slice), or null
 #ifdef SOLO_STAMPS
   unsigned long long* stamps = nullptr;
 #endif
@@ -78,7 +79,7 @@ struct Engine final : EngineBase {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : {(void*)dparams, (void*)state, (void*)snapshot, (void*)targets, (void*)params,
                     (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
-                    (void*)term_count, (void*)order, (void*)cost, (void*)stats, (void*)terrain, (void*)traj})
+                    (void*)term_count, (void*)order, (void*)cost, (void*)stats, (void*)terrain, (void*)traj, (void*)queue})
       if (p) (void)hipFree(p);
   }
 
@@ -103,6 +104,8 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMalloc((void**)&cost, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMemset(cost, 0, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&traj, (size_t)spl() * ns * sizeof(T)));
+    if (migrate_chunk() > 0)
+      HIP_TRY(hipMalloc((void**)&queue, ((size_t)kMaxStreams * solo::kQueueHeader + (size_t)n * (1 + solo::migration_chunks(spl(), migrate_chunk()))) * sizeof(int32_t)));
     HIP_TRY(hipMemset(obs, 0, (size_t)n * SOLO_MAX_OBS * sizeof(T)));
     HIP_TRY(hipMemset(reward, 0, (size_t)n * sizeof(T)));
     HIP_TRY(hipMemset(done, 0, (size_t)n));
@@ -134,6 +137,7 @@ struct Engine final : EngineBase {
     b.obs_rec = b.reward_rec = b.view_obs = b.view_reward = nullptr; b.view_done = nullptr; b.obs_rec_stride = b.reward_rec_stride = 0; b.obs_from = 0;
     b.stats = stats; b.terrain = terrain; b.order = use_order ? order : nullptr; b.cost = cost; b.num_envs = n; b.flags = flags; b.env_base = 0; b.count = n; b.steps = 1;
     b.action_stride = b.done_stride = 0;
+    b.queue = nullptr; b.q_rings = 1; b.q_chunk = 0;
 #ifdef SOLO_STAMPS
     b.stamps = stamps;
 #endif
@@ -222,13 +226,23 @@ struct Engine final : EngineBase {
     return (int)(want < cap ? want : (cap > 1 ? cap : 1));
   }
 
+  // robot migration (SoloConfig::migrate_steps): steps per chunk, 0 = off (never in the diagnostic stamps builds,
+  // whose per-wave stamps assume one robot per wave)
+  int migrate_chunk() const {
+#ifdef SOLO_STAMPS
+    return 0;
+#else
+    return cfg.migrate_steps > 0 ? cfg.migrate_steps : 0;
+#endif
+  }
+
   // one chain of launches covering steps [0, k) for robots [lo, lo+count): per launch the step
   // kernel (one wave per robot, S fused steps; its output epilogue evaluates the S step records the robot left)
   // final_chunk: this chain ends the caller's rollout - a RECORDING rollout then has its last launch's epilogue
   // also leave the last step's observation / reward / done in the engine's view (what three
   // device-to-device copies after the chain used to do: ~15 us of a 0.4 ms 20-step rollout)
   int launch_chain(const T* act, long long act_stride, int k, uint32_t flags, T* obs_out, T* reward_out,
-                   uint8_t* done_out, hipStream_t s, int lo, int count, bool final_chunk = true) {
+                   uint8_t* done_out, hipStream_t s, int lo, int count, bool final_chunk = true, int slice = 0) {
     const int S = spl();
     const bool want_obs = (flags & SOLO_STEP_OBS) != 0, want_reward = (flags & SOLO_STEP_REWARD) != 0;
     for (int i = 0; i < k; i += S) {
@@ -261,11 +275,27 @@ struct Engine final : EngineBase {
         }
         if (done_out && (flags & SOLO_STEP_DONE) && tail_to_view) b.view_done = done;
       }
+      // robot migration: a launch of more than one chunk of steps gets a work queue (its own region per rollout slice:
+      // the slices' launches run side by side), initialised on the stream in front of the step kernel; eight rings -
+      // one per XCD - when the robots divide evenly, else one
+      if (migrate_chunk() > 0 && steps > migrate_chunk() && (flags & SOLO_STEP_PHYSICS)) {
+        const int chunk = solo::migration_chunk_steps(steps, migrate_chunk());
+        b.q_chunk = chunk;
+        b.q_rings = solo::migration_rings(count);
+        b.queue = queue + (size_t)slice * solo::kQueueHeader + (size_t)lo * (1 + solo::migration_chunks(spl(), migrate_chunk()));
+        const size_t ints = solo::migration_queue_ints(count, steps, chunk);
+        hipLaunchKernelGGL(solo::solo_queue_init_kernel, dim3((unsigned)((ints + 255) / 256)), dim3(256), 0, s, b.queue, ints, lo, count,
+                           b.q_rings, steps, chunk, (const int32_t*)(use_order ? order : nullptr));
+        HIP_TRY(hipGetLastError());
+      }
       // stepSimulation-only calls (settle loop, client.stepSimulation()) run the physics-only
       // instantiation: no termination code, and a separate name in profiles
       // (pybullet's residual threshold, an opt-in, is a kernel instantiation of its own: the default kernels carry none of it)
       const bool resid = cfg.solver_residual_threshold > 0;
-      if (flags == SOLO_STEP_PHYSICS) {
+      if (b.queue != nullptr) {  // (robot migration is a kernel instantiation of its own too - always the full kernel: kFull only selects code)
+        if (resid) hipLaunchKernelGGL((solo::solo_step_kernel<T, true, true, true>), dim3(count), dim3(64), 0, s, dparams, b);
+        else hipLaunchKernelGGL((solo::solo_step_kernel<T, true, false, true>), dim3(count), dim3(64), 0, s, dparams, b);
+      } else if (flags == SOLO_STEP_PHYSICS) {
         if (resid) hipLaunchKernelGGL((solo::solo_step_kernel<T, false, true>), dim3(count), dim3(64), 0, s, dparams, b);
         else hipLaunchKernelGGL((solo::solo_step_kernel<T, false, false>), dim3(count), dim3(64), 0, s, dparams, b);
       } else {
@@ -333,7 +363,7 @@ struct Engine final : EngineBase {
         const int kk = (k - i < S) ? (k - i) : S;
         if (int rc = launch_chain(act ? act + (size_t)i * stride : nullptr, stride, kk, flags,
                                   oo ? oo + (size_t)i * n * obs_dim : nullptr, ro ? ro + (size_t)i * n : nullptr,
-                                  dn ? dn + (size_t)i * n : nullptr, sub[g], lo, hi - lo, i + S >= k))
+                                  dn ? dn + (size_t)i * n : nullptr, sub[g], lo, hi - lo, i + S >= k, g))
           return rc;
       }
     for (int g = 0; g < groups; ++g) {
@@ -473,6 +503,7 @@ int check_config(const SoloConfig* c, std::string* err) {
   if (!(c->solver_residual_threshold >= 0)) return fail("solver_residual_threshold must be >= 0");
   if (c->settle_steps < 0 || c->settle_steps > 100000) return fail("settle_steps out of range");
   if (c->steps_per_launch < 0 || c->steps_per_launch > 100000) return fail("steps_per_launch out of range");
+  if (c->migrate_steps < 0 || c->migrate_steps > 100000 || c->reserved0 != 0) return fail("migrate_steps out of range");
   if (c->restitution != 0.0) return fail("only restitution 0 is supported (gym_solo configs.py:23)");
   if (!(c->action_scale > 0)) return fail("action_scale must be positive");
   if (c->lateral_friction < 0 || c->contact_margin < 0 || c->contact_erp < 0) return fail("negative contact parameter");

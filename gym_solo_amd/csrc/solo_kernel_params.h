@@ -106,6 +106,50 @@ __host__ __device__ constexpr int xcd_contiguous(int b, int count) {
   return ((b & 7) < (count & 7) ? (b & 7) * ((count >> 3) + 1) : (count & 7) * ((count >> 3) + 1) + ((b & 7) - (count & 7)) * (count >> 3)) + (b >> 3);
 }
 
+// ---- robot migration inside a fused launch (SoloConfig::migrate_steps) -----------------------------------------
+// A launch of S steps is cut into chunks of c steps; a CHUNK is the unit a wave executes, and between chunks a robot
+// is nothing but its 32-real record, its termination counters and two integers in device memory - any wave can
+// continue it.  The queue of a launch (one int32 array in device memory, initialised by migration_queue_init before
+// the step kernel starts):
+//   [r * 32]        head of ring r: the next TICKET (an index into the ring; waves take tickets with one atomic add)
+//   [r * 32 + 16]   tail of ring r: the next free ring slot
+//   [H + e]         robot e (relative to the launch's first): Gauss-Seidel sweeps so far in this launch (H = kQueueHeader)
+//   [H + n ..]      the rings, `q_rings` of them with per_ring = n / q_rings robots x chunks entries each: ring slot ->
+//                   robot e ready for its chunk c, as e | c << 24, or -1 = not published yet.  The first per_ring slots
+//                   are the ring's robots (chunk 0); every finished chunk but a robot's last publishes ONE further slot,
+//                   and every chunk consumes ONE ticket: tickets and slots are both exactly per_ring x chunks, a ring is
+//                   a FIFO (robots advance round-robin, so all of them approach the end of the launch together), and the
+//                   lowest ticket in flight always finds its slot published (no wave waits for a wave that waits).
+// Eight rings, one per XCD (the waves of XCD x serve ring x first: a robot's records and its neighbours' rows of the
+// [step][robot][.] arrays stay in one L2), each owning a contiguous eighth of the launch's robots; one ring when the
+// robots do not divide evenly.  A wave whose ring has no tickets left goes on to the next ring (so every ring is drained
+// whatever the placement of the waves, and the XCDs level out at the end).  (64 rings of 64 robots, measured: slower -
+// the pools get too small to balance; the counters' serialisation - read-modify-writes of one address, ~12 ns each -
+// is not what a hand-over costs: its chain of device-scope round trips is.)
+constexpr int kQueueMaxRings = 8;
+constexpr int kQueueHeader = 32 * kQueueMaxRings;
+__host__ __device__ constexpr int migration_rings(int n) { return (n % 8 == 0 && n >= 8 * 8) ? 8 : 1; }
+__host__ __device__ constexpr int migration_chunks(int steps, int chunk) { return (steps + chunk - 1) / chunk; }
+__host__ __device__ constexpr size_t migration_queue_ints(int n, int steps, int chunk) {
+  return (size_t)kQueueHeader + (size_t)n + (size_t)n * (size_t)migration_chunks(steps, chunk);
+}
+// the chunk length a launch really uses: a slot has 7 bits for the chunk index
+__host__ __device__ constexpr int migration_chunk_steps(int steps, int chunk) { return migration_chunks(steps, chunk) <= 127 ? chunk : (steps + 126) / 127; }
+// entry i of the initialisation (i < migration_queue_ints): order = optional dispatch order of the launch's robots
+__host__ __device__ inline void migration_queue_init(int32_t* q, size_t i, int env_base, int n, int rings, int steps, int chunk, const int32_t* order) {
+  const int chunks = migration_chunks(steps, chunk), per = n / rings;
+  if (i < (size_t)kQueueHeader) {
+    const int r = (int)i / 32, w = (int)i % 32;
+    q[i] = (r < rings && w == 16) ? per : 0;   // heads 0, tails behind the ring's own robots
+  } else if (i < (size_t)kQueueHeader + (size_t)n) {
+    q[i] = 0;
+  } else {
+    const size_t j = i - kQueueHeader - (size_t)n;           // ring slot
+    const int r = (int)(j / ((size_t)per * chunks)), k = (int)(j % ((size_t)per * chunks));
+    q[i] = k < per ? (order != nullptr ? order[env_base + r * per + k] - env_base : r * per + k) : -1;
+  }
+}
+
 template <typename T>
 struct KBuffers {
   T* state;           // [N][32]
@@ -138,6 +182,10 @@ struct KBuffers {
   int32_t steps;       // env steps per launch (>= 1)
   // element strides between consecutive steps of a multi-step launch (0: reuse the buffer)
   long long action_stride, done_stride;
+  // robot migration (SoloConfig::migrate_steps): the launch's work queue (MigrationQueue below), or null = one wave
+  // steps one robot through the whole launch; number of rings (8: one per XCD, or 1); steps per chunk
+  int32_t* queue;
+  int32_t q_rings, q_chunk;
 #ifdef SOLO_STAMPS
   int32_t stamp_row;           // (set by the kernel: the robot this wave steps)
   unsigned long long* stamps;  // [N][32] s_memtime stamps, DIAGNOSTIC builds only (make stamps):

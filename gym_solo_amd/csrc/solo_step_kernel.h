@@ -888,7 +888,7 @@ template <typename T, bool kFull> constexpr bool kInlineOutputs = kFull && sizeo
 #endif
 template <typename T> constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : SOLO_F64_WAVES;
 
-template <typename T, bool kFull, bool kResid = false>
+template <typename T, bool kFull, bool kResid = false, bool kMigrate = false>
 __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const KParams<T>* __restrict__ Pin, KBuffers<T> Bin) {
   KBuffers<T> B = Bin;
   if (!kFull) B.flags = SOLO_STEP_PHYSICS;
@@ -930,12 +930,24 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   // robot), else the XCD-contiguous map (xcd_contiguous, solo_kernel_params.h: the robots whose waves share an L2 are
   // neighbours in the batch, so their rows of the [step][robot][.] arrays complete each other's cache lines there)
   const int32_t* order = wave_cold_args(Bin)->order;
-  const int env = order != nullptr ? wave_uniform(order[slot]) : B.env_base + xcd_contiguous(block_id(), B.count);
+  // A TASK = one robot and a range of the launch's steps.  kMigrate = false: this workgroup's robot, all steps.
+  // kMigrate (SoloConfig::migrate_steps; the queue: solo_kernel_params.h): chunks of q_chunk steps of whichever robot
+  // is ready next, taken from the ring of this wave's XCD first - the wave loops over tasks until the rings hold no
+  // ticket, and a robot moves from wave to wave as its record in device memory.  A kernel instantiation of its own:
+  // the one-robot-per-wave kernels keep their straight-line code.
+  int32_t* const queue = kMigrate ? wave_cold_args(Bin)->queue : nullptr;
+  int env = 0, step_begin = 0, step_end = B.steps;
+  bool last_chunk = true;   // this task ends the robot's launch: output epilogue, final bookkeeping
+  int q_ring = 0, q_rings_left = 0, q_sweeps = 0, q_chunk_at = 0;
+  if constexpr (!kMigrate) env = order != nullptr ? wave_uniform(order[slot]) : B.env_base + xcd_contiguous(block_id(), B.count);
+  else {
+    // home ring: one of the rings of this wave's XCD (q_rings = 8 x rings per XCD, or 1)
+    const int per_xcd = B.q_rings >= 8 ? B.q_rings >> 3 : 1;
+    q_ring = B.q_rings >= 8 ? (wave_xcc_id() & 7) * per_xcd + (block_id() >> 3) % per_xcd : 0;
+    q_rings_left = B.q_rings;
+  }
 #ifdef SOLO_STAMPS
   B.stamp_row = env;
-#endif
-  const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
-#ifdef SOLO_STAMPS
   __shared__ unsigned long long s_acc[17];
   if (lane0 < 17) s_acc[lane0] = lane0 == 16 ? __builtin_amdgcn_s_memtime() : 0ull;
   B.acc = s_acc;
@@ -948,40 +960,25 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
 #define SOLO_STATS_ROW (wave_cold_args(Bin)->stats + (size_t)(env % SOLO_STATS_SHARDS) * SOLO_STATS_WIDTH)
 
   const KParams<T>* __restrict__ const P0 = Pin;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s_hext[lane0][i] = T(0);
-  // ---- the prologue's global loads, ALL ISSUED BEFORE THE FIRST ONE IS WAITED FOR (written as copy loops
-  //      and load-then-store pairs they were eight exposed round trips to memory, one after the other:
-  //      nothing in a fused launch, 17 % of a closed-loop step, which is a launch of its own)
+  // ---- the per-launch tables (per-leg / per-row / per-step constants, the polynomial coefficients): loaded ...
   constexpr int kLegWords = (int)(sizeof(LegConst<T>) * 4 / sizeof(T)), kLegLoads = (kLegWords + 63) / 64;
   constexpr int kConstWords = (int)(sizeof(StepConst<T>) / sizeof(int32_t)), kConstLoads = (kConstWords + 63) / 64;
-  const T* leg_src = reinterpret_cast<const T*>(P0->leg);
-  const int32_t* const_src = reinterpret_cast<const int32_t*>(&P0->c);
   T leg_w[kLegLoads];
   int32_t const_w[kConstLoads];
-#pragma unroll
-  for (int j = 0; j < kLegLoads; ++j) leg_w[j] = (lane0 + 64 * j < kLegWords) ? leg_src[lane0 + 64 * j] : T(0);
-  const RowConst<T> row_w = P0->row[lane0];
-#pragma unroll
-  for (int j = 0; j < kConstLoads; ++j) const_w[j] = (lane0 + 64 * j < kConstWords) ? const_src[lane0 + 64 * j] : 0;
-  const T state_w = lane0 < SOLO_STATE_STRIDE ? wave_cold_args(Bin)->state[rec + lane0] : T(0);
-  const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
-  const T mass_scale = wave_cold_args(Bin)->params[(size_t)env * 4 + 1];
-  const int count_w = lane0 < SOLO_MAX_TERMS ? wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane0] : 0;
+  RowConst<T> row_w;
   T math_w = T(0);
-  if constexpr (Real<T>::kTabSize > 0) math_w = wave_math_table<T>(lane0 < Real<T>::kTabSize ? lane0 : 0);
-  // issue priority (see physics_solve): a closed-loop step() is a launch of ONE step - it has no history
-  // of its own, and its slowest robot, one that runs all the sweeps, decides how long the step takes.  A
-  // robot's Gauss-Seidel cost is persistent, so such a launch starts from the sweep count of the robot's
-  // previous step (fused launches build their own history: seeded the same way they were 4 % slower)
-  int hist_w = 0, prio_steps = 0;
-  if (B.steps == 1) {
-    const int32_t* cost = wave_cold_args(Bin)->cost;
-    if ((B.flags & SOLO_STEP_PHYSICS) && cost != nullptr) { hist_w = cost[env]; prio_steps = 1; }
-  }
-  // ---- ... and into LDS: the per-leg / per-row / per-step tables, the state record, the TimeBased counters
-  //      (kept in scalar registers next to the termination program they cost 25 SGPR spills in the step loop)
-  {
+  auto load_tables = [&]() {
+    const T* leg_src = reinterpret_cast<const T*>(P0->leg);
+    const int32_t* const_src = reinterpret_cast<const int32_t*>(&P0->c);
+#pragma unroll
+    for (int j = 0; j < kLegLoads; ++j) leg_w[j] = (lane0 + 64 * j < kLegWords) ? leg_src[lane0 + 64 * j] : T(0);
+    row_w = P0->row[lane0];
+#pragma unroll
+    for (int j = 0; j < kConstLoads; ++j) const_w[j] = (lane0 + 64 * j < kConstWords) ? const_src[lane0 + 64 * j] : 0;
+    if constexpr (Real<T>::kTabSize > 0) math_w = wave_math_table<T>(lane0 < Real<T>::kTabSize ? lane0 : 0);
+  };
+  // ... and staged into LDS
+  auto store_tables = [&]() {
     T* leg_dst = reinterpret_cast<T*>(s_legc);
     int32_t* const_dst = reinterpret_cast<int32_t*>(&s_const);
 #pragma unroll
@@ -992,25 +989,118 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     s_rowgeo[lane0][3] = row_w.radius;
 #pragma unroll
     for (int j = 0; j < kConstLoads; ++j) if (lane0 + 64 * j < kConstWords) const_dst[lane0 + 64 * j] = const_w[j];
-    if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = state_w;
-    s_cnt[lane0] = count_w;
-    // f64: the robot's friction coefficient and base-mass scale wait in LDS, not in two register pairs held across the
-    // whole step loop (the f64 kernel lives on 168 VGPRs: see physics_solve, "PARK EARLY")
-    if constexpr (sizeof(T) == 8) { if (lane0 == 0) { s_keep[27] = mu; s_keep[28] = mass_scale; } }
     if constexpr (Real<T>::kTabSize > 0) { if (lane0 < Real<T>::kTabSize) s_math[lane0] = math_w; }
-  }
-  int prio_sweeps = wave_uniform(hist_w);
-  const int hist_sweeps = prio_sweeps;
-  int prio_rot = (prio_steps + wave_slot_id()) % 3;  // the rotation's phase (advanced once per step)
-  if (prio_steps > 0) wave_set_priority_level(prio_sweeps > 8 ? 3 : wave_slot_id() % 3);  // (thresholds 4 / 8 / 20 / 40 measured: 1.063 / 1.060 / 1.027 / 1.021e8 env-steps/s)
-  wave_sync();
-  {  // the termination tables, from the staged constants
+  };
+  // the termination tables, from the staged constants
+  auto make_term_tables = [&]() {
     const int tl = lane0 & (SOLO_MAX_TERMS - 1);
     const int kind = s_const.term_kind[tl], param = s_const.term_param[tl];
     const bool mine = lane0 < s_const.num_terms;  // (num_terms <= SOLO_MAX_TERMS)
     s_termlim[lane0] = (mine && kind == SOLO_T_TIME) ? param : ((mine && kind == SOLO_T_CONST && param != 0) ? -1 : 0x7fffffff);
     s_termtick[lane0] = (mine && kind == SOLO_T_TIME) ? 1 : 0;
+  };
+  if constexpr (kMigrate) {  // once per wave, in front of the task loop
+    load_tables();
+    store_tables();
+    wave_sync();
+    make_term_tables();
   }
+  do {  // ---- the task loop (kMigrate; else one pass)
+  if constexpr (kMigrate) {
+    // a ticket of the current ring; a ring without tickets sends the wave on to the next one, and a whole round of
+    // empty rings ends it
+    const int chunks = migration_chunks(B.steps, B.q_chunk), per_ring = B.count / B.q_rings, ring_len = per_ring * chunks;
+    int32_t* const ring_slots = queue + kQueueHeader + (size_t)B.count;
+    // (a ticket is taken when the wave is FREE, never ahead: a ticket reserved while the wave still works is matched
+    // with a robot in reservation order, not in the order waves become free, and waves then wait for "their" robot while
+    // others are ready - measured: slower at every chunk length)
+    int ticket = ring_len;
+    bool tried = false;
+    for (;;) {
+      if (ticket < ring_len) break;
+      if (tried) { if (--q_rings_left <= 0) break; q_ring = q_ring + 1 == B.q_rings ? 0 : q_ring + 1; }
+      // (the ring the wave is on: one read-modify-write - one device-scope round trip; a ring it walks on to at the
+      // end of a launch is first looked at with a load: read-modify-writes of one address serialise at ~12 ns each,
+      // and every wave ends by walking over every ring)
+      if (lane0 == 0) {
+        ticket = tried ? wave_atomic_load(queue + q_ring * 32) : 0;
+        if (ticket < ring_len) ticket = wave_atomic_add(queue + q_ring * 32, 1);
+      }
+      ticket = wave_readlane_int(ticket, 0);
+      tried = true;
+    }
+    if (ticket >= ring_len) break;
+    // the slot of that ticket: published already unless more waves ask than robots are ready (the end of a launch).
+    // BOUNDED wait: a wave that gives up counts itself in slot 6 of the statistics and leaves (never observed; a
+    // launch must not hang on a bug)
+    int ready = -1;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      if (lane0 == 0) ready = wave_atomic_load(ring_slots + (size_t)q_ring * ring_len + ticket);
+      ready = wave_readlane_int(ready, 0);
+      if (ready >= 0) break;
+      wave_backoff();
+    }
+    if (ready < 0) { if (lane0 == 0) stats_add(&wave_cold_args(Bin)->stats[6], 1.0); break; }
+    wave_acquire_device();  // (orders the loads of the robot's record and counters behind the poll)
+    // the slot says which robot and which of its chunks: everything else is loaded in ONE round trip below
+    env = B.env_base + (ready & 0xffffff);
+    q_chunk_at = ready >> 24;
+    step_begin = q_chunk_at * B.q_chunk;
+    step_end = step_begin + B.q_chunk < B.steps ? step_begin + B.q_chunk : B.steps;
+    last_chunk = step_end == B.steps;
+  }
+  const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
+  // (lane = row keeps the joint-space parts of dead legs' slots at zero - they are written once: here, and again after
+  // an output epilogue has used the block as scratch; slot space rewrites all eight every step)
+  if constexpr (!kMigrate || !ColumnBank<T>::kCompact) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_hext[lane0][i] = T(0);
+  }
+  // ---- the prologue's global loads, ALL ISSUED BEFORE THE FIRST ONE IS WAITED FOR (written as copy loops
+  //      and load-then-store pairs they were eight exposed round trips to memory, one after the other:
+  //      nothing in a fused launch, 17 % of a closed-loop step, which is a launch of its own)
+  if constexpr (!kMigrate) load_tables();
+  T state_w = T(0);
+  int count_w = 0;
+  if constexpr (kMigrate) {  // (what a robot travels as is read and written with device-coherent accesses: solo_wave_ops.h)
+    if (lane0 < SOLO_STATE_STRIDE) state_w = wave_load_shared(wave_cold_args(Bin)->state + rec + lane0);
+    if (lane0 < SOLO_MAX_TERMS) count_w = wave_atomic_load(wave_cold_args(Bin)->term_count + (size_t)env * SOLO_MAX_TERMS + lane0);
+  } else {
+    if (lane0 < SOLO_STATE_STRIDE) state_w = wave_cold_args(Bin)->state[rec + lane0];
+    if (lane0 < SOLO_MAX_TERMS) count_w = wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane0];
+  }
+  const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
+  const T mass_scale = wave_cold_args(Bin)->params[(size_t)env * 4 + 1];
+  // issue priority (see physics_solve): a closed-loop step() is a launch of ONE step - it has no history
+  // of its own, and its slowest robot, one that runs all the sweeps, decides how long the step takes.  A
+  // robot's Gauss-Seidel cost is persistent, so such a launch starts from the sweep count of the robot's
+  // previous step (fused launches build their own history: seeded the same way they were 4 % slower)
+  int hist_w = 0, prio_steps = 0;
+  if (B.steps == 1) {
+    const int32_t* cost = wave_cold_args(Bin)->cost;
+    if ((B.flags & SOLO_STEP_PHYSICS) && cost != nullptr) { hist_w = cost[env]; prio_steps = 1; }
+  }
+  if constexpr (kMigrate) {  // (a migrating robot brings its history along: its sweeps so far in this launch)
+    if (lane0 == 0) hist_w = wave_atomic_load(queue + kQueueHeader + (env - B.env_base));
+    hist_w = wave_readlane_int(hist_w, 0);
+    prio_steps = step_begin;
+  }
+  // ---- ... and into LDS: the per-leg / per-row / per-step tables, the state record, the TimeBased counters
+  //      (kept in scalar registers next to the termination program they cost 25 SGPR spills in the step loop)
+  {
+    if constexpr (!kMigrate) store_tables();
+    if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = state_w;
+    s_cnt[lane0] = count_w;
+    // f64: the robot's friction coefficient and base-mass scale wait in LDS, not in two register pairs held across the
+    // whole step loop (the f64 kernel lives on 168 VGPRs: see physics_solve, "PARK EARLY")
+    if constexpr (sizeof(T) == 8) { if (lane0 == 0) { s_keep[27] = mu; s_keep[28] = mass_scale; } }
+  }
+  int prio_sweeps = wave_uniform(hist_w);
+  const int hist_sweeps = kMigrate ? 0 : prio_sweeps;
+  int prio_rot = (prio_steps + wave_slot_id()) % 3;  // the rotation's phase (advanced once per step)
+  if (prio_steps > 0) wave_set_priority_level(prio_sweeps > 8 ? 3 : wave_slot_id() % 3);  // (thresholds 4 / 8 / 20 / 40 measured: 1.063 / 1.060 / 1.027 / 1.021e8 env-steps/s)
+  wave_sync();
+  if constexpr (!kMigrate) make_term_tables();
   // The auto-reset belongs to a step that advanced the simulation (or asks for it explicitly): a
   // query-only launch - TerminationFactory.is_terminated() outside step(), termination.py:38-50 - never
   // mutates the physics state.
@@ -1023,7 +1113,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   // the steps, which averages out the contact-count imbalance between robots.
   wave_sync();  // the staged tables, the state record and the counters are in LDS
 #pragma unroll 1
-  for (int step = 0; step < B.steps; ++step) {
+  for (int step = step_begin; step < step_end; ++step) {
     const StepConst<T>& C = s_const;  // (LDS: re-read every step, nothing carried across the step loop in registers)
     const int lane = wave_opaque_lane(lane0);  // per-lane address arithmetic stays in the step instead of being
     // hoisted out of the fused step loop and kept live across it (spills)
@@ -1038,12 +1128,20 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     const bool motor_lane = rc.type == ROW_MOTOR;
     const size_t tgt_at = (size_t)env * SOLO_NUM_JOINTS + (size_t)(3 * (lane >> 4) + (lane & 15));  // pybullet joint index
     T raw_target = T(0);
-    if (motor_lane) raw_target = B.actions != nullptr ? B.actions[(size_t)step * B.action_stride + tgt_at] : wave_cold_args(Bin)->targets[tgt_at];
+    // (the robot's motor targets are written from several chunks - the last step's action, an auto-reset's settle pose -
+    // and read back when a launch brings no actions: device-coherent accesses in a migrating launch, like its record)
+    if (motor_lane) {
+      if (B.actions != nullptr) raw_target = B.actions[(size_t)step * B.action_stride + tgt_at];
+      else if constexpr (kMigrate) raw_target = wave_load_shared(wave_cold_args(Bin)->targets + tgt_at);
+      else raw_target = wave_cold_args(Bin)->targets[tgt_at];
+    }
     // action de-normalisation (solo8v2vanilla.py:84-85), applied where the target is used
     const T target_scale = B.actions != nullptr ? C.action_scale : T(1);
-    if (B.actions != nullptr && step == B.steps - 1 && lane < SOLO_NUM_JOINTS)  // the view's targets: all 12 entries
-      wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] =
-          B.actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * C.action_scale;
+    if (B.actions != nullptr && step == B.steps - 1 && lane < SOLO_NUM_JOINTS) {  // the view's targets: all 12 entries
+      const T tv = B.actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * C.action_scale;
+      if constexpr (kMigrate) wave_store_shared(wave_cold_args(Bin)->targets + (size_t)env * SOLO_NUM_JOINTS + lane, tv);
+      else wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = tv;
+    }
 
     SOLO_STAMP(B, 1);
     bool diverged = false;
@@ -1139,7 +1237,10 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
         if (lane < SOLO_S_RETURN) s_state[lane] = wave_cold_args(Bin)->snapshot[rec + lane];
         s_cnt[lane] = 0;
         // reset() leaves the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
-        if (lane < SOLO_NUM_JOINTS) wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = C.settle_tgt[lane];
+        if (lane < SOLO_NUM_JOINTS) {
+          if constexpr (kMigrate) wave_store_shared(wave_cold_args(Bin)->targets + (size_t)env * SOLO_NUM_JOINTS + lane, C.settle_tgt[lane]);
+          else wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = C.settle_tgt[lane];
+        }
       }
       // (a launch that leaves records has its done flags written by the output epilogue, from slot 31)
       if (B.traj == nullptr && lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
@@ -1159,13 +1260,17 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   //      wrote them: L2-resident, its own robot's are contiguous); the reward program's values live in the row-vector
   //      block of LDS, which is dead by now; lane 0 then folds the pass's rewards into the episodic accumulators in
   //      step order (accumulate_returns: the additions stay sequential).
+  //      With robot migration every chunk's wave does this for the steps of ITS chunk (it reads only records it wrote
+  //      itself; the episodic accumulators travel in the robot's record) and goes on to its next task afterwards - so
+  //      the scratch stays clear of the per-launch tables (28 steps per pass in f64).
   if constexpr (kFull) if (B.traj != nullptr) {
     wave_fence_global();  // this wave's record stores before its loads of them
     const auto A = wave_cold_args(Bin);
     const int n_obs = wave_uniform(s_const.num_obs), n_rops = wave_uniform(s_const.num_reward_ops);
-    constexpr int kPass = 32;
-    T* const val = s_blk;                                            // [n_rops][kPass]
-    uint8_t* const ev_bytes = reinterpret_cast<uint8_t*>(s_termlim);  // (the termination tables are dead)
+    constexpr int kPass = kRowsReals / SOLO_MAX_REWARD_OPS < 32 ? kRowsReals / SOLO_MAX_REWARD_OPS : 32;
+    static_assert(kPass >= 16 && sizeof(T) * 32 >= (size_t)kPass, "the output epilogue's scratch");
+    T* const val = s_blk;                                            // [n_rops][kPass]: the row vectors' block (dead here)
+    uint8_t* const ev_bytes = reinterpret_cast<uint8_t*>(s_keep);    // (the parked factors are dead too)
     const T* const my_traj = B.traj + (size_t)env * (size_t)B.steps * SOLO_STATE_STRIDE;
     const bool want_reward = (B.flags & SOLO_STEP_REWARD) != 0;
     const bool bookkeeping = want_reward && (B.flags & SOLO_STEP_DONE) != 0;
@@ -1173,9 +1278,9 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     T* const view_obs = A->view_obs; T* const view_reward = A->view_reward; uint8_t* const view_done = A->view_done;
     const long long obs_stride = A->obs_rec_stride, reward_stride = A->reward_rec_stride;
     const int obs_from = A->obs_from;
-    for (int base = 0; base < B.steps; base += kPass) {
+    for (int base = step_begin; base < step_end; base += kPass) {
       const int k = base + lane1;
-      if (lane1 < kPass && k < B.steps) {
+      if (lane1 < kPass && k < step_end) {
         const T* rec = my_traj + (size_t)k * SOLO_STATE_STRIDE;
         const bool last = k == B.steps - 1;
         const int ev = (int)rec[SOLO_S_SPARE];
@@ -1204,24 +1309,50 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       }
       wave_sync();
       if (bookkeeping && lane1 == 0) {
-        const int cnt = B.steps - base < kPass ? B.steps - base : kPass;
+        const int cnt = step_end - base < kPass ? step_end - base : kPass;
         accumulate_returns<T>(s_state, ev_bytes, 1, val + (size_t)(n_rops - 1) * kPass, 1, cnt, SOLO_STATS_ROW,
                               [](double* p, double x) { stats_add(p, x); });
       }
       wave_sync();
     }
   }
-  if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
-  if ((B.flags & SOLO_STEP_PHYSICS) && lane1 == 0) { int32_t* cost = wave_cold_args(Bin)->cost; if (cost != nullptr) cost[env] = prio_sweeps - hist_sweeps; }
+  if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) {
+    if constexpr (kMigrate) wave_atomic_store(wave_cold_args(Bin)->term_count + (size_t)env * SOLO_MAX_TERMS + lane1, s_cnt[lane1]);
+    else wave_cold_args(Bin)->term_count[(size_t)env * SOLO_MAX_TERMS + lane1] = s_cnt[lane1];
+  }
+  if ((B.flags & SOLO_STEP_PHYSICS) && lane1 == 0 && last_chunk) { int32_t* cost = wave_cold_args(Bin)->cost; if (cost != nullptr) cost[env] = prio_sweeps - hist_sweeps; }
   // (slots SOLO_S_RETURN.. of the record: the episodic accumulators, kept by whichever path evaluated the rewards)
   const bool own_returns = (B.flags & SOLO_STEP_REWARD) && (B.flags & SOLO_STEP_DONE) &&
                            (B.traj != nullptr || (kInlineOutputs<T, kFull> && B.reward_inline != nullptr));
-  if (lane1 < (own_returns ? SOLO_S_SPARE : SOLO_S_RETURN)) wave_cold_args(Bin)->state[rec + lane1] = s_state[lane1];
+  if (lane1 < (own_returns ? SOLO_S_SPARE : SOLO_S_RETURN)) {
+    if constexpr (kMigrate) wave_store_shared(wave_cold_args(Bin)->state + rec + lane1, s_state[lane1]);
+    else wave_cold_args(Bin)->state[rec + lane1] = s_state[lane1];
+  }
   SOLO_STAMP(B, 14);
 #ifdef SOLO_STAMPS
   wave_sync();
   if (lane1 < 16) B.stamps[(size_t)env * 32 + 16 + lane1] = s_acc[lane1];
 #endif
+  if constexpr (kMigrate) if (!last_chunk) {
+    // hand the robot on: its progress, then - when the device-coherent stores of its record and counters above have
+    // completed - its number into the next free slot of its ring (whoever holds that slot's ticket continues it)
+    const int chunks = migration_chunks(B.steps, B.q_chunk), ring_len = (B.count / B.q_rings) * chunks;
+    if (lane1 == 0) wave_atomic_store(queue + kQueueHeader + (env - B.env_base), prio_sweeps);
+    wave_release_device();
+    if (lane1 == 0) {
+      const int at = wave_atomic_add(queue + q_ring * 32 + 16, 1);
+      wave_atomic_store(queue + kQueueHeader + (size_t)B.count + (size_t)q_ring * ring_len + at, (env - B.env_base) | ((q_chunk_at + 1) << 24));
+    }
+  }
+  if constexpr (kMigrate) wave_sync();  // (the next task's prologue rewrites the LDS record)
+  } while (kMigrate);  // the task loop
+}
+
+// the work queue of a launch with robot migration (solo_kernel_params.h): one thread per entry
+__global__ void solo_queue_init_kernel(int32_t* __restrict__ q, size_t ints, int env_base, int n, int rings, int steps, int chunk,
+                                       const int32_t* __restrict__ order) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ints) migration_queue_init(q, i, env_base, n, rings, steps, chunk, order);
 }
 
 // setJointMotorControlArray without a step (solo8v2vanilla.py:87-90)

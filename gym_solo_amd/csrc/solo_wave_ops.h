@@ -298,6 +298,27 @@ template <typename B> __device__ __forceinline__ ColdArgs<B> wave_cold_args(cons
   return p;
 }
 
+// ---- device-scope primitives of the robot-migration queue (solo_kernel_params.h: MigrationQueue) -----------------
+// relaxed atomics at agent scope (they go to the L2 / memory side: visible to every CU of every XCD) ...
+__device__ __forceinline__ int wave_atomic_add(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int wave_atomic_load(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wave_atomic_store(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... for the counters AND for the data a robot travels as (its record, its termination counters): every access to
+// them in a migrating launch is a relaxed agent-scope atomic (sc1: served at the coherence point, whichever XCD asks -
+// the L2s of the eight XCDs are not coherent with each other for plain accesses).  The publication is then ordered by
+// waits alone: the data stores, s_waitcnt vmcnt(0) (a workgroup-scope release: no cache operation), the ring slot; and
+// on the other side the poll, then the data loads.  (An agent-scope release / acquire PAIR of fences instead writes
+// back and invalidates a whole L2 per hand-over: measured, 4096 hand-overs cost 90 us - a fifth of a 20-step launch.)
+__device__ __forceinline__ float wave_load_shared(const float* p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ double wave_load_shared(const double* p) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void wave_store_shared(float* p, float v) { __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wave_store_shared(double* p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wave_release_device() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void wave_acquire_device() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+__device__ __forceinline__ void wave_backoff() { __builtin_amdgcn_s_sleep(8); }
+// the XCD this wave runs on (hardware register XCC_ID)
+__device__ __forceinline__ int wave_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf); }
+
 // slot of this wave among the waves resident on its SIMD (HW_ID[3:0])
 __device__ __forceinline__ int wave_slot_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 0xf); }
 // issue priority of this wave in its SIMD

@@ -36,8 +36,9 @@
 extern "C" {
 #endif
 
-#define SOLO_ABI_VERSION 3  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets
-                               3: SoloConfig::solver_residual_threshold */
+#define SOLO_ABI_VERSION 4  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets
+                               3: SoloConfig::solver_residual_threshold
+                               4: SoloConfig::migrate_steps */
 
 /* ---- fixed Solo8 dimensions -------------------------------------------- */
 #define SOLO_NUM_LEGS 4
@@ -145,6 +146,12 @@ typedef struct SoloConfig {
                                 btMultiBodyConstraintSolver::solveSingleIteration / resolveSingleConstraintRowGeneric
                                 returning deltaImpulse / jacDiagABInv - is <= this value.  0 = never (every sweep that
                                 still changes a row runs, up to solver_iterations).  Negative values are rejected. */
+  int32_t migrate_steps;     /* c > 0: a fused launch of more than c steps hands its robots from wave to wave every c
+                                steps through a work queue in device memory (the robot's 256-B record travels; any idle
+                                wave continues any robot), so that the launch ends when the WORK is done and not when
+                                the unluckiest SIMD's robots are.  Scheduling only: results are bit-identical.  0 = off
+                                (one wave steps one robot through the whole launch). */
+  int32_t reserved0;         /* (padding; must be 0) */
 } SoloConfig;
 
 /* ---- fused observation / reward / termination programs ------------------ */

@@ -98,12 +98,26 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   B.done = done; B.term_count = term_count; B.stats = stats;
   B.num_envs = n; B.flags = flags; B.env_base = 0; B.count = n; B.steps = steps;
   B.action_stride = (long long)n * SOLO_NUM_JOINTS; B.done_stride = n;
+  // robot migration (SoloConfig::migrate_steps), as Engine::launch_chain sets it up: chunks of the launch's steps go
+  // through the queue; the emulated waves run one after the other, so the first drains every ring it can reach
+  std::vector<int32_t> queue;
+  B.queue = nullptr; B.q_rings = 1; B.q_chunk = 0;
+  if (cfg->migrate_steps > 0 && steps > cfg->migrate_steps && (flags & SOLO_STEP_PHYSICS)) {
+    B.q_chunk = migration_chunk_steps(steps, cfg->migrate_steps);
+    B.q_rings = n == 16 ? 8 : migration_rings(n);  // (16 robots: eight rings of two, so that the CPU suite walks several rings too)
+    queue.resize(migration_queue_ints(n, steps, B.q_chunk));
+    for (size_t i = 0; i < queue.size(); ++i) migration_queue_init(queue.data(), i, 0, n, B.q_rings, steps, B.q_chunk, nullptr);
+    B.queue = queue.data();
+  }
   const KParams<T>* Pp = &P;
   // the step kernel, output epilogue included: one emulated wavefront per robot (as Engine::launch_chain launches it)
   for (int b = 0; b < n; ++b)
     WaveEmu::get().run_block(b, n, [&]() {
       // (as Engine::launch_chain: pybullet's residual threshold is a kernel instantiation of its own)
-      if (cfg->solver_residual_threshold > 0) solo_step_kernel<T, true, true>(Pp, B);
+      if (B.queue != nullptr) {
+        if (cfg->solver_residual_threshold > 0) solo_step_kernel<T, true, true, true>(Pp, B);
+        else solo_step_kernel<T, true, false, true>(Pp, B);
+      } else if (cfg->solver_residual_threshold > 0) solo_step_kernel<T, true, true>(Pp, B);
       else solo_step_kernel<T, true, false>(Pp, B);
     });
   for (size_t i = 0; i < st.size(); ++i) state[i] = (double)st[i];

@@ -128,6 +128,16 @@ inline void wave_set_priority_level(int) {}
 template <typename B> using ColdArgs = const B*;
 template <typename B> inline ColdArgs<B> wave_cold_args(const B& by_value) { return &by_value; }
 inline int wave_slot_id() { return 0; }
+// the robot-migration queue's device-scope primitives: plain memory operations (the emulated waves run one after the other)
+inline int wave_atomic_add(int32_t* p, int v) { const int o = *p; *p = o + v; return o; }
+inline int wave_atomic_load(const int32_t* p) { return *p; }
+inline void wave_atomic_store(int32_t* p, int v) { *p = v; }
+template <typename T> inline T wave_load_shared(const T* p) { return *p; }
+template <typename T> inline void wave_store_shared(T* p, T v) { *p = v; }
+inline void wave_release_device() {}
+inline void wave_acquire_device() {}
+inline void wave_backoff() {}
+inline int wave_xcc_id() { return (int)(blockIdx.x & 7); }  // (as the hardware deals workgroups over the XCDs)
 inline void wave_fence_global() {}  // (one emulated wave runs its lanes as fibres over plain memory)
 template <typename T> struct RowDot {
   T g[6], h[2];

@@ -84,6 +84,30 @@ def test_fused_rollout_equals_single_steps():
   assert fd[4].all() and fd.sum() == 2  # TimeBased(4) fires on the 5th step of each robot
 
 
+@pytest.mark.parametrize('dtype,n,k,chunk', [('float32', 2, 9, 2), ('float64', 3, 9, 4), ('float64', 16, 7, 3), ('float32', 8, 40, 32)])
+def test_robot_migration_is_scheduling_only(dtype, n, k, chunk):
+  """SoloConfig.migrate_steps: a fused launch cut into chunks whose robots travel from wave to wave through the
+  launch's work queue (one ring for 2 / 3 robots, eight rings for 8 / 16; ragged last chunks; more steps than one
+  epilogue pass holds) - the same trajectories, outputs, counters, statistics and per-robot sweep counts, bit for bit,
+  including an auto-reset inside the launch."""
+  prog = bench_program()
+  rng = np.random.default_rng(7)
+  acts = rng.uniform(-6, 6, (k, n, 12))
+  out = []
+  for migrate in (0, chunk):
+    ca, ma = make_abi(dtype, auto_reset=True, settle_steps=40, migrate_steps=migrate)
+    e = EmuEngine(ca, ma, n, program=prog)
+    if not out:
+      e.settle()
+      start = (e.state.copy(), e.snapshot.copy())
+    e.state[:], e.snapshot[:] = start
+    o, r, d = e.rollout(acts)
+    out.append((o, r, d, e.state.copy(), e.term_count.copy(), e.stats.copy(), e.cost.copy(), e.targets.copy()))
+  for a, b in zip(*out):
+    np.testing.assert_array_equal(a, b)
+  assert out[1][2][4].all()  # TimeBased(4): every robot ends its first episode on the fifth step
+
+
 def test_ubsan_build_runs_clean():
   """-fsanitize=undefined,bounds-strict build of the kernel source: aborts on the first report."""
   ca, ma = make_abi('float32', settle_steps=30)

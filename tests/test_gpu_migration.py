@@ -1,0 +1,82 @@
+"""Robot migration inside a fused launch (SoloConfig.migrate_steps; include/solo_engine.h, the queue:
+gym_solo_amd/csrc/solo_kernel_params.h) ON THE GPU: chunks of a launch's steps are handed from wave to wave through a
+work queue in device memory.  Scheduling only - every result must be bit-identical to the one-robot-per-wave launch,
+whatever the batch size, the chunk size, the number of rings (8 = one per XCD, or 1), the stream slices and the
+precision; and no wave may ever have given up waiting (slot 6 of the statistics)."""
+import numpy as np
+import pytest
+
+from gym_solo_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(n, dtype, spl, streams, migrate, max_steps, **kw):
+  import torch
+  if not torch.cuda.is_available():
+    pytest.fail('GPU tests need a visible MI355X')
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
+  from gym_solo_amd.workloads import register_benchmark_workload
+  cfg = Solo8VanillaConfig()
+  cfg.num_envs, cfg.dtype, cfg.auto_reset, cfg.steps_per_launch, cfg.rollout_streams = n, dtype, True, spl, streams
+  cfg.migrate_steps = migrate
+  for k, v in kw.items():
+    setattr(cfg, k, v)
+  env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
+  register_benchmark_workload(env, max_steps=max_steps)
+  env._ensure_program()
+  return env
+
+
+@pytest.mark.parametrize('dtype,n,spl,streams,k,chunk', [
+  ('float64', 4096, 20, 1, 20, 5),     # the driver's geometry: eight rings, 4096 robots on 3072 wave slots
+  ('float32', 4096, 20, 1, 20, 5),
+  ('float64', 1000, 20, 1, 40, 3),     # eight rings of 125 robots, ragged last chunk, two launches
+  ('float32', 777, 13, 2, 30, 4),      # one ring per slice (not divisible by 8), slices on two streams, ragged everything
+  ('float64', 64, 50, 1, 50, 40),      # more steps than one epilogue pass holds (28 in f64); two chunks
+  ('float32', 8192, 20, 2, 20, 2),     # many short chunks
+])
+def test_migration_is_bit_identical(dtype, n, spl, streams, k, chunk):
+  import torch
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  ref = _env(n, dtype, spl, streams, 0, 17)
+  mig = _env(n, dtype, spl, streams, chunk, 17)
+  g = torch.Generator(device='cuda').manual_seed(n + k)
+  acts = (torch.rand(k, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.2831853
+  # spread the episode phases, so that terminations / auto-resets fall into every chunk
+  phase = torch.randint(0, 17, (n,), device='cuda', generator=g, dtype=torch.int32)
+  for e in (ref, mig):
+    e.engine.term_count[:, 0] = phase
+  a = ref.engine.rollout(acts, abi.STEP_ALL, record=True)
+  b = mig.engine.rollout(acts, abi.STEP_ALL, record=True)
+  torch.cuda.synchronize()
+  for x, y in zip(a, b):
+    assert torch.equal(x, y)
+  for name in ('state', 'targets', 'term_count', 'cost', 'obs', 'reward', 'done'):
+    assert torch.equal(getattr(ref.engine, name), getattr(mig.engine, name)), name
+  sa, sb = ref.engine.stats.cpu().numpy(), mig.engine.stats.cpu().numpy()
+  assert sb[6] == 0                                  # no wave gave up waiting for a ring slot
+  np.testing.assert_array_equal(sa[[2, 5]], sb[[2, 5]])   # episodes, restored robots: exact counts
+  np.testing.assert_allclose(sa[:4], sb[:4], rtol=1e-12)   # (sums of returns: atomic adds in another order)
+  assert sa[2] > 0
+  ref._close(); mig._close()
+
+
+def test_migration_physics_only_rollout_and_residual_threshold():
+  """The physics-only rollout (client.stepSimulation loops: flags = PHYSICS) and pybullet's residual threshold (an
+  opt-in with kernel instantiations of its own) under migration."""
+  import torch
+  n, k = 512, 24
+  for resid in (0.0, 1e-7):
+    ref = _env(n, 'float64', 24, 1, 0, 1000, solver_residual_threshold=resid)
+    mig = _env(n, 'float64', 24, 1, 6, 1000, solver_residual_threshold=resid)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    acts = (torch.rand(k, n, 12, device='cuda', dtype=torch.float64, generator=g) * 2 - 1) * 6.2831853
+    for flags in (abi.STEP_PHYSICS, abi.STEP_ALL):
+      ref.engine.rollout(acts, flags)
+      mig.engine.rollout(acts, flags)
+      torch.cuda.synchronize()
+      assert torch.equal(ref.engine.state, mig.engine.state)
+      assert torch.equal(ref.engine.cost, mig.engine.cost)
+    assert mig.engine.stats.cpu().numpy()[6] == 0
+    ref._close(); mig._close()

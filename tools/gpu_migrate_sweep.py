@@ -1,0 +1,28 @@
+"""MEASUREMENT: robot migration (SoloConfig.migrate_steps) on the bench workload's steady state - the open-loop rollout
+of K steps with S steps per launch on G stream slices, over a list of chunk lengths (0 = off).
+  python tools/gpu_migrate_sweep.py float64 K S G  m1 m2 ..."""
+import sys, os, time, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from gym_solo_amd import abi
+dtype = sys.argv[1]; k, spl, streams = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+n = 4096
+tdt = torch.float32 if dtype == 'float32' else torch.float64
+for m in [int(x) for x in sys.argv[5:]]:
+  env = bench.build_env(n, 0, dtype, steps_per_launch=spl, rollout_streams=streams, migrate_steps=m)
+  eng = env.engine
+  gen = torch.Generator(device='cuda').manual_seed(1234)
+  bench.desynchronise_episodes(eng, gen)
+  acts = (torch.rand(k, n, abi.NUM_JOINTS, device='cuda', dtype=tdt, generator=gen) * 2 - 1) * 6.283185307179586
+  out = eng.rollout_buffers(k)
+  eng.rollout(acts, abi.STEP_ALL, out=out)
+  ts = []
+  for _ in range(7):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.rollout(acts, abi.STEP_ALL, out=out)
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+  print('%s K = %d, %d steps per launch, %d slices, migrate_steps %3d: %.4g env-steps/s (median of 7; gave up waiting: %d)' % (
+    dtype, k, spl, streams, m, n * k / statistics.median(ts), int(eng.stats.cpu()[6])), flush=True)
+  env._close()

@@ -13,9 +13,9 @@ dtype = sys.argv[1] if len(sys.argv) > 1 else 'float64'
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 sizes = [int(x) for x in sys.argv[3:]] or [2048, 3072, 4096, 6144, 8192]
 tdt = torch.float32 if dtype == 'float32' else torch.float64
-print('library: %s' % os.environ.get('SOLO_HIP_LIB', 'libsolo_hip.so'), flush=True)
+print('library: %s  migrate_steps: %s' % (os.environ.get('SOLO_HIP_LIB', 'libsolo_hip.so'), os.environ.get('MIGRATE', '0')), flush=True)
 for n in sizes:
-  env = bench.build_env(n, 0, dtype, steps_per_launch=k, rollout_streams=1)
+  env = bench.build_env(n, 0, dtype, steps_per_launch=k, rollout_streams=1, migrate_steps=int(os.environ.get('MIGRATE', '0')))
   eng = env.engine
   gen = torch.Generator(device='cuda').manual_seed(1234)
   bench.desynchronise_episodes(eng, gen)
