@@ -75,7 +75,12 @@ def desynchronise_episodes(eng, generator, max_steps=1000, advance=True):
   from gym_solo_amd import abi
   n, dev = eng.num_envs, eng.state.device
   phase = torch.randint(0, max_steps, (n,), device=dev, generator=generator, dtype=torch.int32)
-  eng.term_count[:, 0] = phase
+  # the TimeBased termination's counter: its slot in the registered program (not "column 0")
+  prog = eng.program
+  slots = [i for i in range(prog.num_terms) if prog.term_kind[i] == abi.T_TIME] if prog is not None else []
+  if len(slots) != 1:
+    raise SystemExit('desynchronise_episodes expects exactly one TimeBasedTermination in the workload, found %d' % len(slots))
+  eng.term_count[:, slots[0]] = phase
   eng.state[:, abi.S_EPLEN] = phase.to(eng.tdtype)
   if not advance:
     return
@@ -199,12 +204,20 @@ def pmc_profile(dtype, spl, slices):
       table = json.load(f)
   except Exception:  # noqa: BLE001
     return {}
+  # a profile is only as good as the binary it was taken on: every entry carries the hash of the kernel sources
+  # (gym_solo_amd/build_info.py); an entry from other sources is reported as stale and none of its figures is quoted
+  from gym_solo_amd.build_info import kernel_source_hash
+  now = kernel_source_hash()
+  def pick(key, e, match):
+    if e.get('kernel_source_hash') != now:
+      return {'stale': True, 'profile_key': key, 'profile_hash': e.get('kernel_source_hash'), 'source_hash': now}
+    return dict(e, geometry_match=match, profile_key=key, stale=False, source_hash=now)
   for key, e in table.items():
     if key.startswith(dtype) and e.get('steps_per_launch') == spl and e.get('launch_chains') == slices:
-      return dict(e, geometry_match=True, profile_key=key)
+      return pick(key, e, True)
   for key in (dtype + '_k20' if spl <= 20 else dtype, dtype, dtype + '_k20'):
     if key in table:
-      return dict(table[key], geometry_match=False, profile_key=key)
+      return pick(key, table[key], False)
   return {}
 
 
@@ -447,7 +460,9 @@ def main():
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
             'traffic_note': pmc.get('traffic_note'),
-            'traffic_profile': None if not pmc else {'entry': pmc.get('profile_key'), 'measured_on_this_launch_geometry': pmc.get('geometry_match')},
+            'traffic_profile': None if not pmc else {'entry': pmc.get('profile_key'), 'measured_on_this_launch_geometry': pmc.get('geometry_match'),
+                                                     'stale': bool(pmc.get('stale')), 'kernel_source_hash': pmc.get('source_hash'),
+                                                     'profile_kernel_source_hash': pmc.get('profile_hash') or pmc.get('kernel_source_hash')},
             'kernel': eng.kernel_name, 'kernel_ms': kern_ms,
             'kernel_ms_note': 'HIP events around the launch chain of every slice, on the stream it is launched on; mean per '
                               'launch over slices and launches (the step kernel is the only kernel of a launch: its epilogue writes the outputs)',
@@ -514,7 +529,7 @@ def main():
                              'TimeBasedTermination(1000)+auto-reset, steady state (episode phases spread uniformly by 1000 untimed steps), dt=1e-3, 50 PGS iterations' % n,
                  'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': slices, 'migrate_steps': int(eng.cfg.migrate_steps),
                  'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
-      'timing': {'repeats': len(times), 'statistic': 'median', 'min_ms_per_step': min(times) / k * 1e3,
+      'timing': {'repeats': len(times), 'statistic': 'median', 'stats_reduction_inside_timed_region': bool(distributed), 'min_ms_per_step': min(times) / k * 1e3,
                  'max_ms_per_step': max(times) / k * 1e3, 'value_best_repeat': world * n * k / min(times),
                  'value_worst_repeat': world * n * k / max(times), 'first_repeats_ms_per_step': [t / k * 1e3 for t in times[:6]],
                  'note': 'W warm-up steps and one untimed repeat of the timed call first; then each repeat = exactly K steps '

@@ -39,6 +39,52 @@ def test_struct_sizes_match_header():
   assert got == want
 
 
+def test_field_offsets_match_header():
+  """sizeof() alone lets two equal-sized fields swap places unnoticed: compare offsetof() of EVERY field of every
+  struct of the boundary (names taken from the ctypes mirror, so a field missing in the header fails the compile)."""
+  import subprocess, tempfile
+  structs = [t for t in (abi.SoloModel, abi.SoloConfig, abi.SoloObsElem, abi.SoloRewardInstr, abi.SoloProgram,
+                         abi.SoloStateView, abi.SoloTerrain)]
+  lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "solo_engine.h"', 'int main(){']
+  want = []
+  for t in structs:
+    for name, *_ in t._fields_:
+      lines.append('printf("%%zu\\n", offsetof(%s, %s));' % (t.__name__, name))
+      want.append((t.__name__, name, getattr(t, name).offset))
+  lines.append('return 0;}')
+  with tempfile.TemporaryDirectory() as d:
+    open(os.path.join(d, 't.c'), 'w').write('\n'.join(lines) + '\n')
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', os.path.join(d, 't'), os.path.join(d, 't.c')])
+    got = [int(x) for x in subprocess.check_output([os.path.join(d, 't')]).split()]
+  assert len(got) == len(want) > 60
+  for (sname, fname, off), g in zip(want, got):
+    assert off == g, '%s.%s: ctypes offset %d, header offset %d' % (sname, fname, off, g)
+
+
+def test_counter_profiles_are_pinned_to_the_kernel_sources(tmp_path, monkeypatch):
+  """bench.py quotes HBM traffic / instruction counts from profiles/pmc_traffic.json only when the profile was taken
+  on the kernel sources of THIS tree (gym_solo_amd/build_info.py); otherwise the roofline block says stale and carries
+  no traffic figure."""
+  import json, sys
+  sys.path.insert(0, ROOT)
+  import bench
+  from gym_solo_amd import build_info
+  now = build_info.kernel_source_hash()
+  assert len(now) == 16 and now == build_info.kernel_source_hash()
+  table = {'float64_k20': {'kernel_source_hash': now, 'steps_per_launch': 20, 'launch_chains': 1, 'hbm_bytes_per_env_step': 700.0},
+           'float32_k20': {'kernel_source_hash': 'deadbeefdeadbeef', 'steps_per_launch': 20, 'launch_chains': 1, 'hbm_bytes_per_env_step': 330.0}}
+  (tmp_path / 'profiles').mkdir()
+  (tmp_path / 'profiles' / 'pmc_traffic.json').write_text(json.dumps(table))
+  monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+  fresh = bench.pmc_profile('float64', 20, 1)
+  assert fresh['stale'] is False and fresh['hbm_bytes_per_env_step'] == 700.0 and fresh['geometry_match'] is True
+  stale = bench.pmc_profile('float32', 20, 1)
+  assert stale['stale'] is True and 'hbm_bytes_per_env_step' not in stale and stale['profile_hash'] == 'deadbeefdeadbeef'
+  # a changed kernel source changes the hash
+  monkeypatch.setattr(build_info, 'kernel_source_files', lambda: [HEADER])
+  assert build_info.kernel_source_hash() != now
+
+
 def test_library_exports_every_declared_symbol():
   if not os.path.exists(LIB):
     import subprocess

@@ -1,0 +1,55 @@
+"""BUILD CHECK (CPU): the register-index mode switches of the product kernels.
+
+Round 3 found the step kernel computing wave-dependent garbage when a VECTOR instruction directly follows
+s_set_gpr_idx_on (solo_pgs_gfx950.h: observed on this kernel, mechanism not established).  The rule the code follows -
+(1) every s_set_gpr_idx_on / s_set_gpr_idx_off is followed by a SCALAR instruction, and (2) the product contains no
+compiler-generated indexed sequence at all (every switch sits inside the hand-written Gauss-Seidel loops, i.e. between
+the ;;#ASMSTART / ;;#ASMEND markers of an inline-asm statement) - is checked here on the generated assembly of EVERY
+kernel instantiation, so that a compiler bump or a new dynamically indexed local array cannot bring the failure back
+unnoticed.   usage: python tools/check_gpr_idx.py [file.s]   (default: make -C gym_solo_amd/csrc asm)"""
+import os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def check(path):
+  lines = open(path).read().split('\n')
+  in_asm, func, errors, switches = False, None, [], 0
+  def next_instruction(i):
+    for j in range(i + 1, len(lines)):
+      t = lines[j].strip()
+      if not t or t.startswith(';') or t.startswith('.') or t.endswith(':') or t.startswith('//'):
+        continue
+      return t
+    return ''
+  for i, raw in enumerate(lines):
+    t = raw.strip()
+    m = re.match(r'^(_Z\w+):', raw)
+    if m:
+      func = m.group(1)
+    if t.startswith(';;#ASMSTART'):
+      in_asm = True
+    elif t.startswith(';;#ASMEND'):
+      in_asm = False
+    if re.match(r'^s_set_gpr_idx_(on|off)\b', t):
+      switches += 1
+      if not in_asm:
+        errors.append('%s:%d: compiler-generated %s in %s' % (path, i + 1, t.split()[0], func))
+      nxt = next_instruction(i)
+      if not nxt.startswith('s_'):
+        errors.append('%s:%d: %s is followed by a vector instruction (%s) in %s' % (path, i + 1, t.split()[0], nxt, func))
+    elif re.match(r'^(s_set_gpr_idx_idx|s_set_gpr_idx_mode|v_movrel)', t):
+      errors.append('%s:%d: unexpected indexed-register instruction %s in %s' % (path, i + 1, t, func))
+  return switches, errors
+
+
+if __name__ == '__main__':
+  if len(sys.argv) > 1:
+    path = sys.argv[1]
+  else:
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'gym_solo_amd', 'csrc'), 'asm'])
+    path = os.path.join(ROOT, 'gym_solo_amd', 'csrc', 'solo_engine.gfx950.s')
+  n, errs = check(path)
+  for e in errs:
+    print(e)
+  print('%d register-index mode switches checked, %d violations' % (n, len(errs)))
+  sys.exit(1 if errs or n == 0 else 0)

@@ -15,6 +15,8 @@ outputs kernel) re-reads its own records and writes the rows with dword stores. 
 import json, os, sys
 src, cfg = sys.argv[1], (sys.argv[2:] or ['f32'])[0]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gym_solo_amd.build_info import kernel_source_hash
 hbm = json.load(open(os.path.join(src, 'pmc_hbm_%s.json' % cfg)))
 sq = json.load(open(os.path.join(src, 'pmc_sq_%s.json' % cfg)))
 meta = json.load(open(os.path.join(src, 'prof_driver_%s.json' % cfg)))   # robots per launch, steps per launch
@@ -31,6 +33,9 @@ wr = sum(p['write_bytes_per_env_step'] for p in per.values())
 s = sq['step']
 wave_cycles = s.get('SQ_WAVE_CYCLES')
 out = {key: {
+  # the kernel sources the counters were collected on (bench.py drops the profile when they have changed since)
+  'kernel_source_hash': kernel_source_hash(),
+  'migrate_steps': meta.get('migrate_steps', 0),
   'env_steps_per_profiled_launch': n,
   'steps_per_launch': meta['steps_per_launch'], 'robots_per_launch': meta['robots_per_launch'], 'launch_chains': meta.get('launch_chains', 1),
   'hbm_bytes_per_env_step': rd + wr,
