@@ -45,23 +45,34 @@ VALU_CYCLES_SHARED = 2                                  # wave64 VALU instructio
 VALU_CYCLES_ALONE = 4                                   # the SIMD; 4 for one wave alone (MI355X_MICROARCH.md constants)
 SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICROARCH.md chip table
 METRIC = 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X'
+# REHEARSAL knobs (never set by the driver; tests/test_bench_launcher.py): SOLO_BENCH_ENGINE=emu runs the whole script -
+# launcher, process group (gloo), timed regions, statistics all-reduce, JSON line - on the CPU wave emulator of the
+# product kernel source, a few robots per rank; SOLO_BENCH_MAX_STEPS shortens the episodes so that a tiny run ends some.
+EMU = os.environ.get('SOLO_BENCH_ENGINE') == 'emu'
+MAX_STEPS = int(os.environ.get('SOLO_BENCH_MAX_STEPS', '1000'))
 
 
-def build_env(num_envs, device, dtype, max_steps=1000, steps_per_launch=1, rollout_streams=1, residual_threshold=0.0, migrate_steps=0):
+def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=1, rollout_streams=1, residual_threshold=0.0, migrate_steps=0):
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
+  if EMU:  # CPU REHEARSAL of the launcher / collective / JSON plumbing (tests/test_bench_launcher.py): never a measurement
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from emu_kernel import make_emu_env_class
+    Solo8VanillaEnv = make_emu_env_class()
   cfg = Solo8VanillaConfig()
   cfg.num_envs, cfg.device, cfg.dtype, cfg.auto_reset = num_envs, device, dtype, True
   cfg.steps_per_launch, cfg.rollout_streams = steps_per_launch, rollout_streams
   cfg.solver_residual_threshold = residual_threshold
   cfg.migrate_steps = migrate_steps
+  if EMU:
+    cfg.settle_steps = 30
   env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
   register_benchmark_workload(env, max_steps=max_steps)
   env._ensure_program()
   return env
 
 
-def desynchronise_episodes(eng, generator, max_steps=1000, advance=True):
+def desynchronise_episodes(eng, generator, max_steps=MAX_STEPS, advance=True):
   """Brings the batch into the STEADY STATE of the workload before anything is timed.  All robots are created
   in the same post-reset pose with their 1000-step episodes in phase: a 20-step window right after that would
   never see a termination, an auto-reset or a real number in the statistics all-reduce, and would time 4096
@@ -84,11 +95,12 @@ def desynchronise_episodes(eng, generator, max_steps=1000, advance=True):
   eng.state[:, abi.S_EPLEN] = phase.to(eng.tdtype)
   if not advance:
     return
-  chunk = 100
+  chunk = min(100, max_steps)
   for _ in range(0, max_steps, chunk):
     a = (torch.rand(chunk, n, abi.NUM_JOINTS, device=dev, dtype=eng.tdtype, generator=generator) * 2 - 1) * (2 * 3.141592653589793)
     eng.rollout(a, abi.STEP_ALL)
-  torch.cuda.synchronize(dev)
+  if dev.type == 'cuda':
+    torch.cuda.synchronize(dev)
 
 
 def host_cores():
@@ -104,7 +116,7 @@ def host_cores():
   return max(1, min(n, int(os.environ.get('SOLO_CPU_BASELINE_THREADS', '16'))))
 
 
-def cpu_baseline(num_envs, seconds_target=12.0):
+def cpu_baseline(num_envs, seconds_target=float(os.environ.get('SOLO_CPU_BASELINE_SECONDS', '12'))):
   """The CPU oracle (double-precision scalar C restatement + numpy reductions) on the host
   cores, bounded sample of the same workload.  kind = "port": PyBullet itself is not
   installable in this pipeline.  The ONLY place bench.py touches tests/ or
@@ -143,7 +155,7 @@ def cpu_baseline(num_envs, seconds_target=12.0):
     env1.phys = so.OraclePhysics(ca, ma, lib_path)
   env1.step(rng.uniform(-2 * np.pi, 2 * np.pi, (256, 12)))
   s1, t1 = 0, time.perf_counter()
-  while time.perf_counter() - t1 < 3.0:
+  while time.perf_counter() - t1 < min(3.0, seconds_target):
     env1.step(rng.uniform(-2 * np.pi, 2 * np.pi, (256, 12)))
     s1 += 1
   one_core = 256 * s1 / (time.perf_counter() - t1)
@@ -334,14 +346,15 @@ def main():
   from gym_solo_amd import abi
   from gym_solo_amd.distributed import all_reduce_stats, rank_seed, summarize
 
-  if not torch.cuda.is_available():
+  if not EMU and not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
   # rehearsal knobs for a 1-GPU box (never set by the driver): every rank on cuda:0, gloo instead of
   # RCCL (which refuses two ranks on one device) - exercises the launcher and the multi-rank timing
-  backend = os.environ.get('SOLO_BENCH_BACKEND', 'nccl')
+  backend = os.environ.get('SOLO_BENCH_BACKEND', 'gloo' if EMU else 'nccl')
   if os.environ.get('SOLO_BENCH_SHARE_GPU') == '1':
     local_rank = 0
-  torch.cuda.set_device(local_rank)
+  if not EMU:
+    torch.cuda.set_device(local_rank)
   # under torch.distributed.run the collective path is exercised even with one rank
   distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or os.environ.get('SOLO_BENCH_FORCE_DIST') == '1'
   log = (lambda *a: print('[bench rank %d]' % rank, *a, file=sys.stderr, flush=True)) if distributed else (lambda *a: None)
@@ -350,19 +363,23 @@ def main():
     os.environ.setdefault('MASTER_PORT', '29531')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend == 'nccl':
-      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))  # (RCCL)
     else:
       dist.init_process_group(backend, rank=rank, world_size=world)
     log("init_process_group('%s') ok: world_size %d, backend %s, device cuda:%d" % (backend, world, dist.get_backend(), local_rank))
 
-  dev = 'cuda:%d' % local_rank
+  dev = 'cpu' if EMU else 'cuda:%d' % local_rank
   n, k, w = args.envs_per_gpu, args.steps, args.warmup
   two_pi = 2 * 3.141592653589793
 
   def barrier():
     if distributed:
       dist.barrier()
-    torch.cuda.synchronize(local_rank)
+    device_sync()
+
+  def device_sync():
+    if not EMU:
+      torch.cuda.synchronize(local_rank)
 
   def max_over_ranks(x):
     if not distributed:
@@ -423,7 +440,7 @@ def main():
         # i.e. after every rank's K steps (stream-ordered in front of its contribution) - a dist.barrier() behind it
         # would be a second collective with the same meaning (~5 % of a 0.4-ms region on one rank)
         after = all_reduce_stats(eng.stats_shards.sum(dim=0), in_place=True)
-        torch.cuda.synchronize(local_rank)
+        device_sync()
       else:
         barrier()
       t = max_over_ranks(time.perf_counter() - t0)
@@ -526,7 +543,7 @@ def main():
       'dtype': 'f32' if args.dtype == 'float32' else 'f64', 'data': 'synthetic',
       'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
                              'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
-                             'TimeBasedTermination(1000)+auto-reset, steady state (episode phases spread uniformly by 1000 untimed steps), dt=1e-3, 50 PGS iterations' % n,
+                             'TimeBasedTermination(%d)+auto-reset, steady state (episode phases spread uniformly by %d untimed steps), dt=1e-3, 50 PGS iterations' % (n, MAX_STEPS, MAX_STEPS),
                  'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': slices, 'migrate_steps': int(eng.cfg.migrate_steps),
                  'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'timing': {'repeats': len(times), 'statistic': 'median', 'stats_reduction_inside_timed_region': bool(distributed), 'min_ms_per_step': min(times) / k * 1e3,

@@ -173,6 +173,43 @@ class EmuTorchEngine:
   def set_targets(self, actions):
     self._e.targets[:] = actions.detach().cpu().numpy() * self.cfg.action_scale
 
+  # ---- the rollout calls of gym_solo_amd.engine.Engine (what bench.py drives) ------------------------------------
+  @property
+  def steps_per_launch(self):
+    return max(1, int(self.cfg.steps_per_launch))
+
+  def rollout_buffers(self, k):
+    torch = self._torch
+    return (torch.empty(k, self.num_envs, max(self.obs_dim, 1), dtype=torch.float64), torch.empty(k, self.num_envs, dtype=torch.float64),
+            torch.empty(k, self.num_envs, dtype=torch.uint8))
+
+  def rollout(self, actions, flags=abi.STEP_ALL, record=False, out=None):
+    """K open-loop steps in fused launches of steps_per_launch steps (robot migration as configured)."""
+    a = actions.detach().cpu().numpy()
+    k, spl = a.shape[0], self.steps_per_launch
+    parts = [self._e.rollout(a[i:i + spl], flags) for i in range(0, k, spl)]
+    if not record and out is None:
+      return None
+    obs, rew, done = out if out is not None else self.rollout_buffers(k)
+    torch = self._torch
+    obs.copy_(torch.from_numpy(np.concatenate([p[0] for p in parts])))
+    rew.copy_(torch.from_numpy(np.concatenate([p[1] for p in parts])))
+    done.copy_(torch.from_numpy(np.concatenate([p[2] for p in parts])))
+    return obs, rew, done
+
+  def time_step(self, actions=None, flags=abi.STEP_ALL, reps=100):
+    """Mean ms per emulated launch (wall clock: there is no device to time)."""
+    import time
+    spl = self.steps_per_launch
+    reps = int(actions.shape[0]) // spl
+    t0 = time.perf_counter()
+    self.rollout(actions[:reps * spl], flags)
+    return (time.perf_counter() - t0) * 1e3 / max(reps, 1)
+
+  @property
+  def cost(self):
+    return self._torch.from_numpy(self._e.cost)
+
   @staticmethod
   def _settle_targets(cfg):
     return np.array(list(cfg.settle_targets))
@@ -204,3 +241,18 @@ class EmuTorchEngine:
   @property
   def kernel_name(self):
     return 'emulated'
+
+
+def make_emu_env_class():
+  """Solo8VanillaEnv on the emulator engine (the host-side API without a GPU): tests/test_env_host.py, and bench.py's
+  CPU rehearsal (SOLO_BENCH_ENGINE=emu)."""
+  from gym_solo_amd.core.configs import config_to_abi
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaEnv
+  from gym_solo_amd.model import JOINT_NAMES
+
+  class EmuSolo8VanillaEnv(Solo8VanillaEnv):
+    def create_engine(self):
+      cfg = config_to_abi(self.config, self.config.starting_joint_pos, JOINT_NAMES, normalize_actions=self._normalize)
+      return EmuTorchEngine(cfg, self.solo_model.to_abi(), self.config.num_envs)
+
+  return EmuSolo8VanillaEnv

@@ -54,3 +54,25 @@ def test_a_dying_peer_rank_stops_rank_zero_at_once():
     bench.launch_ranks(2, child_cmd=child)
   assert time.time() - t0 < 60
   assert e.value.code not in (0, None)
+
+
+def test_two_rank_bench_end_to_end_on_the_emulator():
+  """`python bench.py --gpus 2` as the driver starts it - the self-launched ranks, the process group (gloo here, RCCL on
+  the node), per-rank seeds, the timed repeats with the statistics all-reduce as their closing barrier, max over
+  ranks, the roofline and cpu_baseline blocks, ONE JSON line from rank 0 - on the CPU wave emulator of the product
+  kernel source (SOLO_BENCH_ENGINE=emu: a few robots per rank, short episodes).  A launcher regression must not wait
+  for an 8-GPU node to show."""
+  import json
+  r = _run(['--gpus', '2', '--steps', '6', '--warmup', '2', '--envs-per-gpu', '4', '--no-extra', '--max-repeats', '2', '--min-seconds', '0'],
+           env={'SOLO_BENCH_ENGINE': 'emu', 'SOLO_BENCH_MAX_STEPS': '5', 'SOLO_CPU_BASELINE_SECONDS': '1', 'SOLO_CPU_BASELINE_THREADS': '2'})
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith('[Gloo]')]  # (gloo announces itself on stdout)
+  assert len(lines) == 1, r.stdout
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['steps'] == 6 and d['warmup'] == 2 and d['dtype'] == 'f64' and d['scaling'] == 'weak'
+  assert d['value'] > 0 and abs(d['value'] - 2 * 4 * 6 / (d['ms_per_step'] * 6e-3)) < 1e-6 * d['value']
+  assert d['roofline']['bound'] == 'hbm' and d['roofline']['achieved'] > 0 and d['roofline']['bytes_per_env_step'] == 765
+  assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0
+  assert d['episodes']['episodes'] > 0                      # both ranks' episodes went through the all-reduce
+  assert d['timing']['stats_reduction_inside_timed_region'] is True
+  assert "init_process_group('gloo') ok: world_size 2" in r.stderr and 'final barrier ok' in r.stderr

@@ -4,17 +4,9 @@ import numpy as np
 import pytest
 
 import env_cases as cases
-from emu_kernel import EmuTorchEngine
-from gym_solo_amd.core.configs import config_to_abi
-from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaEnv
-from gym_solo_amd.model import JOINT_NAMES
+from emu_kernel import make_emu_env_class
 
-
-class EmuSolo8VanillaEnv(Solo8VanillaEnv):
-  def create_engine(self):
-    cfg = config_to_abi(self.config, self.config.starting_joint_pos, JOINT_NAMES,
-                        normalize_actions=self._normalize)
-    return EmuTorchEngine(cfg, self.solo_model.to_abi(), self.config.num_envs)
+EmuSolo8VanillaEnv = make_emu_env_class()
 
 
 def make_env(config=None, **kw):
