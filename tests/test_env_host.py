@@ -5,6 +5,7 @@ import pytest
 
 import env_cases as cases
 from emu_kernel import make_emu_env_class
+from gym_solo_amd.core.configs import config_to_abi
 
 EmuSolo8VanillaEnv = make_emu_env_class()
 
