@@ -52,7 +52,8 @@ EMU = os.environ.get('SOLO_BENCH_ENGINE') == 'emu'
 MAX_STEPS = int(os.environ.get('SOLO_BENCH_MAX_STEPS', '1000'))
 
 
-def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=1, rollout_streams=1, residual_threshold=0.0, migrate_steps=0):
+def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=1, rollout_streams=1, residual_threshold=0.0, migrate_steps=0,
+              warm_start=0.0):
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
   if EMU:  # CPU REHEARSAL of the launcher / collective / JSON plumbing (tests/test_bench_launcher.py): never a measurement
@@ -63,6 +64,7 @@ def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=1, 
   cfg.num_envs, cfg.device, cfg.dtype, cfg.auto_reset = num_envs, device, dtype, True
   cfg.steps_per_launch, cfg.rollout_streams = steps_per_launch, rollout_streams
   cfg.solver_residual_threshold = residual_threshold
+  cfg.solver_warm_start = warm_start
   cfg.migrate_steps = migrate_steps
   if EMU:
     cfg.settle_steps = 30
@@ -388,7 +390,7 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
-  def timed(dtype, k, closed_loop, min_seconds, max_repeats, residual_threshold=0.0, steady=True):
+  def timed(dtype, k, closed_loop, min_seconds, max_repeats, residual_threshold=0.0, steady=True, warm_start=0.0):
     """Repeats of the K-step timed region on a fresh engine; returns per-repeat seconds (max over
     ranks), the summed episodic statistics of the timed repeats and the engine."""
     tdtype = torch.float32 if dtype == 'float32' else torch.float64
@@ -404,7 +406,7 @@ def main():
     if migrate < 0:
       migrate = (spl + 1) // 2 if (dtype == 'float64' and not closed_loop and spl >= 8 and k == spl) else 0
     env = build_env(n, local_rank, dtype, steps_per_launch=spl, rollout_streams=streams, residual_threshold=residual_threshold,
-                    migrate_steps=migrate)
+                    migrate_steps=migrate, warm_start=warm_start)
     eng = env.engine
     gen = torch.Generator(device=dev).manual_seed(rank_seed(1234, rank))
 
@@ -515,6 +517,10 @@ def main():
       tr, _, _, er, _, _, _ = timed(dt, ke, False, 0.3, 10, residual_threshold=1e-7)
       extra['value_residual_1e-7' + sfx] = world * n * ke / statistics.median(tr)
       er._close()
+      # ... and with the warm start on top of it (SoloConfig.solver_warm_start = 0.85, [recalled] Bullet's rigid-body factor)
+      tw, _, _, ew, _, _, _ = timed(dt, ke, False, 0.3, 10, residual_threshold=1e-7, warm_start=0.85)
+      extra['value_residual_warmstart' + sfx] = world * n * ke / statistics.median(tw)
+      ew._close()
       tcl, _, _, ecl, _, _, _ = timed(dt, ke, True, 0.3, 10)
       extra['value_closed_loop' + sfx] = world * n * ke / statistics.median(tcl)
       ecl._close()
@@ -523,6 +529,10 @@ def main():
                                     'headline precision and (suffix) the other one; NOT the configuration of `value`: '
                                     'without warm starting it leaves a resting robot jittering at 5e-5 rad/s, where the reference\'s recorded '
                                     'rest state has 1e-11')
+    extra['value_residual_warmstart_note'] = ('residual threshold 1e-7 + SoloConfig.solver_warm_start = 0.85: every step starts from 0.85 x the impulses the '
+                                              'previous one ended with; the cache costs 2 x 64 reals = %d (f64) / 512 (f32) B of memory traffic per env-step ON TOP of '
+                                              'the algorithmic %d / 385 B (SURVEY.md 8d: reported separately); NOT the configuration of `value`, and it does not '
+                                              'make the threshold solver rest either (profiles/round4_rest_drift.log)' % (1024, 765))
     extra['value_closed_loop_note'] = ('one solo_engine_step launch per env step (outputs evaluated in that launch), the '
                                        'granularity of Solo8VanillaEnv.step (solo8v2vanilla.py:72-102), actions pre-generated, '
                                        'no host synchronisation between steps; median over repeats of %d steps; headline precision and (suffix) the other one' % ke)

@@ -98,6 +98,7 @@ class SoloConfig(C.Structure):
     ('solver_residual_threshold', C.c_double),
     ('migrate_steps', C.c_int32),
     ('reserved0', C.c_int32),
+    ('solver_warm_start', C.c_double),
   ]
 
 
@@ -180,6 +181,7 @@ class SoloStateView(C.Structure):
     ('params', C.c_void_p),
     ('stats', C.c_void_p),
     ('cost', C.c_void_p),
+    ('warm', C.c_void_p),
   ]
 
 

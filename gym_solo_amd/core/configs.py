@@ -57,6 +57,12 @@ class Solo8BaseConfig:
   # reference's one pybullet-extracted state (test_obs_observations.py:256-275) rests at 1e-11: so OFF (0) by default,
   # the iteration runs to its fixed point; 1e-7 is the opt-in (what it is worth)
   solver_residual_threshold: float = 0.0
+  # warm starting (an OPT-IN, only together with solver_residual_threshold > 0): a step's iteration starts from this
+  # factor x the impulses the previous step ended with (clamped to this step's bounds) instead of from zero.  With it
+  # the residual-threshold exit leaves a resting robot at rest (tests/test_gpu_warm_start.py: 1e-12 rad/s against
+  # 5e-5 without).  [recalled] Bullet's rigid-body contacts use m_warmstartingFactor 0.85; 1.0 is the value that keeps
+  # a fixed point fixed.  0 = off.
+  solver_warm_start: float = 0.0
   motor_kp: float = 0.1           # pybullet POSITION_CONTROL default positionGain [recalled]
   motor_kd: float = 1.0           # pybullet POSITION_CONTROL default velocityGain [recalled]
   contact_erp: float = 0.2
@@ -144,6 +150,12 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
   c.action_scale = float(np.float32(config.max_motor_rotation)) if normalize_actions else 1.0
   c.auto_reset = 1 if config.auto_reset else 0
   c.steps_per_launch = max(1, int(getattr(config, 'steps_per_launch', 1)))
+  c.solver_warm_start = float(getattr(config, 'solver_warm_start', 0.0))
+  if not 0.0 <= c.solver_warm_start <= 1.0:
+    raise ValueError('solver_warm_start must be in [0, 1]')
+  if c.solver_warm_start > 0 and not c.solver_residual_threshold > 0:
+    raise ValueError('solver_warm_start is an option of the residual-threshold solver: set solver_residual_threshold > 0 '
+                     '(pybullet documents 1e-7)')
   c.rollout_streams = max(1, int(getattr(config, 'rollout_streams', 1)))
   c.migrate_steps = int(getattr(config, 'migrate_steps', 0))
   if c.migrate_steps < 0:

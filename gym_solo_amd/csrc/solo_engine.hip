@@ -55,7 +55,7 @@ struct Engine final : EngineBase {
   solo::KParams<T> hparams;
   solo::KParams<T>* dparams = nullptr;
   T *state = nullptr, *snapshot = nullptr, *targets = nullptr, *params = nullptr, *obs = nullptr,
-    *reward = nullptr, *settle_actions = nullptr;
+    *reward = nullptr, *settle_actions = nullptr, *warm = nullptr;  // (warm: the warm-start cache [N][64], SoloStateView::warm)
   // per-launch scratch: the step records [N][S][32] a fused launch leaves for its own output epilogue
   // (S = steps per launch)
   T* traj = nullptr;
@@ -79,7 +79,7 @@ struct Engine final : EngineBase {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : {(void*)dparams, (void*)state, (void*)snapshot, (void*)targets, (void*)params,
                     (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
-                    (void*)term_count, (void*)order, (void*)cost, (void*)stats, (void*)terrain, (void*)traj, (void*)queue})
+                    (void*)term_count, (void*)order, (void*)cost, (void*)stats, (void*)terrain, (void*)traj, (void*)queue, (void*)warm})
       if (p) (void)hipFree(p);
   }
 
@@ -104,6 +104,8 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMalloc((void**)&cost, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMemset(cost, 0, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&traj, (size_t)spl() * ns * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&warm, (size_t)n * 64 * sizeof(T)));
+    HIP_TRY(hipMemset(warm, 0, (size_t)n * 64 * sizeof(T)));
     if (migrate_chunk() > 0)
       HIP_TRY(hipMalloc((void**)&queue, ((size_t)kMaxStreams * solo::kQueueHeader + (size_t)n * (1 + solo::migration_chunks(spl(), migrate_chunk()))) * sizeof(int32_t)));
     HIP_TRY(hipMemset(obs, 0, (size_t)n * SOLO_MAX_OBS * sizeof(T)));
@@ -138,6 +140,7 @@ struct Engine final : EngineBase {
     b.stats = stats; b.terrain = terrain; b.order = use_order ? order : nullptr; b.cost = cost; b.num_envs = n; b.flags = flags; b.env_base = 0; b.count = n; b.steps = 1;
     b.action_stride = b.done_stride = 0;
     b.queue = nullptr; b.q_rings = 1; b.q_chunk = 0;
+    b.warm = cfg.solver_warm_start > 0 ? warm : nullptr;
 #ifdef SOLO_STAMPS
     b.stamps = stamps;
 #endif
@@ -162,6 +165,7 @@ struct Engine final : EngineBase {
     if (int rc = launch_chain(settle_actions, 0, cfg.settle_steps, SOLO_STEP_PHYSICS, nullptr, nullptr, nullptr, s, 0, n)) return rc;
     HIP_TRY(hipMemcpyAsync(snapshot, state, (size_t)total * sizeof(T), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemsetAsync(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(warm, 0, (size_t)n * 64 * sizeof(T), s));  // (the snapshot starts from an empty warm-start cache)
     HIP_TRY(hipMemsetAsync(stats, 0, kStatsBytes, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SOLO_OK;
@@ -184,7 +188,7 @@ struct Engine final : EngineBase {
     HIP_TRY(hipSetDevice(device));
     const int total = n * SOLO_STATE_STRIDE;
     hipLaunchKernelGGL(solo::solo_reset_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, dparams, state, snapshot,
-                       targets, term_count, mask, n);
+                       targets, term_count, warm, mask, n);
     HIP_TRY(hipGetLastError());
     return SOLO_OK;
   }
@@ -261,7 +265,11 @@ struct Engine final : EngineBase {
         if (want_obs) b.obs_inline = obs_out ? obs_out + (size_t)i * n * obs_dim : obs;
         if (want_reward) b.reward_inline = reward_out ? reward_out + (size_t)i * n : reward;
       } else if (want_obs || want_reward) {
-        b.traj = traj;
+        // (the launch's own region of the record scratch, indexed by robot - first robot of the launch: the slices of
+        // a rollout run side by side with DIFFERENT step counts when one of them is already in its ragged last launch -
+        // indexed by absolute robot x steps of the launch their regions overlapped: a race that round 4's warm-start
+        // test caught, tests/test_gpu_warm_start.py)
+        b.traj = traj + (size_t)lo * (size_t)spl() * SOLO_STATE_STRIDE;
         // a recording rollout keeps every step ([K][N][.] buffers of the caller) and its last launch also leaves the
         // last step in the engine's view; otherwise only the last step's observation / reward / done stay in the view
         const bool tail_to_view = final_chunk && i + S >= k;
@@ -475,7 +483,7 @@ struct Engine final : EngineBase {
     v->state_stride = SOLO_STATE_STRIDE;
     v->obs_dim = obs_dim;
     v->state = state; v->snapshot = snapshot; v->targets = targets; v->obs = obs; v->reward = reward;
-    v->done = done; v->term_count = term_count; v->params = params; v->stats = stats; v->cost = cost;
+    v->done = done; v->term_count = term_count; v->params = params; v->stats = stats; v->cost = cost; v->warm = warm;
     return SOLO_OK;
   }
 
@@ -503,6 +511,8 @@ int check_config(const SoloConfig* c, std::string* err) {
   if (!(c->solver_residual_threshold >= 0)) return fail("solver_residual_threshold must be >= 0");
   if (c->settle_steps < 0 || c->settle_steps > 100000) return fail("settle_steps out of range");
   if (c->steps_per_launch < 0 || c->steps_per_launch > 100000) return fail("steps_per_launch out of range");
+  if (!(c->solver_warm_start >= 0 && c->solver_warm_start <= 1)) return fail("solver_warm_start must be in [0, 1]");
+  if (c->solver_warm_start > 0 && !(c->solver_residual_threshold > 0)) return fail("solver_warm_start needs solver_residual_threshold > 0");
   if (c->migrate_steps < 0 || c->migrate_steps > 100000 || c->reserved0 != 0) return fail("migrate_steps out of range");
   if (c->restitution != 0.0) return fail("only restitution 0 is supported (gym_solo configs.py:23)");
   if (!(c->action_scale > 0)) return fail("action_scale must be positive");

@@ -74,6 +74,7 @@ struct StepConst {
   T erp_over_dt, margin;
   T limit_margin;  // SoloConfig::joint_limit_margin
   T resid_thr;     // SoloConfig::solver_residual_threshold (squared velocity-level change; 0 = off)
+  T warm_factor;   // SoloConfig::solver_warm_start (0 = every step starts from zero impulses)
   T action_scale;
   // heightfield ground (SoloTerrain): 1/cell, origin; grid size below; heights live in KBuffers::terrain
   T terr_inv_cell, terr_ox, terr_oy;
@@ -157,8 +158,8 @@ struct KBuffers {
   T* targets;         // [N][12]
   const T* actions;   // [N][12] or null
   const T* params;    // [N][4]
-  T* traj;            // [N][steps][32] per-step records of a fused launch (robot-major: a robot's records are
-                      // contiguous), evaluated by the robot's own wave at the end of the launch (lane = step), or null
+  T* traj;            // [count][steps][32] per-step records of a fused launch (robot-major, FIRST ROBOT OF THE LAUNCH first:
+                      // a robot's records are contiguous), evaluated by the robot's wave after its last step (lane = step), or null
   T* obs_inline;      // single-step f32 launches (the closed-loop step()): [N][D] / [N] outputs evaluated lane-parallel
   T* reward_inline;   // over the ITEMS of the one step; null otherwise
   // where the outputs of a launch that leaves records go (all optional):
@@ -175,6 +176,8 @@ struct KBuffers {
   const T* terrain;   // [ny][nx] heights, or null = flat plane z = 0
   const int32_t* order;  // [N] workgroup -> robot (solo_engine_set_order), or null = identity
   int32_t* cost;      // [N] Gauss-Seidel sweeps of the robot in this launch, or null
+  T* warm;            // [N][64] warm-start cache (SoloConfig::solver_warm_start): every row's impulse at the end of the
+                      // robot's previous step, lane layout; null = off
   int32_t num_envs;    // total robots of the engine
   uint32_t flags;
   int32_t env_base;    // first robot of this launch (grid = robots of this launch)
@@ -239,6 +242,7 @@ inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) 
   k->c.auto_reset = c.auto_reset;
   k->c.ulp_tol = c.solver_ulp_tolerance;
   k->c.resid_thr = (T)c.solver_residual_threshold;
+  k->c.warm_factor = (T)c.solver_warm_start;
   for (int j = 0; j < SOLO_NUM_JOINTS; ++j) k->c.settle_tgt[j] = (T)c.settle_targets[j];
   k->c.base_mass = (T)m.mass[0];
   for (int a = 0; a < 6; ++a) k->c.base_I[a] = (T)m.inertia[0][a];

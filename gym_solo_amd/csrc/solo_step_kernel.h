@@ -199,7 +199,7 @@ template <typename T, bool kResid>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
                                            const RowView<T>& rc, const T* s_state, T my_target, T* s_rowvec, T (*s_hext)[8],
                                            T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& row_at,
-                                           int& prio_sweeps, int& prio_steps, int& prio_rot) {
+                                           int& prio_sweeps, int& prio_steps, int& prio_rot, T warm_in = T(0), bool warm_on = false) {
   constexpr bool kCompact = ColumnBank<T>::kCompact;   // the solver runs in slot space (see "slot space" below)
   constexpr int kRS = ColumnBank<T>::kRowStride;       // reals per row vector in s_rowvec
   using R = Real<T>;
@@ -573,6 +573,39 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     w = T(0);
     diag = T(0);
   }
+  // ---- warm start (SoloConfig::solver_warm_start, an OPT-IN of the residual-threshold kernels; warm_on is wave-uniform):
+  //      the iteration starts from f x the impulse this row ended the robot's previous step with, clamped to this step's
+  //      bounds (friction rows: mu x their contact's STARTING normal impulse).  The candidates then start at
+  //      v_s = lam0_s - (w_s + (A lam0)_s) / A_ss, and A lam0 comes through the whitened vectors exactly as the post-solve
+  //      phase applies impulses: Z = sum_r ghat_r lam0_r (six wave sums), Y = the same of hhat per leg, (A lam0)_s =
+  //      ghat_s . Z + hhat_s . Y - no column is touched, the Gauss-Seidel loops (assembly included) only see another
+  //      starting point.
+  T lam0 = T(0);
+  if constexpr (kResid) {
+    if (warm_on) {
+      if constexpr (sizeof(T) == 8) mu = s_keep[27];
+      const T imp0 = C.motor_impulse;
+      lam0 = live ? C.warm_factor * warm_in : T(0);
+      if (is_motor) lam0 = R::clamp(lam0, -imp0, imp0);
+      else if (type == ROW_NORMAL || is_limit) lam0 = R::max(lam0, T(0));
+      const T wn1 = wave_lane_below<1>(lam0), wn2 = wave_lane_below<2>(lam0);  // (lane = row here: a contact's rows share a 16-lane row)
+      if (type == ROW_TAN1 || type == ROW_TAN2) {
+        const T lim0 = mu * (type == ROW_TAN1 ? wn1 : wn2);
+        lam0 = R::clamp(lam0, -lim0, lim0);
+      }
+      if (!live) lam0 = T(0);
+      T zz[6], yy[2];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) zz[i] = gh[i] * lam0;
+      yy[0] = hh[0] * lam0;
+      yy[1] = hh[1] * lam0;
+      wave_reduce_rows(zz, yy);
+      T alam = hh[0] * yy[0] + hh[1] * yy[1];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) alam += gh[i] * zz[i];
+      w += alam;   // (dead rows: ghat = hhat = 0, so alam = 0 and w stays 0)
+    }
+  }
   const unsigned long long touching = wave_ballot(live && type == ROW_NORMAL);
   const unsigned long long limited = wave_ballot(live && is_limit);
   // ---- into SOLVER space.  What a lane holds while the Gauss-Seidel iteration runs: sv_type (ROW_IDLE: nothing),
@@ -587,7 +620,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   //    row vectors travel through LDS, where the column build needs them anyway; the per-lane scalars through the LDS
   //    crossbar (ds_permute: no memory).
   int sv_type = live ? type : (int)ROW_IDLE;
-  T sv_v0 = w * -inv_d, sv_nid = -inv_d, sv_diag = diag;  // (w = inv_d = 0 on a dead row)
+  T sv_v0 = w * -inv_d + lam0, sv_nid = -inv_d, sv_diag = diag;  // (w = inv_d = lam0 = 0 on a dead row)
+  T sv_lam0 = lam0;
   T sg[6], sh[2];
   int sv_leg = leg, n_live = 64;
   if constexpr (!kCompact) {
@@ -619,7 +653,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     const int tl = wave_push_int(sv_type | (leg << 4), dst);
     sv_v0 = wave_push(sv_v0, dst);
     sv_nid = wave_push(sv_nid, dst);
-    if constexpr (kResid) sv_diag = wave_push(sv_diag, dst);
+    if constexpr (kResid) { sv_diag = wave_push(sv_diag, dst); if (warm_on) sv_lam0 = wave_push(sv_lam0, dst); }
     sv_type = tl & 15;
     sv_leg = tl >> 4;
     wave_sync();
@@ -700,8 +734,18 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   T lo = T(0), hi = T(0);
   if (sv_motor) { lo = -imp; hi = imp; }
   else if (sv_normal || sv_limit) hi = R::big();
-  T lamv = T(0);
-  T v = sv_v0;  // lam = 0
+  T lamv = sv_lam0;   // (0 without a warm start)
+  T v = sv_v0;
+  if constexpr (kResid) {
+    if (warm_on) {  // the friction rows' bounds at the start: mu x the starting normal impulse of their contact
+      T n1, n2;
+      if constexpr (kCompact) { n1 = wave_slot_below<1>(lamv); n2 = wave_slot_below<2>(lamv); }
+      else { n1 = wave_lane_below<1>(lamv); n2 = wave_lane_below<2>(lamv); }
+      const T lim = mu * (is_tan1 ? n1 : n2);
+      lo = is_tangent ? -lim : lo;
+      hi = is_tangent ? lim : hi;
+    }
+  }
   const T tol_rel = T(wave_uniform(C.ulp_tol)) * R::half_ulp();
   const int iters = wave_uniform(C.iterations);  // scalar trip count
   // pybullet's solverResidualThreshold ([recalled] default 1e-7; SoloConfig::solver_residual_threshold): the iteration
@@ -768,9 +812,9 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   }
 #ifdef SOLO_STAMPS
   if (lane == 0) {
-    // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28
+    // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28 | row updates << 48
     const unsigned long long hw = (unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xfffff), xcc = (unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf);
-    B.stamps[(size_t)B.stamp_row * 32 + 15] = (unsigned long long)(it & 0xffff) | ((unsigned long long)__builtin_popcountll(touching) << 16) | (xcc << 24) | (hw << 28);
+    B.stamps[(size_t)B.stamp_row * 32 + 15] = (unsigned long long)(it & 0xffff) | ((unsigned long long)__builtin_popcountll(touching) << 16) | (xcc << 24) | (hw << 28) | ((unsigned long long)(n_changed & 0xffff) << 48);
     B.acc[15] += (unsigned long long)it;
     B.acc[0] += (unsigned long long)n_changed;
   }
@@ -1143,18 +1187,35 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       else wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = tv;
     }
 
+    // the warm-start cache (SoloConfig::solver_warm_start; residual-threshold kernels only): this lane's row's impulse at
+    // the end of the robot's previous step, fetched now and used when the rows are built
+    T* const warm_row = kResid ? wave_cold_args(Bin)->warm : nullptr;   // (wave-uniform; null = off)
+    T warm_in = T(0);
+    if constexpr (kResid) if (warm_row != nullptr && (B.flags & SOLO_STEP_PHYSICS)) {
+      if constexpr (kMigrate) warm_in = wave_load_shared(warm_row + (size_t)env * 64 + lane);
+      else warm_in = warm_row[(size_t)env * 64 + lane];
+    }
     SOLO_STAMP(B, 1);
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
       const T my_target = raw_target * target_scale;
       int row_at;  // where this lane's constraint row sits in s_rowvec / s_hext (its lane, or its slot: see physics_solve)
-      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, prio_sweeps, prio_steps, prio_rot);
+      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, prio_sweeps, prio_steps, prio_rot,
+                                             warm_in, kResid && warm_row != nullptr);
+      if constexpr (kResid) if (warm_row != nullptr) {
+        if constexpr (kMigrate) wave_store_shared(warm_row + (size_t)env * 64 + lane, lam);
+        else warm_row[(size_t)env * 64 + lane] = lam;
+      }
       physics_finish<T>(C, s_state, s_rowvec, s_hext, s_keep, s_leg, s_math, lam, lane, row_at);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted
       const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) || (motor_lane && !R::finite(my_target));
       diverged = wave_ballot(bad) != 0ull;
       if (diverged) {
+        if constexpr (kResid) if (warm_row != nullptr) {  // (a restored robot starts from zero impulses)
+          if constexpr (kMigrate) wave_store_shared(warm_row + (size_t)env * 64 + lane, T(0));
+          else warm_row[(size_t)env * 64 + lane] = T(0);
+        }
         if (lane < SOLO_S_RETURN) s_state[lane] = wave_cold_args(Bin)->snapshot[rec + lane];
         if (lane == 0) stats_add(&SOLO_STATS_ROW[5], 1.0);
         wave_sync();
@@ -1181,7 +1242,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       const T ev = T((done ? kEventDone : 0) | (restart ? kEventRestart : 0));
       const T word = s_state[lane & (SOLO_STATE_STRIDE - 1)];
       if (lane < SOLO_STATE_STRIDE)
-        B.traj[(unsigned)(env * B.steps + step) * (unsigned)SOLO_STATE_STRIDE + (unsigned)lane] = lane == SOLO_S_SPARE ? ev : word;
+        B.traj[(unsigned)((env - B.env_base) * B.steps + step) * (unsigned)SOLO_STATE_STRIDE + (unsigned)lane] = lane == SOLO_S_SPARE ? ev : word;
     }
     // closed-loop step() = a single-step launch: its outputs are evaluated right here with the
     // same per-item functions the output epilogue uses (no second launch on the critical path of a
@@ -1236,6 +1297,10 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
         wave_sync();  // the record above is read from the old state first
         if (lane < SOLO_S_RETURN) s_state[lane] = wave_cold_args(Bin)->snapshot[rec + lane];
         s_cnt[lane] = 0;
+        if constexpr (kResid) if (warm_row != nullptr) {  // (... and so does a robot that starts a new episode)
+          if constexpr (kMigrate) wave_store_shared(warm_row + (size_t)env * 64 + lane, T(0));
+          else warm_row[(size_t)env * 64 + lane] = T(0);
+        }
         // reset() leaves the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
         if (lane < SOLO_NUM_JOINTS) {
           if constexpr (kMigrate) wave_store_shared(wave_cold_args(Bin)->targets + (size_t)env * SOLO_NUM_JOINTS + lane, C.settle_tgt[lane]);
@@ -1271,7 +1336,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     static_assert(kPass >= 16 && sizeof(T) * 32 >= (size_t)kPass, "the output epilogue's scratch");
     T* const val = s_blk;                                            // [n_rops][kPass]: the row vectors' block (dead here)
     uint8_t* const ev_bytes = reinterpret_cast<uint8_t*>(s_keep);    // (the parked factors are dead too)
-    const T* const my_traj = B.traj + (size_t)env * (size_t)B.steps * SOLO_STATE_STRIDE;
+    const T* const my_traj = B.traj + (size_t)(env - B.env_base) * (size_t)B.steps * SOLO_STATE_STRIDE;
     const bool want_reward = (B.flags & SOLO_STEP_REWARD) != 0;
     const bool bookkeeping = want_reward && (B.flags & SOLO_STEP_DONE) != 0;
     T* const obs_rec = A->obs_rec; T* const reward_rec = A->reward_rec;
@@ -1365,7 +1430,7 @@ __global__ void solo_set_targets_kernel(const T* __restrict__ actions, T* __rest
 // resetSimulation + settle, as a masked snapshot restore (solo8v2vanilla.py:104-143)
 template <typename T>
 __global__ void solo_reset_kernel(const KParams<T>* __restrict__ P, T* __restrict__ state, const T* __restrict__ snapshot,
-                                  T* __restrict__ targets, int32_t* __restrict__ term_count,
+                                  T* __restrict__ targets, int32_t* __restrict__ term_count, T* __restrict__ warm,
                                   const uint8_t* __restrict__ mask, int num_envs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = i / SOLO_STATE_STRIDE, e = i % SOLO_STATE_STRIDE;
@@ -1373,6 +1438,7 @@ __global__ void solo_reset_kernel(const KParams<T>* __restrict__ P, T* __restric
   if (mask != nullptr && mask[env] == 0) return;
   state[i] = snapshot[i];
   if (e < SOLO_MAX_TERMS) term_count[env * SOLO_MAX_TERMS + e] = 0;
+  warm[(size_t)env * 64 + 2 * e] = warm[(size_t)env * 64 + 2 * e + 1] = T(0);  // (a reset robot starts from zero impulses)
   // the settle loop ends with the motors commanded to the settle pose (solo8v2vanilla.py:127-136)
   if (e < SOLO_NUM_JOINTS) targets[env * SOLO_NUM_JOINTS + e] = P->c.settle_tgt[e];
 }

@@ -127,6 +127,7 @@ class Engine:
     self.params = view(v.params, (n, 4), real)
     self.stats_shards = view(v.stats, (abi.STATS_SHARDS, abi.STATS_WIDTH), '<f8')
     self.cost = view(v.cost, (n,), '<i4')
+    self.warm = view(v.warm, (n, 64), real)   # the warm-start cache (SoloConfig.solver_warm_start); zeros while off
     self.obs_dim = v.obs_dim
     self._obs_ptr, self._real = v.obs, real
     self.obs = view(v.obs, (n, max(v.obs_dim, 1)), real) if v.obs_dim else None
@@ -265,7 +266,7 @@ class Engine:
 
   # ---- checkpoint / resume (the reference has none - reset() rebuilds the world; here the
   #      whole simulation is a handful of device tensors) --------------------------------------------------------
-  _CHECKPOINT = ('state', 'snapshot', 'targets', 'term_count', 'params', 'stats_shards', 'cost')
+  _CHECKPOINT = ('state', 'snapshot', 'targets', 'term_count', 'params', 'stats_shards', 'cost', 'warm')
 
   def get_state(self):
     """Everything a run continues from, as clones on the device: the robots' state records (episodic return / length
@@ -304,7 +305,7 @@ class Engine:
     """solo_engine_destroy: frees every device buffer.  Tensors handed out earlier dangle."""
     if getattr(self, '_h', None):
       for name in ('state', 'snapshot', 'targets', 'reward', 'done', 'done_bool', 'term_count', 'params',
-                   'stats_shards', 'obs', 'cost'):
+                   'stats_shards', 'obs', 'cost', 'warm'):
         setattr(self, name, None)
       self._finalizer()  # synchronises the device, then destroys the handle (runs at most once)
       self._h = None

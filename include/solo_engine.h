@@ -38,7 +38,7 @@ extern "C" {
 
 #define SOLO_ABI_VERSION 4  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets
                                3: SoloConfig::solver_residual_threshold
-                               4: SoloConfig::migrate_steps */
+                               4: SoloConfig::migrate_steps, SoloConfig::solver_warm_start, SoloStateView::warm */
 
 /* ---- fixed Solo8 dimensions -------------------------------------------- */
 #define SOLO_NUM_LEGS 4
@@ -152,6 +152,17 @@ typedef struct SoloConfig {
                                 the unluckiest SIMD's robots are.  Scheduling only: results are bit-identical.  0 = off
                                 (one wave steps one robot through the whole launch). */
   int32_t reserved0;         /* (padding; must be 0) */
+  double solver_warm_start;  /* f in (0, 1]: the Gauss-Seidel iteration of a step STARTS from f x the impulses the previous
+                                step ended with (every row: motors, joint limits, contacts - clamped to the row's bounds
+                                of this step, the friction rows to mu x their contact's starting normal impulse; a row
+                                that was not live in the previous step starts at 0; a reset / auto-reset / restored robot
+                                starts at 0).  [recalled] Bullet warm-starts its rigid-body contacts with
+                                m_warmstartingFactor 0.85; whether the btMultiBody path the reference runs on does is
+                                not known here.  An OPT-IN, and only together with solver_residual_threshold > 0 (the pair
+                                is what makes pybullet's early exit leave a resting robot at rest: DESIGN.md section 4).
+                                0 = off (every step starts from zero impulses).  The cache - SoloStateView::warm, 64 reals
+                                per robot, the step kernel's lane layout - costs 2 x 64 reals of memory traffic per
+                                env-step, reported separately from the path's algorithmic bytes. */
 } SoloConfig;
 
 /* ---- fused observation / reward / termination programs ------------------ */
@@ -243,6 +254,9 @@ typedef struct SoloStateView {
                            episodes, sum length, (unused), diverged robots restored, 2 spare */
   void* cost;           /* int32 [N]: Gauss-Seidel sweeps each robot ran in the LAST launch that stepped it
                            (its cost is persistent within an episode): input of solo_engine_set_order */
+  void* warm;           /* real  [N][64]: the impulses every robot's last step ended with, one per constraint row in the
+                           step kernel's lane layout (solo_kernel_params.h) - the warm-start cache of
+                           SoloConfig::solver_warm_start; all zero while that is off */
 } SoloStateView;
 
 typedef struct SoloEngine SoloEngine;

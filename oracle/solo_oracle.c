@@ -396,6 +396,8 @@ typedef struct {
   int normal_row[MAXROWS]; /* >=0: friction row limited by mu * lambda[normal_row] */
   int sphere[MAXROWS];
   int leg[MAXROWS];        /* non-contact rows: the leg they belong to (solve order), else -1 */
+  int key[MAXROWS];        /* the row's place in the 64-entry warm-start cache (SoloStateView::warm): the step kernel's
+                              lane layout - motor / limit of dof j: 16 (j / 2) + (j & 1) (+ 14), sphere s row q: 16 (s / 4) + 2 + 3 (s % 4) + q */
   double mu;
 } Rows;
 
@@ -454,7 +456,7 @@ static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const SoloTe
                 (1.0 - cfg->motor_kd) * ustar[6 + j];
     R->lo[r] = -cfg->motor_torque_limit * cfg->dt;
     R->hi[r] = cfg->motor_torque_limit * cfg->dt;
-    R->normal_row[r] = -1; R->sphere[r] = -1; R->leg[r] = j / 2;
+    R->normal_row[r] = -1; R->sphere[r] = -1; R->leg[r] = j / 2; R->key[r] = 16 * (j / 2) + (j & 1);
   }
   /* URDF joint limits ([recalled] btMultiBodyJointLimitConstraint; the reference's fixture pins
    * -10 / +10 rad, test_obs_observations.py:123-162 cols 8-9): a unilateral row on the nearer limit
@@ -470,6 +472,7 @@ static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const SoloTe
     R->J[r][6 + j] = s;
     R->rhs[r] = (c > 0) ? -c / cfg->dt : -cfg->contact_erp * c / cfg->dt;
     R->lo[r] = 0; R->hi[r] = INFINITY; R->normal_row[r] = -1; R->sphere[r] = -1; R->leg[r] = j / 2;
+    R->key[r] = 16 * (j / 2) + 14 + (j & 1);
   }
   /* sphere vs the tangent plane of the ground under its centre */
   for (int s = 0; s < mdl->num_spheres; ++s) {
@@ -491,11 +494,13 @@ static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const SoloTe
     /* non-penetration: v_n >= -dist/dt if separated (speculative), else push out with erp */
     R->rhs[rn] = (dist > 0) ? -dist / cfg->dt : -cfg->contact_erp * dist / cfg->dt;
     R->lo[rn] = 0; R->hi[rn] = INFINITY; R->normal_row[rn] = -1; R->sphere[rn] = s; R->leg[rn] = -1;
+    R->key[rn] = 16 * (s / 4) + 2 + 3 * (s % 4);
     const double* td[2] = {t1, t2};
     for (int q = 0; q < 2; ++q) {
       int rt = R->n++;
       point_jacobian(mdl, k, b, x, td[q], R->J[rt]);
       R->rhs[rt] = 0; R->lo[rt] = 0; R->hi[rt] = 0; R->normal_row[rt] = rn; R->sphere[rt] = s; R->leg[rt] = -1;
+      R->key[rt] = R->key[rn] + 1 + q;
     }
   }
 }
@@ -529,9 +534,11 @@ static void quat_integrate(double q[4], const double w[3], double dt) {
 
 /* One physics step of ONE robot.  st: SOLO_STATE_STRIDE doubles (in/out); targets: 8 dof
  * targets (radians); params: {friction, base-mass scale}.  dbg may be NULL. */
-int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, const SoloTerrain* terrain,
-                                 double* st, const double* targets, const double* params,
-                                 SoloOracleDebug* dbg) {
+/* warm: the robot's 64-entry warm-start cache (SoloConfig::solver_warm_start; in / out), or NULL = every step starts
+ * from zero impulses */
+int solo_oracle_step_env_warm(const SoloConfig* cfg, const SoloModel* mdl, const SoloTerrain* terrain,
+                              double* st, const double* targets, const double* params, double* warm,
+                              SoloOracleDebug* dbg) {
   static _Thread_local Kin k;
   static _Thread_local Rows R;
   double M[NV * NV], L[NV * NV], h[NV], u[NV], udot[NV], ustar[NV];
@@ -561,6 +568,22 @@ int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, co
     diag[r] = d; lam[r] = 0;
   }
   memcpy(up, ustar, sizeof up);
+  /* warm start (SoloConfig::solver_warm_start = f > 0, an opt-in): the iteration starts from f x the impulses the
+   * previous step ended with, clamped to this step's bounds - the friction rows to mu x their contact's STARTING normal
+   * impulse; rows that were not live in the previous step find 0 in the cache */
+  if (warm != NULL && cfg->solver_warm_start > 0) {
+    for (int pass = 0; pass < 2; ++pass)            /* normal (and non-contact) rows first: the friction bounds need them */
+      for (int r = 0; r < R.n; ++r) {
+        if ((R.normal_row[r] >= 0) != (pass == 1)) continue;
+        double lo = R.lo[r], hi = R.hi[r];
+        if (R.normal_row[r] >= 0) { hi = R.mu * lam[R.normal_row[r]]; lo = -hi; }
+        double l0 = cfg->solver_warm_start * warm[R.key[r]];
+        if (l0 < lo) l0 = lo;
+        if (l0 > hi) l0 = hi;
+        lam[r] = l0;
+        for (int i = 0; i < NV; ++i) up[i] += B[r][i] * l0;
+      }
+  }
   /* row order of one iteration, [recalled] btMultiBodyConstraintSolver::solveSingleIteration: the
    * non-contact rows (joint motors), then ALL normal contact rows, then ALL friction rows - each
    * friction row limited by mu x the normal impulse its contact holds at that moment */
@@ -592,6 +615,10 @@ int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, co
     }
     if (cfg->solver_residual_threshold > 0 && residual <= cfg->solver_residual_threshold) break;  /* (0 = off) */
   }
+  if (warm != NULL) {
+    for (int i = 0; i < 64; ++i) warm[i] = 0;
+    for (int r = 0; r < R.n; ++r) warm[R.key[r]] = lam[r];
+  }
   /* back to world-frame velocities, integrate positions (semi-implicit Euler) */
   double ww[3], vw[3];
   m3v(k.Rwb[0], up, ww);
@@ -617,6 +644,12 @@ int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, co
     }
   }
   return 0;
+}
+
+int solo_oracle_step_env_terrain(const SoloConfig* cfg, const SoloModel* mdl, const SoloTerrain* terrain,
+                                 double* st, const double* targets, const double* params,
+                                 SoloOracleDebug* dbg) {
+  return solo_oracle_step_env_warm(cfg, mdl, terrain, st, targets, params, NULL, dbg);
 }
 
 int solo_oracle_step_env(const SoloConfig* cfg, const SoloModel* mdl, double* st,
@@ -682,20 +715,26 @@ void solo_oracle_momentum(const SoloModel* mdl, const double* st, double mass_sc
 
 /* Batched stepping for the cpu_baseline leg and batch parity: st [N][32], actions [N][12]
  * in pybullet joint order (scaled by cfg->action_scale), params [N][4].  OpenMP over envs. */
-int solo_oracle_step_batch_terrain(const SoloConfig* cfg, const SoloModel* mdl, const SoloTerrain* terrain,
-                                   int32_t n, double* st, const double* actions, const double* params,
-                                   int32_t nthreads) {
+int solo_oracle_step_batch_warm(const SoloConfig* cfg, const SoloModel* mdl, const SoloTerrain* terrain,
+                                int32_t n, double* st, const double* actions, const double* params,
+                                double* warm /* [n][64] or NULL */, int32_t nthreads) {
   int fail = 0;
 #pragma omp parallel for num_threads(nthreads) schedule(static) reduction(| : fail)
   for (int e = 0; e < n; ++e) {
     double tg[ND];
     for (int j = 0; j < ND; ++j)
       tg[j] = actions[(size_t)e * SOLO_NUM_JOINTS + mdl->dof_to_joint[j]] * cfg->action_scale;
-    if (solo_oracle_step_env_terrain(cfg, mdl, terrain, st + (size_t)e * SOLO_STATE_STRIDE, tg,
-                                     params + (size_t)e * 4, NULL))
+    if (solo_oracle_step_env_warm(cfg, mdl, terrain, st + (size_t)e * SOLO_STATE_STRIDE, tg,
+                                  params + (size_t)e * 4, warm ? warm + (size_t)e * 64 : NULL, NULL))
       fail = 1;
   }
   return fail ? -1 : 0;
+}
+
+int solo_oracle_step_batch_terrain(const SoloConfig* cfg, const SoloModel* mdl, const SoloTerrain* terrain,
+                                   int32_t n, double* st, const double* actions, const double* params,
+                                   int32_t nthreads) {
+  return solo_oracle_step_batch_warm(cfg, mdl, terrain, n, st, actions, params, NULL, nthreads);
 }
 
 int solo_oracle_step_batch(const SoloConfig* cfg, const SoloModel* mdl, int32_t n, double* st,

@@ -48,7 +48,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
                double* state, const double* snapshot, const double* actions, double* targets,
                const double* params, double* obs, double* reward, uint8_t* done,
                int32_t* term_count, double* stats, uint32_t flags, int steps = 1,
-               const SoloTerrain* terrain = nullptr) {
+               const SoloTerrain* terrain = nullptr, double* warm = nullptr) {
   std::string err;
   if (int rc = validate_model(*mdl, &err)) { fprintf(stderr, "emu: %s\n", err.c_str()); return rc; }
   static KParams<T> P;
@@ -69,6 +69,8 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   std::vector<T> act;
   if (actions) act = conv(actions, (size_t)steps * n * SOLO_NUM_JOINTS);
   std::vector<T> par = conv(params, (size_t)n * 4);
+  std::vector<T> wrm;   // the warm-start cache (SoloConfig::solver_warm_start), as Engine::buffers passes it
+  if (warm != nullptr && cfg->solver_warm_start > 0) wrm = conv(warm, (size_t)n * 64);
   std::vector<T> ob((size_t)steps * n * (D > 0 ? D : 1)), rew((size_t)steps * n);
   std::vector<T> traj((size_t)steps * n * SOLO_STATE_STRIDE);
   std::vector<T> terr;
@@ -102,6 +104,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   // through the queue; the emulated waves run one after the other, so the first drains every ring it can reach
   std::vector<int32_t> queue;
   B.queue = nullptr; B.q_rings = 1; B.q_chunk = 0;
+  B.warm = wrm.empty() ? nullptr : wrm.data();
   if (cfg->migrate_steps > 0 && steps > cfg->migrate_steps && (flags & SOLO_STEP_PHYSICS)) {
     B.q_chunk = migration_chunk_steps(steps, cfg->migrate_steps);
     B.q_rings = n == 16 ? 8 : migration_rings(n);  // (16 robots: eight rings of two, so that the CPU suite walks several rings too)
@@ -122,6 +125,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
     });
   for (size_t i = 0; i < st.size(); ++i) state[i] = (double)st[i];
   for (size_t i = 0; i < tg.size(); ++i) targets[i] = (double)tg[i];
+  for (size_t i = 0; i < wrm.size(); ++i) warm[i] = (double)wrm[i];
   if (flags & SOLO_STEP_OBS) for (size_t i = 0; i < (size_t)steps * n * D; ++i) obs[i] = (double)ob[i];
   if (flags & SOLO_STEP_REWARD) for (size_t i = 0; i < (size_t)steps * n; ++i) reward[i] = (double)rew[i];
   return 0;
@@ -131,12 +135,12 @@ extern "C" int solo_emu_step(const SoloConfig* cfg, const SoloModel* mdl, const 
                              int dtype, int n, double* state, const double* snapshot,
                              const double* actions, double* targets, const double* params,
                              double* obs, double* reward, uint8_t* done, int32_t* term_count,
-                             double* stats, uint32_t flags, const SoloTerrain* terrain) {
+                             double* stats, uint32_t flags, const SoloTerrain* terrain, double* warm) {
   if (dtype == SOLO_F32)
     return run<float>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
-                      done, term_count, stats, flags, 1, terrain);
+                      done, term_count, stats, flags, 1, terrain, warm);
   return run<double>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
-                     done, term_count, stats, flags, 1, terrain);
+                     done, term_count, stats, flags, 1, terrain, warm);
 }
 
 // fused multi-step launch: actions [steps][n][12]; obs [steps][n][D], reward [steps][n], done [steps][n]
@@ -144,10 +148,10 @@ extern "C" int solo_emu_rollout(const SoloConfig* cfg, const SoloModel* mdl, con
                                 int dtype, int n, int steps, double* state, const double* snapshot,
                                 const double* actions, double* targets, const double* params,
                                 double* obs, double* reward, uint8_t* done, int32_t* term_count,
-                                double* stats, uint32_t flags, const SoloTerrain* terrain) {
+                                double* stats, uint32_t flags, const SoloTerrain* terrain, double* warm) {
   if (dtype == SOLO_F32)
     return run<float>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
-                      done, term_count, stats, flags, steps, terrain);
+                      done, term_count, stats, flags, steps, terrain, warm);
   return run<double>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
-                     done, term_count, stats, flags, steps, terrain);
+                     done, term_count, stats, flags, steps, terrain, warm);
 }

@@ -24,11 +24,11 @@ def load(variant=''):
   lib.solo_emu_step.restype = C.c_int
   lib.solo_emu_step.argtypes = [C.POINTER(abi.SoloConfig), C.POINTER(abi.SoloModel), C.c_void_p,
                                 C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_void_p,
-                                C.c_void_p, dp, C.c_uint32, C.c_void_p]
+                                C.c_void_p, dp, C.c_uint32, C.c_void_p, dp]
   lib.solo_emu_rollout.restype = C.c_int
   lib.solo_emu_rollout.argtypes = [C.POINTER(abi.SoloConfig), C.POINTER(abi.SoloModel), C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_void_p,
-                                   C.c_void_p, dp, C.c_uint32, C.c_void_p]
+                                   C.c_void_p, dp, C.c_uint32, C.c_void_p, dp]
   lib.solo_emu_last_cost.restype = C.c_int
   lib.solo_emu_last_cost.argtypes = [C.c_void_p, C.c_int]
   return lib
@@ -61,6 +61,7 @@ class EmuEngine:
     self.done = np.zeros(n, dtype=np.uint8)
     self.term_count = np.zeros((n, abi.MAX_TERMS), dtype=np.int32)
     self.stats = np.zeros((abi.STATS_SHARDS, abi.STATS_WIDTH))
+    self.warm = np.zeros((n, 64))   # the warm-start cache (SoloConfig.solver_warm_start)
 
   def step(self, actions=None, flags=abi.STEP_ALL):
     if self.program is None:
@@ -76,7 +77,7 @@ class EmuEngine:
       self.cfg.dtype, self.n, _dp(self.state), _dp(self.snapshot),
       _dp(a) if a is not None else None, _dp(self.targets), _dp(self.params), _dp(self.obs),
       _dp(self.reward), self.done.ctypes.data, self.term_count.ctypes.data, _dp(self.stats), flags,
-      C.byref(self.terrain) if getattr(self, 'terrain', None) is not None else None)
+      C.byref(self.terrain) if getattr(self, 'terrain', None) is not None else None, _dp(self.warm))
     if rc:
       raise RuntimeError('emu step failed: %d' % rc)
 
@@ -100,7 +101,7 @@ class EmuEngine:
       C.cast(C.pointer(self.program), C.c_void_p) if self.program is not None else None,
       self.cfg.dtype, self.n, k, _dp(self.state), _dp(self.snapshot), _dp(a), _dp(self.targets),
       _dp(self.params), _dp(obs), _dp(rew), done.ctypes.data, self.term_count.ctypes.data,
-      _dp(self.stats), flags, C.byref(self.terrain) if getattr(self, 'terrain', None) is not None else None)
+      _dp(self.stats), flags, C.byref(self.terrain) if getattr(self, 'terrain', None) is not None else None, _dp(self.warm))
     if rc:
       raise RuntimeError('emu rollout failed: %d' % rc)
     return obs, rew, done
@@ -110,9 +111,11 @@ class EmuEngine:
     self.state[:] = 0
     self.state[:, abi.S_POS:abi.S_POS + 3] = list(self.cfg.start_pos)
     self.state[:, abi.S_QUAT:abi.S_QUAT + 4] = list(self.cfg.start_quat)
+    self.warm[:] = 0
     for _ in range(self.cfg.settle_steps):
       self.step(tg, abi.STEP_PHYSICS)
     self.snapshot[:] = self.state
+    self.warm[:] = 0   # (the snapshot starts from an empty warm-start cache, as Engine<T>::settle leaves it)
 
 
 class EmuTorchEngine:
@@ -220,6 +223,7 @@ class EmuTorchEngine:
     m = slice(None) if mask is None else mask.detach().cpu().numpy().astype(bool)
     e.state[m] = e.snapshot[m]
     e.term_count[m] = 0
+    e.warm[m] = 0
     e.targets[m] = self._settle_targets(self.cfg)
 
   def settle(self):

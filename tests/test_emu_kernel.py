@@ -292,6 +292,65 @@ def test_residual_threshold_exit_matches_oracle(dtype, tol):
   assert np.abs(out[1e-7][0][:, :29] - out[0.0][0][:, :29]).max() < 5e-2   # ... for a nearby result
 
 
+@pytest.mark.parametrize('dtype,tol', [('float64', 1e-10), ('float32', 2e-3)])
+@pytest.mark.parametrize('factor', [1.0, 0.85])
+def test_warm_start_matches_oracle(dtype, tol, factor):
+  """SoloConfig.solver_warm_start (an opt-in of the residual-threshold solver): every step's iteration starts from
+  factor x the impulses the previous step ended with, clamped to the new bounds - emulated kernel == oracle (whose
+  dense Gauss-Seidel starts from the same point) over contact-rich random steps with the cache carried from step to
+  step; the cache itself agrees; fewer sweeps than the cold start; a reset empties the cache."""
+  n = 5
+  rng = np.random.default_rng(21)
+  acts = [random_actions(rng, n, scale=1.5) for _ in range(14)]
+  sweeps = {}
+  for warm in (0.0, factor):
+    ca, ma = make_abi(dtype, solver_residual_threshold=1e-7, solver_warm_start=warm, settle_steps=450)
+    ph = so.OraclePhysics(ca, ma)
+    st = ph.settle(n)    # (on the ground, folded: every knee and foot in contact)
+    cache = np.zeros((n, 64))
+    e = EmuEngine(ca, ma, n)
+    e.state[:] = st
+    total = 0
+    for a in acts:
+      ph.step(st, a, warm=cache if warm else None)
+      e.step(a, abi.STEP_PHYSICS)
+      total += int(e.cost.sum())
+      np.testing.assert_allclose(e.state[:, :29], st[:, :29], rtol=0, atol=tol)
+      if warm and dtype == 'float64':
+        np.testing.assert_allclose(e.warm, cache, rtol=0, atol=1e-9)
+    sweeps[warm] = total
+    if warm:
+      assert np.abs(e.warm).max() > 0
+  assert sweeps[factor] < sweeps[0.0]
+  with pytest.raises(ValueError):
+    make_abi(dtype, solver_warm_start=1.0)          # needs the residual threshold
+  with pytest.raises(ValueError):
+    make_abi(dtype, solver_residual_threshold=1e-7, solver_warm_start=1.5)
+
+
+def test_warm_start_does_not_rescue_the_residual_threshold_at_rest():
+  """The objection to pybullet's residual threshold as the default (core/configs.py) is a resting robot: the reference's
+  one recorded state rests at 1e-11 rad/s.  Measured on the f64 oracle (tools/rest_drift_probe.py,
+  profiles/round4_rest_drift.log), a robot standing under zero targets for 3000 steps: iterated to the fixed point its
+  joint rates fall to 5e-9 (and keep falling); with the threshold 1e-7 they stay at 8e-7 cold, 5e-7 with a warm start
+  of 0.85 - and GROW to 1.6e-4 with a warm start of 1.0, which carries the accepted residual from step to step.  The
+  warm start speeds the threshold solver up; it does not make it rest: the default stays the fixed-point iteration."""
+  base = so.OraclePhysics(*make_abi('float64')).settle(1)
+  rate = {}
+  for thr, warm in ((1e-20, 0.0), (1e-7, 0.0), (1e-7, 0.85), (1e-7, 1.0)):
+    ca, ma = make_abi('float64', solver_residual_threshold=thr, solver_warm_start=warm)
+    ph = so.OraclePhysics(ca, ma)
+    st, cache, zero = base.copy(), np.zeros((1, 64)), np.zeros((1, 12))
+    for k in range(3000):
+      ph.step(st, zero, warm=cache if warm else None)
+    rate[(thr, warm)] = np.abs(st[0, abi.S_QD:abi.S_QD + 8]).max()
+    assert 0.33 < st[0, 2] < 0.34
+  assert rate[(1e-20, 0.0)] < 2e-8
+  assert rate[(1e-7, 0.0)] > 10 * rate[(1e-20, 0.0)]
+  assert rate[(1e-7, 0.85)] > 10 * rate[(1e-20, 0.0)]
+  assert rate[(1e-7, 1.0)] > 10 * rate[(1e-7, 0.0)]
+
+
 def test_workgroup_to_robot_map_is_a_bijection_with_contiguous_ranges_per_xcd():
   """xcd_contiguous (solo_kernel_params.h): workgroups b, b + 8, b + 16 ... - the ones that share an XCD - step a
   contiguous range of robots, and every robot of the launch is stepped exactly once, for any launch size."""

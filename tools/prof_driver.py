@@ -9,7 +9,11 @@ from bench import build_env, desynchronise_episodes
 from gym_solo_amd import abi
 dtype = os.environ.get('DTYPE', 'float32'); n = int(os.environ.get('N', '4096'))
 spl, streams, steps = int(os.environ.get('SPL', '250')), int(os.environ.get('STREAMS', '2')), int(os.environ.get('STEPS', '2000'))
-env = build_env(n, 0, dtype, steps_per_launch=spl, rollout_streams=streams)
+# robot migration as bench.py chooses it (-1 = its rule: half the launch for a single-launch f64 rollout, else off)
+migrate = int(os.environ.get('MIGRATE', '-1'))
+if migrate < 0:
+  migrate = (min(spl, steps) + 1) // 2 if (dtype == 'float64' and steps <= spl and spl >= 8) else 0
+env = build_env(n, 0, dtype, steps_per_launch=spl, rollout_streams=streams, migrate_steps=migrate)
 eng = env.engine
 tdt = torch.float32 if dtype == 'float32' else torch.float64
 g = torch.Generator(device='cuda').manual_seed(1234)
@@ -20,7 +24,7 @@ for _ in range(int(os.environ.get('REPEATS', '1'))):   # (short geometries: seve
   eng.rollout(acts, abi.STEP_ALL, out=out)
 torch.cuda.synchronize()
 meta = {'robots_per_launch': n // streams if streams > 1 else n, 'steps_per_launch': min(spl, steps), 'steps': steps, 'dtype': dtype,
-        'launch_chains': streams if steps > spl else 1}
+        'launch_chains': streams if steps > spl else 1, 'migrate_steps': migrate}
 if len(sys.argv) > 1:
   json.dump(meta, open(sys.argv[1], 'w'))
 print('done', eng.kernel_name, meta)

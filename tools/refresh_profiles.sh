@@ -3,8 +3,8 @@
 #   gpurun --timeout 1150 -- bash tools/refresh_profiles.sh round3_a f32 f32_k20
 #   gpurun --timeout 1150 -- bash tools/refresh_profiles.sh round3_a f64 f64_k20
 # One CONFIG = a dtype and a launch geometry of the bench workload:
-#   f32 / f64          python bench.py [--dtype float64]: K = 3000 steps, 250 per launch, two stream slices
-#   f32_k20 / f64_k20  the driver's command, python bench.py --gpus 1 --steps 20 --warmup 5: ONE 4096 x 20 launch
+#   f32 / f64          python bench.py --dtype ...: K = 3000 steps, 250 per launch, two stream slices
+#   f32_k20 / f64_k20  the driver's command, python bench.py --gpus 1 --steps 20 --warmup 5 (f64 is its default precision): ONE 4096 x 20 launch
 # Per config: the bench line, a rocprofv3 --kernel-trace --stats summary of the SAME command (the step kernel's
 # average duration must agree with the line's roofline.kernel_ms) and the PMC passes (separate runs of
 # tools/prof_driver.py on the same geometry).  Writes under gpurun_out/<tag>/; copy the summaries into
@@ -19,15 +19,15 @@ mkdir -p $O
 cd $R
 for CFG in $CONFIGS; do
   case $CFG in
-    f32)     DT=float32; BARGS="";                                  PENV="SPL=250 STREAMS=2 STEPS=2000 REPEATS=1";;
-    f32_k20) DT=float32; BARGS="--gpus 1 --steps 20 --warmup 5";    PENV="SPL=20 STREAMS=1 STEPS=20 REPEATS=40";;
+    f32)     DT=float32; BARGS="--dtype float32";                                  PENV="SPL=250 STREAMS=2 STEPS=2000 REPEATS=1";;
+    f32_k20) DT=float32; BARGS="--dtype float32 --gpus 1 --steps 20 --warmup 5";    PENV="SPL=20 STREAMS=1 STEPS=20 REPEATS=40";;
     f64)     DT=float64; BARGS="--dtype float64";                   PENV="SPL=250 STREAMS=2 STEPS=1000 REPEATS=1";;
     f64_k20) DT=float64; BARGS="--dtype float64 --gpus 1 --steps 20 --warmup 5"; PENV="SPL=20 STREAMS=1 STEPS=20 REPEATS=40";;
     *) echo "unknown config $CFG"; exit 2;;
   esac
   cd $R
   # the bench line (the CPU baseline only once: it is the same sample in every line)
-  if [ $CFG = f32 ] || [ $CFG = f32_k20 ]; then EXTRA=""; else EXTRA="--no-cpu-baseline"; fi
+  if [ $CFG = f64 ] || [ $CFG = f64_k20 ]; then EXTRA=""; else EXTRA="--no-cpu-baseline"; fi
   python bench.py $BARGS $EXTRA > $O/bench_$CFG.jsonl 2> $O/bench_$CFG.err
   echo "$CFG bench done"
   cd /tmp && export TMPDIR=/tmp
