@@ -926,7 +926,7 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
 // 13.0 KB of LDS: twelve workgroups per CU; round 3: 2, with 128 VGPRs of columns).
 // kFull = false: physics-only instantiation (flags are treated as SOLO_STEP_PHYSICS).
 // single-step launches evaluate their outputs in the step kernel itself (see the step loop): f32 only
-template <typename T, bool kFull> constexpr bool kInlineOutputs = kFull && sizeof(T) == 4;
+template <typename T, bool kFull> constexpr bool kInlineOutputs = kFull;
 #ifndef SOLO_F64_WAVES
 #define SOLO_F64_WAVES 3   // (-DSOLO_F64_WAVES=2: the A/B build of tools/gpu_occupancy_sweep.py, never the product)
 #endif

@@ -508,9 +508,14 @@ template <> struct Real<double> {
     cp = __builtin_fma(x2, cp, -0.5);
     *c = __builtin_fma(x2, cp, 1.0);
   }
-  static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
-  static __device__ __forceinline__ double asin(double x) { return ::asin(x); }
-  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  // The library atan2 / asin / exp (the Euler angles and the gaussian tolerance of the OUTPUT EPILOGUE only: once per
+  // pass of <= 32 steps) are real CALLS: inlined, their ~40 f64 constants - register pairs, VOP3 takes no f64 literal -
+  // were hoisted in front of the step / task loops and spilled there (48 SGPR spills in every f64 kernel; 42 scratch
+  // stores per lane at the top of a migrating kernel: 24 KB per wave, 1190 B of HBM writes per env-step of a 20-step
+  // launch, measured).  Behind a call the constants live and die inside the callee.
+  static __device__ __attribute__((noinline)) double atan2(double y, double x) { return ::atan2(y, x); }
+  static __device__ __attribute__((noinline)) double asin(double x) { return ::asin(x); }
+  static __device__ __attribute__((noinline)) double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
   static __device__ __forceinline__ double min(double a, double b) { return ::fmin(a, b); }
   static __device__ __forceinline__ double max(double a, double b) { return ::fmax(a, b); }
