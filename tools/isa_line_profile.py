@@ -19,7 +19,7 @@ for l in lines:
   if s.startswith('.file') and len(s.split()) >= 3 and s.split()[1].isdigit():
     parts = s.split('"')
     files[int(s.split()[1])] = os.path.basename(parts[-2])
-start = [i for i, l in enumerate(lines) if l.startswith('_ZN4solo16solo_step_kernelI%sLb1ELb0EE' % t)][0]
+start = [i for i, l in enumerate(lines) if l.startswith('_ZN4solo16solo_step_kernelI%sLb1ELb0ELb0EE' % t)][0]
 fe = [i for i, l in enumerate(lines[start:]) if l.startswith('.Lfunc_end')][0] + start
 acc = collections.defaultdict(lambda: [0, 0, 0])
 loc = ('?', 0)
