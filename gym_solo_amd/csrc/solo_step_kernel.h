@@ -983,6 +983,8 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   int env = 0, step_begin = 0, step_end = B.steps;
   bool last_chunk = true;   // this task ends the robot's launch: output epilogue, final bookkeeping
   int q_ring = 0, q_rings_left = 0, q_sweeps = 0, q_chunk_at = 0;
+  int next_ticket = 0;      // the next task's ticket, taken with the publication of the previous one (see the end of the task loop)
+  bool have_next = false;
   if constexpr (!kMigrate) env = order != nullptr ? wave_uniform(order[slot]) : B.env_base + xcd_contiguous(block_id(), B.count);
   else {
     // home ring: one of the rings of this wave's XCD (q_rings = 8 x rings per XCD, or 1)
@@ -1055,11 +1057,13 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     // empty rings ends it
     const int chunks = migration_chunks(B.steps, B.q_chunk), per_ring = B.count / B.q_rings, ring_len = per_ring * chunks;
     int32_t* const ring_slots = queue + kQueueHeader + (size_t)B.count;
-    // (a ticket is taken when the wave is FREE, never ahead: a ticket reserved while the wave still works is matched
-    // with a robot in reservation order, not in the order waves become free, and waves then wait for "their" robot while
-    // others are ready - measured: slower at every chunk length)
+    // (a ticket is taken when the wave is FREE - at the earliest together with the publication of its previous task,
+    // below -, never while it still works: a ticket reserved during the last step of a task is matched with a robot in
+    // reservation order, not in the order waves become free, and waves then wait for "their" robot while others are
+    // ready - measured: slower at every chunk length)
     int ticket = ring_len;
     bool tried = false;
+    if (have_next) { ticket = next_ticket; tried = true; have_next = false; }
     for (;;) {
       if (ticket < ring_len) break;
       if (tried) { if (--q_rings_left <= 0) break; q_ring = q_ring + 1 == B.q_rings ? 0 : q_ring + 1; }
@@ -1398,16 +1402,26 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   wave_sync();
   if (lane1 < 16) B.stamps[(size_t)env * 32 + 16 + lane1] = s_acc[lane1];
 #endif
-  if constexpr (kMigrate) if (!last_chunk) {
-    // hand the robot on: its progress, then - when the device-coherent stores of its record and counters above have
-    // completed - its number into the next free slot of its ring (whoever holds that slot's ticket continues it)
+  if constexpr (kMigrate) {
+    // hand the robot on (unless this was its last chunk): its history, then - when the device-coherent stores of its
+    // record and counters above have completed - its number and next chunk into the next free slot of its ring (whoever
+    // holds that slot's ticket continues it).  The slot's index and the wave's OWN next ticket are two independent
+    // read-modify-writes: both are issued here, in front of the one wait that the stores need anyway - a hand-over is
+    // a chain of device-scope round trips (~1.8 us each under load), and this takes two of the five off it.
     const int chunks = migration_chunks(B.steps, B.q_chunk), ring_len = (B.count / B.q_rings) * chunks;
-    if (lane1 == 0) wave_atomic_store(queue + kQueueHeader + (env - B.env_base), prio_sweeps);
-    wave_release_device();
+    int at = 0, nt = 0;
     if (lane1 == 0) {
-      const int at = wave_atomic_add(queue + q_ring * 32 + 16, 1);
-      wave_atomic_store(queue + kQueueHeader + (size_t)B.count + (size_t)q_ring * ring_len + at, (env - B.env_base) | ((q_chunk_at + 1) << 24));
+      if (!last_chunk) {
+        wave_atomic_store(queue + kQueueHeader + (env - B.env_base), prio_sweeps);
+        at = wave_atomic_add(queue + q_ring * 32 + 16, 1);
+      }
+      nt = wave_atomic_add(queue + q_ring * 32, 1);
     }
+    wave_release_device();
+    if (!last_chunk && lane1 == 0)
+      wave_atomic_store(queue + kQueueHeader + (size_t)B.count + (size_t)q_ring * ring_len + at, (env - B.env_base) | ((q_chunk_at + 1) << 24));
+    next_ticket = wave_readlane_int(nt, 0);
+    have_next = true;
   }
   if constexpr (kMigrate) wave_sync();  // (the next task's prologue rewrites the LDS record)
   } while (kMigrate);  // the task loop

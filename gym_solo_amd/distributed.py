@@ -27,7 +27,7 @@ def shard_sizes(total_envs: int, world: int):
 
 
 def all_reduce_stats(stats, group=None, in_place=False):
-  """Sum the per-rank statistics [sum return, sum return^2, episodes, sum length, -, diverged, -, -]
+  """Sum the per-rank statistics [sum return, sum return^2, episodes, sum length, -, diverged, migration waits given up, -]
   over all ranks.  Returns a new tensor (or `stats` itself with in_place=True); a no-op without an
   initialised process group."""
   import torch.distributed as dist
@@ -42,8 +42,9 @@ def summarize(stats) -> dict:
   n = s[2]
   if n <= 0:
     return {'episodes': 0.0, 'mean_return': None, 'std_return': None, 'mean_length': None,
-            'diverged': s[5]}
+            'diverged': s[5], 'migration_waits_given_up': s[6]}
   mean = s[0] / n
   var = max(0.0, s[1] / n - mean * mean)
+  # (slot 6: waves of a migrating launch that gave up waiting for a ring slot - a launch must never hang on a bug; always 0)
   return {'episodes': n, 'mean_return': mean, 'std_return': math.sqrt(var),
-          'mean_length': s[3] / n, 'diverged': s[5]}
+          'mean_length': s[3] / n, 'diverged': s[5], 'migration_waits_given_up': s[6]}

@@ -13,7 +13,8 @@ dtype = sys.argv[1] if len(sys.argv) > 1 else 'float64'
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 n = 4096
 tdt = torch.float32 if dtype == 'float32' else torch.float64
-env = build_env(n, 0, dtype, steps_per_launch=k, rollout_streams=1)
+env = build_env(n, 0, dtype, steps_per_launch=k, rollout_streams=1, migrate_steps=int(os.environ.get('MIGRATE', '0')))
+print('migrate_steps', os.environ.get('MIGRATE', '0'))
 eng = env.engine
 g = torch.Generator(device='cuda').manual_seed(1234)
 desynchronise_episodes(eng, g)
