@@ -399,12 +399,20 @@ def main():
     spl = 1 if closed_loop else max(1, min(args.steps_per_launch, k))
     streams = max(1, args.rollout_streams) if (k > spl and not closed_loop) else 1
     # robot migration inside a launch (SoloConfig.migrate_steps: scheduling only, results bit-identical): where it pays -
-    # f64 (4096 robots on 3072 wave slots) when the rollout is ONE launch, so that no other launch overlaps its tail
-    # (measured, tools/gpu_migrate_sweep.py + gpu_occupancy_sweep.py: K = 20 in two chunks +14 %; 250-step launches on
-    # two stream slices -5 ... -15 %; f32 - every robot resident from the first cycle - -5 %)
+    # f64 (4096 robots on 3072 wave slots): a single launch in two chunks, longer rollouts as one chain of launches in
+    # chunks of 25 steps
+    # (measured, tools/gpu_migrate_sweep.py + gpu_occupancy_sweep.py, profiles/round4_ab.log: K = 20 in two chunks +14 %;
+    # 250-step launches in chunks of 25 on one chain +10 % over two stream slices; f32 - every robot resident from the
+    # first cycle - -5 %)
     migrate = args.migrate_steps
     if migrate < 0:
-      migrate = (spl + 1) // 2 if (dtype == 'float64' and not closed_loop and spl >= 8 and k == spl) else 0
+      migrate = 0
+      if dtype == 'float64' and not closed_loop and spl >= 8:
+        if k == spl:
+          migrate = (spl + 1) // 2      # one launch: two chunks
+        elif spl >= 50:
+          migrate, streams = 25, 1      # several launches: ONE chain of migrating launches beats two stream slices
+                                        # (tools/gpu_migrate_sweep.py: 1.63e8 against 1.47e8; f32: the slices stay, 3.75e8 against 3.5e8)
     env = build_env(n, local_rank, dtype, steps_per_launch=spl, rollout_streams=streams, residual_threshold=residual_threshold,
                     migrate_steps=migrate, warm_start=warm_start)
     eng = env.engine

@@ -146,6 +146,14 @@ class Engine:
       raise ValueError('{} must be contiguous'.format(name))
     return C.c_void_p(t.data_ptr())
 
+  def _as_real(self, t):
+    """Actions / per-robot parameters in another floating precision than the engine's are converted here (one cast
+    kernel on the caller's stream); the C-ABI itself takes the engine's precision only."""
+    torch = self._torch
+    if isinstance(t, torch.Tensor) and t.is_floating_point() and t.dtype != self.tdtype:
+      return t.to(self.tdtype)
+    return t
+
   # ---- C-ABI calls -----------------------------------------------------------------------
   def set_program(self, program: abi.SoloProgram):
     self._check(self.lib.solo_engine_set_program(self._handle(), C.byref(program)), 'set_program')
@@ -162,12 +170,14 @@ class Engine:
     self._check(self.lib.solo_engine_settle(self._handle(), self._stream()), 'settle')
 
   def set_targets(self, actions):
+    actions = self._as_real(actions)
     p = self._dev_ptr(actions, (self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
     self._check(self.lib.solo_engine_set_targets(self._handle(), p, self._stream()), 'set_targets')
 
   def step(self, actions=None, flags=abi.STEP_ALL):
     p = None
     if actions is not None:
+      actions = self._as_real(actions)
       p = self._dev_ptr(actions, self._action_shape, self.tdtype, 'actions')
     rc = self.lib.solo_engine_step(self._handle(), p, flags, self._stream())
     if rc != abi.OK:
@@ -191,6 +201,7 @@ class Engine:
     done [K,N] uint8) — what a rollout collector reads; the engine's view holds the last step's
     outputs afterwards in either case."""
     torch = self._torch
+    actions = self._as_real(actions)
     k = int(actions.shape[0])
     p = self._dev_ptr(actions, (k, self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
     if not record and out is None:
@@ -248,6 +259,7 @@ class Engine:
     self.set_order(torch.cat(parts).contiguous())
 
   def set_params(self, which, per_env):
+    per_env = self._as_real(per_env)
     p = self._dev_ptr(per_env, (self.num_envs,), self.tdtype, 'per_env')
     self._check(self.lib.solo_engine_set_params(self._handle(), which, p, self._stream()), 'set_params')
 

@@ -109,8 +109,11 @@ def test_bad_arguments_raise(torch):
     eng.set_params(7, torch.ones(4, device='cuda'))
   with pytest.raises((ValueError, TypeError)):
     eng.step(torch.zeros(3, 12, device='cuda'), abi.STEP_PHYSICS)        # wrong batch size
+  # (another FLOATING precision is converted by the binding - the drop-in env computes in float64 by default and callers
+  # hand it float32 actions -; a non-floating dtype is an error)
+  eng.step(torch.zeros(4, 12, device='cuda', dtype=torch.float64), abi.STEP_PHYSICS)
   with pytest.raises((ValueError, TypeError)):
-    eng.step(torch.zeros(4, 12, device='cuda', dtype=torch.float64), abi.STEP_PHYSICS)  # wrong dtype
+    eng.step(torch.zeros(4, 12, device='cuda', dtype=torch.int32), abi.STEP_PHYSICS)  # wrong dtype
   with pytest.raises(ValueError):
     eng.step(torch.zeros(4, 12, device='cuda'), abi.STEP_ALL)             # no program registered
   eng.close()

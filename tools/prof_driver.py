@@ -12,7 +12,12 @@ spl, streams, steps = int(os.environ.get('SPL', '250')), int(os.environ.get('STR
 # robot migration as bench.py chooses it (-1 = its rule: half the launch for a single-launch f64 rollout, else off)
 migrate = int(os.environ.get('MIGRATE', '-1'))
 if migrate < 0:
-  migrate = (min(spl, steps) + 1) // 2 if (dtype == 'float64' and steps <= spl and spl >= 8) else 0
+  migrate = 0
+  if dtype == 'float64' and spl >= 8:
+    if steps <= spl:
+      migrate = (min(spl, steps) + 1) // 2
+    elif spl >= 50:
+      migrate, streams = 25, 1
 env = build_env(n, 0, dtype, steps_per_launch=spl, rollout_streams=streams, migrate_steps=migrate)
 eng = env.engine
 tdt = torch.float32 if dtype == 'float32' else torch.float64
