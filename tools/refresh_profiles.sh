@@ -21,7 +21,7 @@ for CFG in $CONFIGS; do
   case $CFG in
     f32)     DT=float32; BARGS="--dtype float32";                                  PENV="SPL=250 STREAMS=2 STEPS=2000 REPEATS=1";;
     f32_k20) DT=float32; BARGS="--dtype float32 --gpus 1 --steps 20 --warmup 5";    PENV="SPL=20 STREAMS=1 STEPS=20 REPEATS=40";;
-    f64)     DT=float64; BARGS="--dtype float64";                   PENV="SPL=250 STREAMS=1 STEPS=1000 REPEATS=1";;   # (bench.py's choice for f64: one chain, migration chunks of 25)
+    f64)     DT=float64; BARGS="--dtype float64";                   PENV="SPL=250 STREAMS=1 STEPS=2000 REPEATS=1";;   # (8 launches: pmc_summary averages the last 6; bench.py's choice for f64: one chain, migration chunks of 25)
     f64_k20) DT=float64; BARGS="--dtype float64 --gpus 1 --steps 20 --warmup 5"; PENV="SPL=20 STREAMS=1 STEPS=20 REPEATS=40";;
     *) echo "unknown config $CFG"; exit 2;;
   esac
