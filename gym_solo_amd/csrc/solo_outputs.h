@@ -31,7 +31,7 @@ __device__ __forceinline__ void euler_from_quat(T x, T y, T z, T w, T* roll, T* 
   using R = Real<T>;
   const T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
   const T sarg = T(-2) * (x * z - w * y);
-  const T half_pi = T(1.5707963267948966);
+  const T half_pi = R::half_pi();
   if (sarg <= T(-0.99999)) {
     *roll = T(0); *pitch = -half_pi; *yaw = T(2) * R::atan2(x, -y);
   } else if (sarg >= T(0.99999)) {

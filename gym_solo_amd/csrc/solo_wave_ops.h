@@ -411,6 +411,7 @@ template <> struct Real<float> {
   static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
   static __device__ __forceinline__ float floor(float x) { return floorf(x); }
   static __device__ __forceinline__ float big() { return 3.0e38f; }
+  static __device__ __forceinline__ float half_pi() { return 1.57079637f; }
   static __device__ __forceinline__ float half_ulp() { return 5.9604645e-8f; }  // 2^-24
 };
 // f64 (the reference's precision): hardware v_rsq_f64 / v_rcp_f64 seeds (~2^-26) refined by two fused
@@ -523,7 +524,16 @@ template <> struct Real<double> {
   static __device__ __forceinline__ bool finite(double x) { return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull; }
   static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
   static __device__ __forceinline__ double floor(double x) { return ::floor(x); }
-  static __device__ __forceinline__ double big() { return 1.0e300; }
+  // An f64 constant is a register pair (VOP3 takes no 64-bit literal), and one that is used inside the step loop is
+  // hoisted in front of it and then SPILLED rather than rematerialised (two scratch stores per launch and a reload per
+  // step for 1e300 and for pi/2 each: tools/spill_sites.py).  Built from two opaque halves it is materialised where it is
+  // used: two v_mov.
+  static __device__ __forceinline__ double pinned_constant(unsigned hi, unsigned lo) {
+    asm volatile("" : "+v"(hi), "+v"(lo));
+    return __hiloint2double((int)hi, (int)lo);
+  }
+  static __device__ __forceinline__ double big() { return pinned_constant(0x7e37e43cu, 0x8800759cu); }        // 1.0e300
+  static __device__ __forceinline__ double half_pi() { return pinned_constant(0x3ff921fbu, 0x54442d18u); }    // 1.5707963267948966
   static __device__ __forceinline__ double half_ulp() { return 1.1102230246251565e-16; }  // 2^-53
 };
 

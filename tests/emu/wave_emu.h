@@ -265,6 +265,7 @@ template <> struct Real<float> {
   static float fma(float a, float b, float c) { return std::fma(a, b, c); }
   static float floor(float x) { return std::floor(x); }
   static float big() { return 3.0e38f; }
+  static float half_pi() { return 1.57079637f; }
   static float half_ulp() { return 5.9604645e-8f; }
 };
 template <> struct Real<double> {
@@ -285,6 +286,7 @@ template <> struct Real<double> {
   static double fma(double a, double b, double c) { return std::fma(a, b, c); }
   static double floor(double x) { return std::floor(x); }
   static double big() { return 1.0e300; }
+  static double half_pi() { return 1.5707963267948966; }
   static double half_ulp() { return 1.1102230246251565e-16; }
 };
 

@@ -20,7 +20,8 @@ N = 4096
 CHUNKS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 res = {}
 for dtype in ('float32', 'float64'):
-  env = build_env(N, 0, dtype, steps_per_launch=250, rollout_streams=2)
+  # (the geometries bench.py uses: f32 on two stream slices, f64 as one chain of launches with robot migration in chunks of 25)
+  env = build_env(N, 0, dtype, steps_per_launch=250, rollout_streams=2 if dtype == 'float32' else 1, migrate_steps=0 if dtype == 'float32' else 25)
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(20261004)
   t0 = time.perf_counter()
@@ -38,6 +39,7 @@ for dtype in ('float32', 'float64'):
                st[3] / max(st[2], 1), st[5], finite, qerr, float(eng.state[:, 2].min()), float(eng.state[:, 2].max())), flush=True)
       half.append(st.copy())
       assert finite and qerr < (1e-5 if dtype == 'float32' else 1e-13)
+      assert st[6] == 0   # no wave of a migrating launch ever gave up waiting for a ring slot
       assert st[2] == N * (((c + 1) * 1000) // 1001) and st[3] == 1001.0 * st[2]   # episode accounting: TimeBased(1000) ends an episode at its step 1001
   st = half[-1]
   mean = st[0] / st[2]
