@@ -14,9 +14,14 @@
 #include "solo_pgs_gfx950.h"  // (defines SOLO_PGS_GFX950: the f32 Gauss-Seidel loop of the step kernel in assembly)
 #include "solo_step_kernel.h"
 
-namespace {
-
-thread_local std::string g_create_error;
+// TRANSLATION UNITS (round 4).  The product library is this file compiled TWICE (Makefile): -DSOLO_TU_F32 = the C ABI and
+// the f32 engine, -DSOLO_TU_F64 = the f64 engine alone, with `-mllvm -disable-machine-licm`: the f64 step kernel lives on
+// exactly 168 VGPRs (three waves per SIMD), and what machine LICM hoists out of its step loop (LDS base addresses, flags)
+// it then has to SPILL - scratch reloads inside the step, each behind an s_waitcnt vmcnt(0) that also waits for the
+// step's freshly issued action load.  Without the pass: 0 VGPR spills, +3 ... 5 % (profiles/round4_ab.log); the f32
+// kernels (0 spills either way) are 1 ... 3 % faster WITH it, hence two units.  Without either macro (the test and
+// diagnostic builds) everything is one unit, as before.
+namespace solo_engine_detail {
 
 struct EngineBase {
   virtual ~EngineBase() {}
@@ -501,6 +506,25 @@ struct Engine final : EngineBase {
   }
 };
 
+// the f64 engine's factory: the one entry point of its translation unit (null = out of host memory; *rc = init's status)
+EngineBase* make_engine_f64(const SoloConfig& cfg, const SoloModel& model, int32_t num_envs, int32_t device_id, int* rc);
+#ifndef SOLO_TU_F32
+EngineBase* make_engine_f64(const SoloConfig& cfg, const SoloModel& model, int32_t num_envs, int32_t device_id, int* rc) {
+  auto* e = new (std::nothrow) Engine<double>();
+  *rc = e ? e->init(cfg, model, num_envs, device_id) : (int)SOLO_ERR_HIP;
+  return e;
+}
+#endif
+
+}  // namespace solo_engine_detail
+
+#ifndef SOLO_TU_F64  // ---- the C ABI (and the f32 engine) ----
+using namespace solo_engine_detail;
+
+namespace {
+
+thread_local std::string g_create_error;
+
 int check_config(const SoloConfig* c, std::string* err) {
   auto fail = [&](const char* s) { *err = s; return (int)SOLO_ERR_INVALID_ARG; };
   if (c->abi_version != SOLO_ABI_VERSION) return fail("abi_version mismatch");
@@ -514,7 +538,8 @@ int check_config(const SoloConfig* c, std::string* err) {
   if (!(c->solver_warm_start >= 0 && c->solver_warm_start <= 1)) return fail("solver_warm_start must be in [0, 1]");
   if (c->solver_warm_start > 0 && !(c->solver_residual_threshold > 0)) return fail("solver_warm_start needs solver_residual_threshold > 0");
   if (c->migrate_steps < 0 || c->migrate_steps > 100000 || c->reserved0 != 0) return fail("migrate_steps out of range");
-  if (c->restitution != 0.0) return fail("only restitution 0 is supported (gym_solo configs.py:23)");
+  // (restitution: accepted, and without effect - see include/solo_engine.h: Bullet combines it with the ground's, which is 0)
+  if (!(c->restitution >= 0 && c->restitution <= 1)) return fail("restitution must be in [0, 1] (gym_solo configs.py:23)");
   if (!(c->action_scale > 0)) return fail("action_scale must be positive");
   if (c->lateral_friction < 0 || c->contact_margin < 0 || c->contact_erp < 0) return fail("negative contact parameter");
   return SOLO_OK;
@@ -560,9 +585,7 @@ int solo_engine_create(const SoloConfig* cfg, const SoloModel* model, int32_t nu
     impl = e;
     rc = e ? e->init(*cfg, *model, num_envs, device_id) : SOLO_ERR_HIP;
   } else {
-    auto* e = new (std::nothrow) Engine<double>();
-    impl = e;
-    rc = e ? e->init(*cfg, *model, num_envs, device_id) : SOLO_ERR_HIP;
+    impl = make_engine_f64(*cfg, *model, num_envs, device_id, &rc);
   }
   if (rc != SOLO_OK) {
     g_create_error = impl ? impl->err : "out of host memory";
@@ -611,3 +634,4 @@ int solo_engine_time_step(SoloEngine* eng, const void* a, uint32_t flags, int32_
 const char* solo_engine_last_error(SoloEngine* eng) { return eng && eng->impl ? eng->impl->err.c_str() : "invalid engine handle"; }
 
 }  // extern "C"
+#endif  // !SOLO_TU_F64

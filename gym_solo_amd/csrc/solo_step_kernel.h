@@ -46,14 +46,23 @@
 // In-kernel phase stamps exist only in the diagnostic build (make -C gym_solo_amd/csrc stamps);
 // in the product build the macro expands to nothing.
 #if defined(SOLO_STAMPS) && defined(SOLO_STAMPS_LIGHT)
-// light variant (make stamps_light): only the launch's first and last stamp, nothing per step
+// light variant (make stamps_light): only the launch's first and last stamp, nothing per step - on the 100-MHz
+// real-time counter, which all XCDs share (s_memtime counts per XCD: tools/gpu_critical_path.py compares across them)
 #define SOLO_STAMP(B, i)                                                                          \
   do {                                                                                            \
     if (((i) == 0 || (i) == 14) && solo::lane_id() == 0)                                          \
-      (B).stamps[(size_t)(B).stamp_row * 32 + (i)] = __builtin_amdgcn_s_memtime();             \
+      (B).stamps[(size_t)(B).stamp_row * 32 + (i)] = __builtin_amdgcn_s_memrealtime();         \
   } while (0)
 #elif defined(SOLO_STAMPS)
-#define SOLO_STAMP(B, i)                                                                          \
+// (make stamps_epilogue, -DSOLO_STAMPS_EPILOGUE: stamps 1 .. 12 sit INSIDE the output epilogue instead of the step)
+#ifdef SOLO_STAMPS_EPILOGUE
+#define SOLO_STAMP_ON(i) ((i) == 0 || (i) >= 13)
+#define SOLO_STAMP_E(B, i) SOLO_STAMP_AT(B, i)
+#else
+#define SOLO_STAMP_ON(i) true
+#endif
+#define SOLO_STAMP(B, i) do { if (SOLO_STAMP_ON(i)) SOLO_STAMP_AT(B, i); } while (0)
+#define SOLO_STAMP_AT(B, i)                                                                       \
   do {                                                                                            \
     if (solo::lane_id() == 0) {                                                                   \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                 \
@@ -64,6 +73,9 @@
   } while (0)
 #else
 #define SOLO_STAMP(B, i) do {} while (0)
+#endif
+#ifndef SOLO_STAMP_E
+#define SOLO_STAMP_E(B, i) do {} while (0)
 #endif
 
 // test hook (CPU emulator builds only): called once per Gauss-Seidel sweep
@@ -198,7 +210,7 @@ __device__ __forceinline__ int pgs_solve_cpp(const ColumnBank<T>& A, T& v, T& la
 template <typename T, bool kResid>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
                                            const RowView<T>& rc, const T* s_state, T my_target, T* s_rowvec, T (*s_hext)[8],
-                                           T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& row_at,
+                                           T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& row_at, bool& target_bad,
                                            int& prio_sweeps, int& prio_steps, int& prio_rot, T warm_in = T(0), bool warm_on = false) {
   constexpr bool kCompact = ColumnBank<T>::kCompact;   // the solver runs in slot space (see "slot space" below)
   constexpr int kRS = ColumnBank<T>::kRowStride;       // reals per row vector in s_rowvec
@@ -536,6 +548,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     jl2 = (k == 1) ? T(1) : T(0);
     const T qj = s_leg[leg][17 + k], uj = s_leg[leg][15 + k];
     bias = C.kp_over_dt * (my_target - qj) + C.one_minus_kd * uj;
+    if constexpr (sizeof(T) == 8) target_bad = !R::finite(my_target);  // (f64: looked at where the target is used - the value does not live on to the end of the step)
   } else if (is_limit) {
     // speculative unilateral row, the same form as a contact normal row: v towards the limit
     // <= distance / dt while inside, pushed back with the erp once violated
@@ -843,8 +856,10 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 // post-solve half: apply the impulses (du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam -
 // K du_b), go back to world-frame velocities and integrate.  Everything is re-read from LDS.
 template <typename T>
-__device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, const T* s_rowvec, const T (*s_hext)[8],
+__device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, T* s_scratch, const T (*s_hext)[8],
                                                const T* s_keep, const T (*s_leg)[kLegSlots], const T* s_math, T lam, int lane, int row_at) {
+  const T* const s_rowvec = s_scratch;  // (the row vectors; with s_hext behind them the scratch of the f64 reduction below)
+  if constexpr (sizeof(T) == 8) lane = wave_opaque_lane(lane);  // (f64: per-lane LDS addresses are re-derived here - shared with physics_solve they lived across the whole solver, as a spill)
   using R = Real<T>;
   constexpr int kRS = ColumnBank<T>::kRowStride;
   const int leg = lane >> 4, k = lane & 15;
@@ -861,7 +876,15 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
     yl[0] = s_rowvec[row_at * kRS + 6] * lam;
     yl[1] = s_rowvec[row_at * kRS + 7] * lam;
   }
-  wave_reduce_rows(z, yl);
+  if constexpr (ColumnBank<T>::kCompact) {
+    // f64: through LDS (solo_wave_ops.h: a third of the instructions of the DPP chains) - the row-vector block is the
+    // scratch: every lane has just taken what it needs of it (wave_sync: the reads above come first)
+    static_assert(64 * kRS + 64 * 8 >= kReduceScratch, "the row-vector block holds the reduction's scratch");
+    wave_sync();
+    wave_reduce_rows_lds(z, yl, s_scratch, lane);
+  } else {
+    wave_reduce_rows(z, yl);
+  }
   const T yl1 = yl[0], yl2 = yl[1];
   // C^T x = z (back substitution with the parked Cholesky factor)
 #pragma unroll
@@ -1163,8 +1186,18 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
 #pragma unroll 1
   for (int step = step_begin; step < step_end; ++step) {
     const StepConst<T>& C = s_const;  // (LDS: re-read every step, nothing carried across the step loop in registers)
-    const int lane = wave_opaque_lane(lane0);  // per-lane address arithmetic stays in the step instead of being
-    // hoisted out of the fused step loop and kept live across it (spills)
+    // per-lane address arithmetic stays in the step instead of being hoisted out of the fused step loop and kept live
+    // across it (spills).  kLean (f64: the kernel lives on exactly 168 VGPRs, and what it spilled was reloaded from
+    // scratch INSIDE the step - behind an s_waitcnt vmcnt(0) that also waited for the step's freshly issued action
+    // load): the lane number itself is computed here (solo_wave_ops.h: wave_fresh_lane), "are there actions?" is a compare
+    // on two scalar registers here instead of a flag parked in a vector register across the loop (only the test is
+    // opaque: through an opaque pointer the loads became flat loads), the target's finiteness is looked at where the
+    // target is used (physics_solve) instead of keeping it to the end of the step, and physics_finish re-derives its
+    // LDS addresses.  f32 (0 spills without any of it, 1 % slower with it) keeps its code.
+    constexpr bool kLean = sizeof(T) == 8;
+    const int lane = kLean ? wave_fresh_lane() : wave_opaque_lane(lane0);
+    const bool have_actions = kLean ? wave_opaque_bits((unsigned long long)B.actions) != 0ull : B.actions != nullptr;
+    const T* const actions = have_actions ? B.actions : nullptr;
     const LegConst<T>& L = s_legc[lane >> 4];
     const int row_tb = s_rowtype[lane];
     const RowView<T> rc = {row_tb & 255, row_tb >> 8, s_rowgeo[lane]};
@@ -1179,14 +1212,14 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     // (the robot's motor targets are written from several chunks - the last step's action, an auto-reset's settle pose -
     // and read back when a launch brings no actions: device-coherent accesses in a migrating launch, like its record)
     if (motor_lane) {
-      if (B.actions != nullptr) raw_target = B.actions[(size_t)step * B.action_stride + tgt_at];
+      if (actions != nullptr) raw_target = actions[(size_t)step * B.action_stride + tgt_at];
       else if constexpr (kMigrate) raw_target = wave_load_shared(wave_cold_args(Bin)->targets + tgt_at);
       else raw_target = wave_cold_args(Bin)->targets[tgt_at];
     }
     // action de-normalisation (solo8v2vanilla.py:84-85), applied where the target is used
-    const T target_scale = B.actions != nullptr ? C.action_scale : T(1);
-    if (B.actions != nullptr && step == B.steps - 1 && lane < SOLO_NUM_JOINTS) {  // the view's targets: all 12 entries
-      const T tv = B.actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * C.action_scale;
+    const T target_scale = actions != nullptr ? C.action_scale : T(1);
+    if (actions != nullptr && step == B.steps - 1 && lane < SOLO_NUM_JOINTS) {  // the view's targets: all 12 entries
+      const T tv = actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * C.action_scale;
       if constexpr (kMigrate) wave_store_shared(wave_cold_args(Bin)->targets + (size_t)env * SOLO_NUM_JOINTS + lane, tv);
       else wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = tv;
     }
@@ -1203,8 +1236,9 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
       const T my_target = raw_target * target_scale;
+      bool target_bad = false;  // (set on a motor lane whose target is not finite)
       int row_at;  // where this lane's constraint row sits in s_rowvec / s_hext (its lane, or its slot: see physics_solve)
-      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, prio_sweeps, prio_steps, prio_rot,
+      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, target_bad, prio_sweeps, prio_steps, prio_rot,
                                              warm_in, kResid && warm_row != nullptr);
       if constexpr (kResid) if (warm_row != nullptr) {
         if constexpr (kMigrate) wave_store_shared(warm_row + (size_t)env * 64 + lane, lam);
@@ -1213,7 +1247,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       physics_finish<T>(C, s_state, s_rowvec, s_hext, s_keep, s_leg, s_math, lam, lane, row_at);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted
-      const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) || (motor_lane && !R::finite(my_target));
+      const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) || (kLean ? target_bad : (motor_lane && !R::finite(my_target)));
       diverged = wave_ballot(bad) != 0ull;
       if (diverged) {
         if constexpr (kResid) if (warm_row != nullptr) {  // (a restored robot starts from zero impulses)
@@ -1318,7 +1352,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     wave_sync();  // this step's LDS state is complete before the next step reads it
   }
   SOLO_STAMP(B, 13);
-  const int lane1 = wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
+  const int lane1 = sizeof(T) == 8 ? wave_fresh_lane() : wave_opaque_lane(lane0);  // re-derive the addresses instead of keeping them live
   // ---- THE OUTPUT EPILOGUE (round 3): the launch's observations, rewards, done flags and episodic bookkeeping,
   //      evaluated by the robot's own wave from the records it left, 32 steps per pass with LANE = STEP - one pass
   //      costs what one item costs (~450 instructions), whatever the number of steps in it: 0.2 % of a 250-step
@@ -1334,6 +1368,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   //      the scratch stays clear of the per-launch tables (28 steps per pass in f64).
   if constexpr (kFull) if (B.traj != nullptr) {
     wave_fence_global();  // this wave's record stores before its loads of them
+    SOLO_STAMP_E(B, 1);
     const auto A = wave_cold_args(Bin);
     const int n_obs = wave_uniform(s_const.num_obs), n_rops = wave_uniform(s_const.num_reward_ops);
     constexpr int kPass = kRowsReals / SOLO_MAX_REWARD_OPS < 32 ? kRowsReals / SOLO_MAX_REWARD_OPS : 32;
@@ -1358,8 +1393,10 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
           if (B.done_stride != 0 || last) B.done[(size_t)k * B.done_stride + env] = (uint8_t)(ev & kEventDone);
           if (view_done != nullptr && last) view_done[env] = (uint8_t)(ev & kEventDone);
         }
+        SOLO_STAMP_E(B, 2);
         T roll, pitch, yaw;
         euler_from_quat<T>(rec[SOLO_S_QUAT], rec[SOLO_S_QUAT + 1], rec[SOLO_S_QUAT + 2], rec[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
+        SOLO_STAMP_E(B, 3);
         if (B.flags & SOLO_STEP_OBS) {
           T* o_rec = (obs_rec != nullptr && k >= obs_from) ? obs_rec + (size_t)k * obs_stride + (size_t)env * n_obs : nullptr;
           T* o_view = (view_obs != nullptr && last) ? view_obs + (size_t)env * n_obs : nullptr;
@@ -1370,19 +1407,23 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
               if (o_view != nullptr) o_view[i] = x;
             }
         }
+        SOLO_STAMP_E(B, 4);
         if (want_reward) {
           const T rv = eval_reward<T>(P0, rec, roll, pitch, val + lane1, kPass);
           if (reward_rec != nullptr) reward_rec[(size_t)k * reward_stride + env] = rv;
           if (view_reward != nullptr && last) view_reward[env] = rv;
         }
+        SOLO_STAMP_E(B, 5);
       }
       wave_sync();
+      SOLO_STAMP_E(B, 6);
       if (bookkeeping && lane1 == 0) {
         const int cnt = step_end - base < kPass ? step_end - base : kPass;
         accumulate_returns<T>(s_state, ev_bytes, 1, val + (size_t)(n_rops - 1) * kPass, 1, cnt, SOLO_STATS_ROW,
                               [](double* p, double x) { stats_add(p, x); });
       }
       wave_sync();
+      SOLO_STAMP_E(B, 7);
     }
   }
   if ((B.flags & SOLO_STEP_DONE) && lane1 < SOLO_MAX_TERMS) {
@@ -1428,7 +1469,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
 }
 
 // the work queue of a launch with robot migration (solo_kernel_params.h): one thread per entry
-__global__ void solo_queue_init_kernel(int32_t* __restrict__ q, size_t ints, int env_base, int n, int rings, int steps, int chunk,
+static __global__ void solo_queue_init_kernel(int32_t* __restrict__ q, size_t ints, int env_base, int n, int rings, int steps, int chunk,
                                        const int32_t* __restrict__ order) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < ints) migration_queue_init(q, i, env_base, n, rings, steps, chunk, order);

@@ -26,8 +26,21 @@ template <typename P> __device__ __forceinline__ P* wave_opaque(P* p) {
   asm volatile("" : "+s"(p));
   return p;
 }
+__device__ __forceinline__ unsigned long long wave_opaque_bits(unsigned long long x) {  // (wave-uniform bits)
+  asm volatile("" : "+s"(x));
+  return x;
+}
 __device__ __forceinline__ int wave_opaque_lane(int lane) {
   asm volatile("" : "+v"(lane));
+  return lane;
+}
+// the lane number, computed HERE (v_mbcnt over an all-ones mask: two instructions, any EXEC): the step loop takes its
+// lane from this at the top of every step.  Derived from the kernel's threadIdx register the lane was one more value
+// live across the whole loop - and the f64 kernel, which lives on exactly 168 VGPRs, SPILLED it: a scratch reload per
+// step whose s_waitcnt vmcnt(0) also waited for the step's freshly issued action load (round 4).
+__device__ __forceinline__ int wave_fresh_lane() {
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
   return lane;
 }
 __device__ __forceinline__ int wave_readlane_int(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
@@ -182,6 +195,39 @@ __device__ __forceinline__ void wave_reduce_rows(double (&z)[6], double (&y)[2])
   for (int i = 0; i < 6; ++i) z[i] = wave_sum_all(z[i]);
   y[0] = wave_sum_group16(y[0]);
   y[1] = wave_sum_group16(y[1]);
+}
+// The same eight sums THROUGH LDS (f64, round 4).  As DPP chains a 64-bit sum costs three instructions per stage (two
+// 32-bit DPP moves and the add: DPP takes no 64-bit operands) - ~156 for the eight.  Here every lane parks its eight
+// terms (scratch[lane][9]: the odd stride keeps the column reads below free of bank conflicts), lane (k = lane & 7,
+// part = lane >> 3) adds the terms k of the lanes 8 part ... 8 part + 7 in lane order, one row rotation joins the two
+// parts of a 16-lane row (for k = 6, 7 that is the leg's sum of y: broadcast from the row's lanes 6 / 7 with
+// row_newbcast), the permlane swaps join the four rows, and six v_readlane pairs hand out the totals: ~45 VALU
+// instructions and two LDS round trips.  The caller orders its own LDS reads of the scratch area in front of this.
+// ASSOCIATION (tests/emu/wave_emu.h restates it): ((((((x0 + x1) + x2) + x3) + x4) + x5) + x6) + x7 per part; part 2r +
+// part 2r + 1 per row r; (row 0 + row 1) + (row 2 + row 3).
+constexpr int kReduceScratch = 64 * 9;
+template <int N> __device__ __forceinline__ double dpp_row_bcast(double x) {   // lane N of the caller's 16-lane row
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + N, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void wave_reduce_rows_lds(double (&z)[6], double (&y)[2], double* scratch, int lane) {
+  double* const mine = scratch + lane * 9;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) mine[i] = z[i];
+  mine[6] = y[0]; mine[7] = y[1];
+  wave_sync();
+  const double* const col = scratch + (lane >> 3) * 72 + (lane & 7);
+  double p = col[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) p += col[9 * i];
+  p += dpp_mov<0x128>(p);
+  const double total = wave_sum_legs(p);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) z[i] = wave_readlane(total, i);
+  y[0] = dpp_row_bcast<6>(p);
+  y[1] = dpp_row_bcast<7>(p);
 }
 
 // ghat_s . ghat_r + hhat_s . x for the Delassus columns: the lane's own whitened row stays in

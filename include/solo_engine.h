@@ -115,7 +115,10 @@ typedef struct SoloConfig {
   double linear_damping;     /* configs.py:21 */
   double angular_damping;    /* configs.py:22 */
   double lateral_friction;   /* configs.py:24 (x plane friction 1.0) */
-  double restitution;        /* configs.py:23 (0; only 0 is supported) */
+  double restitution;        /* configs.py:23, passed to changeDynamics for links 0..11 (solo8v2vanilla.py:158-163).  In [0, 1];
+                                WITHOUT EFFECT here, as in the reference: Bullet gives a contact the PRODUCT of its two bodies'
+                                restitutions ([recalled] btManifoldResult::calculateCombinedRestitution), and the ground the
+                                reference loads - pybullet_data's plane.urdf, solo8_base_env.py:47 - declares none (0) */
   double contact_erp;        /* penetration recovery rate (Bullet erp2 0.2 [recalled]) */
   double contact_margin;     /* spheres closer than this to the ground create rows */
   double joint_limit_margin; /* a joint closer than this [rad] to one of its limits gets that limit's row

@@ -26,7 +26,9 @@
  *   stepSimulation()  solo8v2vanilla.py:91, fixedTimeStep=dt, numSubSteps=1
  *       solo8_base_env.py:39-41
  *   gravity configs.py:17, link damping configs.py:21-22 via changeDynamics
- *       solo8v2vanilla.py:158-163, friction configs.py:24, restitution 0 configs.py:23
+ *       solo8v2vanilla.py:158-163, friction configs.py:24, restitution configs.py:23 (never read: a contact's
+ *       restitution is the product of its bodies' - [recalled] btManifoldResult::calculateCombinedRestitution - and the
+ *       ground, plane.urdf, has none)
  */
 #include <math.h>
 #include <stdint.h>

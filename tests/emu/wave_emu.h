@@ -122,6 +122,8 @@ inline int block_id() { return blockIdx.x; }
 inline void wave_sync() { WaveEmu::get().yield(); }
 template <typename P> inline P* wave_opaque(P* p) { return p; }
 inline int wave_opaque_lane(int lane) { return lane; }
+inline unsigned long long wave_opaque_bits(unsigned long long x) { return x; }
+inline int wave_fresh_lane() { return WaveEmu::get().lane(); }
 inline int wave_uniform(int x) { return x; }
 inline int wave_readlane_int(int x, int lane) { return (int)(uint32_t)WaveEmu::get().exchange((uint32_t)x, lane); }
 inline void wave_set_priority_level(int) {}
@@ -234,6 +236,22 @@ template <typename T> inline void wave_reduce_rows(T (&z)[6], T (&y)[2]) {
   for (int i = 0; i < 6; ++i) z[i] = wave_sum_all(z[i]);
   y[0] = wave_sum_group16(y[0]);
   y[1] = wave_sum_group16(y[1]);
+}
+// (the same sums through LDS - solo_wave_ops.h: wave_reduce_rows_lds, its association restated)
+constexpr int kReduceScratch = 64 * 9;
+template <typename T> inline void wave_reduce_rows_lds(T (&z)[6], T (&y)[2], T* scratch, int lane) {
+  for (int i = 0; i < 6; ++i) scratch[lane * 9 + i] = z[i];
+  scratch[lane * 9 + 6] = y[0]; scratch[lane * 9 + 7] = y[1];
+  wave_sync();
+  const T* col = scratch + (lane >> 3) * 72 + (lane & 7);
+  T p = col[0];
+  for (int i = 1; i < 8; ++i) p += col[9 * i];
+  p += emu_shfl_xor(p, 8);
+  const T total = wave_sum_legs(p);
+  for (int i = 0; i < 6; ++i) z[i] = wave_readlane(total, i);
+  y[0] = wave_readlane(p, (lane & 48) + 6);
+  y[1] = wave_readlane(p, (lane & 48) + 7);
+  wave_sync();  // (fibres: nobody rewrites the scratch while another lane still reads it)
 }
 inline unsigned long long wave_ballot(bool p) {
   WaveEmu& e = WaveEmu::get();

@@ -55,6 +55,33 @@ def test_ragged_sizes_fused_equals_single_steps(torch, n, spl, streams, k):
   a.close(); b.close()
 
 
+def test_restitution_is_accepted_and_without_effect(torch):
+  """configs.py:23 / solo8v2vanilla.py:158-163 pass `restitution` to changeDynamics for the robot's links.  Bullet gives
+  a contact the product of its two bodies' restitutions ([recalled] btManifoldResult::calculateCombinedRestitution) and
+  the reference's ground (plane.urdf) has none: any value in [0, 1] is accepted and leaves every trajectory as it is -
+  robots dropped from the reset height, bit for bit, and against the oracle."""
+  from oracle import solo_oracle as so
+  a, ca, ma = _engine(64, 'float64', settle_steps=0, restitution=0.8)
+  b, _, _ = _engine(64, 'float64', settle_steps=0)
+  rng = np.random.default_rng(3)
+  acts = torch.as_tensor(rng.uniform(-6, 6, (400, 64, 12)), device='cuda', dtype=torch.float64)
+  a.rollout(acts, abi.STEP_PHYSICS)
+  b.rollout(acts, abi.STEP_PHYSICS)
+  torch.cuda.synchronize()
+  assert float(b.state[:, 2].max()) < 0.45     # (they have landed)
+  assert torch.equal(a.state, b.state)
+  ph = so.OraclePhysics(ca, ma)                # (the oracle is handed the same configuration, restitution included)
+  e, _, _ = _engine(2, 'float64', settle_steps=0, restitution=0.8)
+  st = e.state.cpu().numpy().copy()
+  for k in range(300):
+    ph.step(st, acts[k, :2].cpu().numpy())
+  e.rollout(acts[:300, :2].contiguous(), abi.STEP_PHYSICS)
+  np.testing.assert_allclose(e.state.cpu().numpy()[:, :29], st[:, :29], rtol=0, atol=1e-9)
+  with pytest.raises(Exception, match='restitution'):
+    _engine(4, 'float64', restitution=1.5)
+  a.close(); b.close(); e.close()
+
+
 def test_empty_rollout_is_a_noop(torch):
   eng, _, _ = _engine(8, 'float32', settle_steps=20)
   before = eng.state.clone()

@@ -8,9 +8,11 @@ import numpy as np, torch
 from gym_solo_amd import abi
 from bench import build_env
 names = ['loads+sync', 'kinematics', 'crba', 'rne bias', 'schur+sum', 'chol+solve', 'rows', 'A build', 'PGS', 'finish+nan check', 'term+record', 'restart+done', 'loop exit', 'epilogue']
+if 'epilogue' in os.environ['SOLO_HIP_LIB']:  # (make stamps_epilogue: stamps 1 .. 12 sit inside the output epilogue; per-step figures = per launch / steps)
+  names = ['record fence', 'event + done', 'euler angles', 'observations', 'rewards', 'sync', 'returns'] + ['-'] * 5 + ['the steps', 'tail']
 DTYPE = os.environ.get('DTYPE', 'float32')
 TD = torch.float32 if DTYPE == 'float32' else torch.float64
-for n in [int(a) for a in sys.argv[1:]] or (1024, 4096):
+for n in ([] if 'epilogue' in os.environ['SOLO_HIP_LIB'] else [int(a) for a in sys.argv[1:]] or (1024, 4096)):
   env = build_env(n, 0, DTYPE)
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(1234)
@@ -38,7 +40,7 @@ for n in [int(a) for a in sys.argv[1:]] or (1024, 4096):
   env._close()
 
 # ---- fused launches (the bench configuration): how unequal are the robots' 100-step totals? ----
-for n, spl in ((1024, 100), (4096, 100)):
+for n, spl in [tuple(int(x) for x in f.split(':')) for f in os.environ.get('FUSED', '1024:100,4096:100').split(',')]:
   env = build_env(n, 0, DTYPE, steps_per_launch=spl, rollout_streams=1)
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(99)

@@ -10,7 +10,7 @@ t = (sys.argv[1:] or ['f'])[0]
 minc = int((sys.argv[2:] or ['8'])[0])
 out = '/tmp/solo_lines.gfx950.s'
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=fast',
-                       '-fno-slp-vectorize', '-gline-tables-only', '-S', '--cuda-device-only', '-o', out,
+                       '-fno-slp-vectorize', *(['-DSOLO_TU_F64', '-mllvm', '-disable-machine-licm'] if (sys.argv[1:] or ['f'])[0] == 'd' else ['-DSOLO_TU_F32']), '-gline-tables-only', '-S', '--cuda-device-only', '-o', out,
                        os.path.join(ROOT, 'gym_solo_amd/csrc/solo_engine.hip')], stderr=subprocess.DEVNULL)
 lines = open(out).read().split('\n')
 files = {}

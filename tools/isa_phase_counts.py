@@ -9,11 +9,11 @@ import os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = '/tmp/solo_stamps.gfx950.s'
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=fast',
-                       '-fno-slp-vectorize', '-DSOLO_STAMPS', '-S', '--cuda-device-only', '-o', path,
+                       '-fno-slp-vectorize', *(['-DSOLO_TU_F64', '-mllvm', '-disable-machine-licm'] if (sys.argv[1:] or ['f'])[0] == 'd' else ['-DSOLO_TU_F32']), '-DSOLO_STAMPS', '-S', '--cuda-device-only', '-o', path,
                        os.path.join(ROOT, 'gym_solo_amd/csrc/solo_engine.hip')], stderr=subprocess.DEVNULL)
 t = (sys.argv[1:] or ['f'])[0]
 lines = open(path).read().split('\n')
-start = [i for i, l in enumerate(lines) if l.startswith('_ZN4solo16solo_step_kernelI%sLb1ELb0EE' % t)][0]
+start = [i for i, l in enumerate(lines) if l.startswith('_ZN4solo16solo_step_kernelI%sLb1ELb0ELb0EE' % t)][0]
 fe = [i for i, l in enumerate(lines[start:]) if l.startswith('.Lfunc_end')][0] + start
 names = ['prologue', 'loads+sync', 'kinematics', 'crba', 'rne bias', 'schur+sum', 'chol+solve', 'rows', 'A build',
          'PGS', 'finish+nan check', 'term+record', 'restart+done', 'loop exit', 'epilogue', 'tail']
