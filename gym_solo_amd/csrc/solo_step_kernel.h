@@ -125,6 +125,14 @@ template <typename T> __device__ __forceinline__ V3<T> from_lower(V3<T> v) { ret
 
 }  // namespace solo
 namespace solo {
+// sweeps per step above which a robot's wave is pinned to the top issue priority (physics_solve).  f32: 8 (thresholds
+// 4 / 8 / 20 / 40 measured in round 2: 1.063 / 1.060 / 1.027 / 1.021e8).  f64 runs to its fixed point in more sweeps
+// (mean 9.4 per robot-step against 4.9): with 8 nearly half of the robots were "slow"; 12 is worth +2 % on 250-step
+// launches, nothing at 20 steps or one (8 / 12 / 16 / 24 / 40: 1.68 / 1.72 / 1.70 / 1.69 / 1.68e8, profiles/round4_ab.log)
+#ifndef SOLO_PRIO_SWEEPS_F64
+#define SOLO_PRIO_SWEEPS_F64 12
+#endif
+template <typename T> constexpr int kPrioSweeps = sizeof(T) == 4 ? 8 : SOLO_PRIO_SWEEPS_F64;
 constexpr int kLegSlots = 26;  // per-leg parking lot in LDS (see physics_solve): 0-11 K, 12-14 Lp factors, 15-16 unconstrained joint rates, 17-18 q, 19-22 cos / sin of the two link angles, 23-24 P^-1 h
 
 // one lane's constraint-row constants, as the step reads them from LDS (staged from KParams::row once per launch)
@@ -842,13 +850,13 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   //    launch (per-robot time per step 18 k ... 30 k cycles by age rank alone).  The waves therefore
   //    ROTATE through priorities 0..2 by step count and wave slot, which equalises their progress;
   //  * a launch lasts as long as its slowest robot, and slow means many Gauss-Seidel sweeps (the
-  //    cost is persistent within an episode): a robot that has averaged more than 8 sweeps per step
-  //    so far in the launch is pinned to priority 3, above the rotation.
+  //    cost is persistent within an episode): a robot that has averaged more than kPrioSweeps (8; f64: 12)
+  //    sweeps per step so far in the launch is pinned to priority 3, above the rotation.
   // +4 % on the 250-step fused rollout, +2 % at 20 steps; no effect on results.
   prio_sweeps += it;
   prio_steps += 1;
   prio_rot = prio_rot == 2 ? 0 : prio_rot + 1;  // = (prio_steps + wave slot) % 3, without the division
-  wave_set_priority_level(prio_sweeps > 8 * prio_steps ? 3 : prio_rot);
+  wave_set_priority_level(prio_sweeps > kPrioSweeps<T> * prio_steps ? 3 : prio_rot);
   SOLO_STAMP(B, 9);
   return lamv;
 }
@@ -1169,7 +1177,9 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   int prio_sweeps = wave_uniform(hist_w);
   const int hist_sweeps = kMigrate ? 0 : prio_sweeps;
   int prio_rot = (prio_steps + wave_slot_id()) % 3;  // the rotation's phase (advanced once per step)
-  if (prio_steps > 0) wave_set_priority_level(prio_sweeps > 8 ? 3 : wave_slot_id() % 3);  // (thresholds 4 / 8 / 20 / 40 measured: 1.063 / 1.060 / 1.027 / 1.021e8 env-steps/s)
+  // (a migrating robot's history is its sweeps over the prio_steps steps it has behind it in this launch; a single-step
+  // launch's the sweeps of the robot's previous step)
+  if (prio_steps > 0) wave_set_priority_level(prio_sweeps > kPrioSweeps<T> * (kMigrate ? prio_steps : 1) ? 3 : wave_slot_id() % 3);
   wave_sync();
   if constexpr (!kMigrate) make_term_tables();
   // The auto-reset belongs to a step that advanced the simulation (or asks for it explicitly): a
