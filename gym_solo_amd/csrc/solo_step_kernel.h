@@ -727,14 +727,27 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     // slots 0, 1 are the first leg's motor rows; behind them the live rows come in threes when no joint-limit row is
     // live (L = 8 + 3 x touching spheres): one test per three columns, none built in vain (a slot beyond L holds a
     // zero row: its column would be zero and is never fetched)
-    A.build(0);
-    A.build(1);
+    // (software-pipelined by one slot: the row of slot r + 1 is fetched - eight LDS broadcasts - in front of the arithmetic
+    // of slot r, across the tests too: a wave alone on its SIMD, the slow robot at the end of a launch, otherwise sits
+    // out an LDS round trip at the head of every triple)
+    typename ColumnBank<T>::Row cur = A.fetch(0);
+    {
+      const typename ColumnBank<T>::Row n1 = A.fetch(1);
+      A.build_from(0, cur);
+      cur = A.fetch(2);
+      A.build_from(1, n1);
+    }
 #pragma unroll
     for (int j = 2; j < ColumnBank<T>::kSlots; j += 3) {
       if (n_live > j) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          if (j + q < ColumnBank<T>::kSlots) A.build(j + q);
+        const typename ColumnBank<T>::Row n1 = A.fetch(j + 1 < 64 ? j + 1 : 63);
+        A.build_from(j, cur);
+        if (j + 1 < ColumnBank<T>::kSlots) {
+          const typename ColumnBank<T>::Row n2 = A.fetch(j + 2 < 64 ? j + 2 : 63);
+          A.build_from(j + 1, n1);
+          cur = A.fetch(j + 3 < 64 ? j + 3 : 63);   // (the next triple's first row; a slot beyond L holds zeros)
+          if (j + 2 < ColumnBank<T>::kSlots) A.build_from(j + 2, n2);
+        }
       }
     }
   }

@@ -326,6 +326,21 @@ template <> struct ColumnBank<double> {
     const double x = column(r);
     if (r < 16) a0[r] = x; else a1[r - 16] = x;
   }
+  // the same in two halves, for a build that fetches slot r + 1's row while it computes slot r's column (the LDS
+  // broadcasts of the next row are in flight behind the arithmetic of this one: solo_step_kernel.h)
+  struct Row { double g[6], h[2]; };
+  __device__ __forceinline__ Row fetch(int r) const {
+    Row x;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x.g[i] = rowvec[kRowStride * r + i];
+    x.h[0] = hext[8 * r]; x.h[1] = hext[8 * r + 1];
+    return x;
+  }
+  __device__ __forceinline__ void build_from(int r, const Row& x) {
+    const double m = (lane == r) ? 0.0 : nid;
+    const double c = m * own.dot(x.g, x.h);
+    if (r < 16) a0[r] = c; else a1[r - 16] = c;
+  }
   __device__ __forceinline__ double get(int bank, int r) const { return bank == 0 ? a0[r & 15] : a1[r & 15]; }
 };
 

@@ -171,6 +171,15 @@ template <typename T> struct ColumnBank {
   }
   T column(int r) const { const T m = (lane == r) ? T(0) : nid; return m * own.dot(rowvec + kRowStride * r, hext + 8 * r); }
   void build(int r) { a[r] = column(r); }
+  // (the pipelined build of the slot-space kernel: solo_wave_ops.h)
+  struct Row { T g[6], h[2]; };
+  Row fetch(int r) const {
+    Row x;
+    for (int i = 0; i < 6; ++i) x.g[i] = rowvec[kRowStride * r + i];
+    x.h[0] = hext[8 * r]; x.h[1] = hext[8 * r + 1];
+    return x;
+  }
+  void build_from(int r, const Row& x) { const T m = (lane == r) ? T(0) : nid; a[r] = m * own.dot(x.g, x.h); }
   T get(int, int r) const { return a[r]; }
 };
 
