@@ -291,7 +291,10 @@ struct Engine final : EngineBase {
       // robot migration: a launch of more than one chunk of steps gets a work queue (its own region per rollout slice:
       // the slices' launches run side by side), initialised on the stream in front of the step kernel; eight rings -
       // one per XCD - when the robots divide evenly, else one
-      if (migrate_chunk() > 0 && steps > migrate_chunk() && (flags & SOLO_STEP_PHYSICS)) {
+      // (stepSimulation-only launches - the settle loop, client.stepSimulation() - keep the physics-only instantiation:
+      // their robots are in step with each other, there is nothing to balance, and in profiles the settle loop stays a
+      // kernel of its own instead of inflating the measured one's average)
+      if (migrate_chunk() > 0 && steps > migrate_chunk() && (flags & SOLO_STEP_PHYSICS) && flags != SOLO_STEP_PHYSICS) {
         const int chunk = solo::migration_chunk_steps(steps, migrate_chunk());
         b.q_chunk = chunk;
         b.q_rings = solo::migration_rings(count);

@@ -105,7 +105,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   std::vector<int32_t> queue;
   B.queue = nullptr; B.q_rings = 1; B.q_chunk = 0;
   B.warm = wrm.empty() ? nullptr : wrm.data();
-  if (cfg->migrate_steps > 0 && steps > cfg->migrate_steps && (flags & SOLO_STEP_PHYSICS)) {
+  if (cfg->migrate_steps > 0 && steps > cfg->migrate_steps && (flags & SOLO_STEP_PHYSICS) && flags != SOLO_STEP_PHYSICS) {  // (as the engine: stepSimulation-only launches do not migrate)
     B.q_chunk = migration_chunk_steps(steps, cfg->migrate_steps);
     B.q_rings = n == 16 ? 8 : migration_rings(n);  // (16 robots: eight rings of two, so that the CPU suite walks several rings too)
     queue.resize(migration_queue_ints(n, steps, B.q_chunk));

@@ -63,8 +63,9 @@ def test_migration_is_bit_identical(dtype, n, spl, streams, k, chunk):
 
 
 def test_migration_physics_only_rollout_and_residual_threshold():
-  """The physics-only rollout (client.stepSimulation loops: flags = PHYSICS) and pybullet's residual threshold (an
-  opt-in with kernel instantiations of its own) under migration."""
+  """The physics-only rollout (client.stepSimulation loops: flags = PHYSICS - on a migrating engine it keeps the
+  physics-only, non-migrating instantiation: robots in step with each other, nothing to balance) and pybullet's
+  residual threshold (an opt-in with kernel instantiations of its own) under migration."""
   import torch
   n, k = 512, 24
   for resid in (0.0, 1e-7):
