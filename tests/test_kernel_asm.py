@@ -27,3 +27,28 @@ def test_the_check_sees_violations(tmp_path):
   n, errors = check_gpr_idx.check(str(bad))
   assert n == 4
   assert len(errors) == 3   # a vector instruction behind the switch; two compiler-generated switches outside a loop
+
+
+def test_resource_budget_of_the_product_kernels():
+  """What the kernels' occupancy rests on: f32 in 128 VGPRs (four waves per SIMD), f64 in 168
+  (three) - and no VGPR spill in the full, non-migrating instantiations: a spill's reload sits INSIDE the step, behind an
+  s_waitcnt vmcnt(0) that also waits for the step's action load (round 4: the f64 engine is a translation unit of its
+  own, compiled without machine LICM, for exactly that).  The migrating f64 instantiations may spill per TASK only."""
+  import re
+  subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'gym_solo_amd', 'csrc'), 'asm'], stderr=subprocess.DEVNULL)
+  text = open(os.path.join(ROOT, 'gym_solo_amd', 'csrc', 'solo_engine.gfx950.s')).read()
+  found = {}
+  # (one metadata block per kernel: "- .agpr_count: ... .name: ... .vgpr_count: N / .vgpr_spill_count: M")
+  for m in re.finditer(r'- \.agpr_count:.*?\.name:\s+(\S+)\n.*?\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)', text, re.S):
+    k = re.search(r'solo_step_kernelI(\w)Lb(\d)ELb(\d)ELb(\d)E', m.group(1))
+    if k:
+      found[(k.group(1), int(k.group(2)), int(k.group(3)), int(k.group(4)))] = (int(m.group(2)), int(m.group(3)))
+  assert len(found) == 12, sorted(found)   # {f, d} x {physics-only, full} x {default solver, residual threshold} + the four migrating ones
+  for (t, full, resid, migrate), (vgprs, spills) in found.items():
+    assert vgprs <= (128 if t == 'f' else 168), (t, full, resid, migrate, vgprs)
+    if t == 'f' and not migrate:
+      assert spills == 0, (t, full, resid, migrate, spills)
+    if t == 'd' and not migrate and not resid:
+      assert spills == 0, (t, full, resid, migrate, spills)
+    if migrate:
+      assert spills <= 8, (t, full, resid, migrate, spills)
