@@ -43,6 +43,10 @@ HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md ch
 NUM_SIMDS = 1024                                        # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 VALU_CYCLES_SHARED = 2                                  # wave64 VALU instruction on a SIMD-32 when >= 2 waves share
 VALU_CYCLES_ALONE = 4                                   # the SIMD; 4 for one wave alone (MI355X_MICROARCH.md constants)
+# f64 arithmetic issues at half the f32 rate (MI355X: 78.6 vs 157.3 vector TFLOP/s -> 4 cycles per wave64 instruction); 61 %
+# of the f64 step kernel's VALU instructions are f64 arithmetic (static count of the product assembly, tools/isa_line_profile.py d:
+# 1560 of 2562), the rest - moves, DPP, selects, integer, compares on 32-bit halves - 32-bit operations
+F64_ARITH_SHARE = 0.61
 SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICROARCH.md chip table
 METRIC = 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X'
 # REHEARSAL knobs (never set by the driver; tests/test_bench_launcher.py): SOLO_BENCH_ENGINE=emu runs the whole script -
@@ -235,7 +239,7 @@ def pmc_profile(dtype, spl, slices):
   return {}
 
 
-def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
+def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd, dtype='float32'):
   """The bound that actually binds (the path is bound by the instruction issue rate of one
   wave per robot, not by HBM): share of the chip's VALU issue capacity the launches use, from the VALU
   instruction count per env-step measured with rocprofv3 --pmc SQ_INSTS_VALU (profiles/)."""
@@ -243,11 +247,13 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd):
   if not valu:
     return 'dependent-issue-latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype', None
   cyc = VALU_CYCLES_SHARED if waves_per_simd >= 2 else VALU_CYCLES_ALONE
+  if dtype == 'float64':  # (the mean over the kernel's mix of f64 arithmetic and 32-bit operations)
+    cyc = cyc * (1.0 + F64_ARITH_SHARE)
   clock = pmc.get('effective_clock_hz') or SHADER_CLOCK_HZ  # measured (GRBM_GUI_ACTIVE / 8 / wall) when profiled
   simd_cycles = NUM_SIMDS * kern_ms * 1e-3 * clock
   util = chains * valu * env_steps_per_launch * cyc / simd_cycles
   return ('latency bound, not HBM bound: %.0f VALU instructions per env-step (rocprofv3 --pmc SQ_INSTS_VALU, '
-          'profiles/pmc_traffic.json) x %d cycles (wave64 on a SIMD-32 shared by %.0f waves, MI355X_MICROARCH.md) x %d '
+          'profiles/pmc_traffic.json) x %.1f cycles (wave64 on a SIMD-32 shared by %.0f waves, MI355X_MICROARCH.md; f64 arithmetic - 61 %% of the f64 kernel\'s VALU instructions - at half rate) x %d '
           'env-steps x %d concurrent launch chains = %.2f of the %d SIMDs\' VALU issue capacity over the measured launch '
           'duration at %.1f GHz; what binds is the issue rate of ONE wave per robot - 4.1 cycles per independent instruction, '
           '6.2 per instruction of the solver\'s serial row-update chain (tools/microbench/simd_rate.hip), %s instructions per '
@@ -483,7 +489,8 @@ def main():
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     pmc = pmc_profile(dtype, spl, slices)
     traffic = pmc['hbm_bytes_per_env_step'] * env_steps_per_launch if pmc.get('hbm_bytes_per_env_step') else None
-    note, secondary = secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, n / NUM_SIMDS)
+    # (waves resident per SIMD: the f32 kernel's 128 VGPRs allow four, the f64 kernel's 168 three)
+    note, secondary = secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, min(n / NUM_SIMDS, 4 if dtype == 'float32' else 3), dtype)
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
             'traffic_note': pmc.get('traffic_note'),
