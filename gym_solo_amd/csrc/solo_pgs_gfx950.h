@@ -287,24 +287,77 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 // 19 instructions per updated row (the compiler's loop over LDS-evaluated columns: ~40), no v_med3 in f64:
 // v_max_f64 + v_min_f64, exactly Real<double>::clamp.  Same rows, same order, same arithmetic as the C++ loop
 // (tests/test_gpu_pgs_asm.py compares the two bit for bit in f64 too).
+// The fixed registers of the f64 loop, by build: 168 VGPRs (three waves per SIMD: the product) - loop variables v[90:103], columns
+// v[104:167]; -DSOLO_F64_WAVES=4 (128 VGPRs: the four-waves A/B build, never the product) - v[50:63], v[64:127]
+#if defined(SOLO_F64_WAVES) && SOLO_F64_WAVES >= 4
+#define SOLO_PGS64_LAM "v[50:51]"
+#define SOLO_PGS64_LAM_LO "v50"
+#define SOLO_PGS64_LAM_HI "v51"
+#define SOLO_PGS64_CAND "v[52:53]"
+#define SOLO_PGS64_CAND_LO "v52"
+#define SOLO_PGS64_CAND_HI "v53"
+#define SOLO_PGS64_DL "v[54:55]"
+#define SOLO_PGS64_DL_LO "v54"
+#define SOLO_PGS64_DL_HI "v55"
+#define SOLO_PGS64_LO "v[56:57]"
+#define SOLO_PGS64_LO_LO "v56"
+#define SOLO_PGS64_LO_HI "v57"
+#define SOLO_PGS64_HI "v[58:59]"
+#define SOLO_PGS64_HI_LO "v58"
+#define SOLO_PGS64_HI_HI "v59"
+#define SOLO_PGS64_X1 "v[60:61]"
+#define SOLO_PGS64_X1_LO "v60"
+#define SOLO_PGS64_X1_HI "v61"
+#define SOLO_PGS64_X2 "v[62:63]"
+#define SOLO_PGS64_X2_LO "v62"
+#define SOLO_PGS64_X2_HI "v63"
+#define SOLO_PGS64_COL0 "v[64:65]"
+#define SOLO_PGS64_BANK0 "v[64:95]"
+#define SOLO_PGS64_BANK1 "v[96:127]"
+#else
+#define SOLO_PGS64_LAM "v[90:91]"
+#define SOLO_PGS64_LAM_LO "v90"
+#define SOLO_PGS64_LAM_HI "v91"
+#define SOLO_PGS64_CAND "v[92:93]"
+#define SOLO_PGS64_CAND_LO "v92"
+#define SOLO_PGS64_CAND_HI "v93"
+#define SOLO_PGS64_DL "v[94:95]"
+#define SOLO_PGS64_DL_LO "v94"
+#define SOLO_PGS64_DL_HI "v95"
+#define SOLO_PGS64_LO "v[96:97]"
+#define SOLO_PGS64_LO_LO "v96"
+#define SOLO_PGS64_LO_HI "v97"
+#define SOLO_PGS64_HI "v[98:99]"
+#define SOLO_PGS64_HI_LO "v98"
+#define SOLO_PGS64_HI_HI "v99"
+#define SOLO_PGS64_X1 "v[100:101]"
+#define SOLO_PGS64_X1_LO "v100"
+#define SOLO_PGS64_X1_HI "v101"
+#define SOLO_PGS64_X2 "v[102:103]"
+#define SOLO_PGS64_X2_LO "v102"
+#define SOLO_PGS64_X2_HI "v103"
+#define SOLO_PGS64_COL0 "v[104:105]"
+#define SOLO_PGS64_BANK0 "v[104:135]"
+#define SOLO_PGS64_BANK1 "v[136:167]"
+#endif
 #define SOLO_PGS_ROW64(PH)                                                                         \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
   "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
-  "v_readlane_b32 s94, v94, %[rs]\n\t"       /* the change of its impulse */                      \
-  "v_readlane_b32 s95, v95, %[rs]\n\t"                                                            \
+  "v_readlane_b32 s94, " SOLO_PGS64_DL_LO ", %[rs]\n\t"       /* the change of its impulse */                      \
+  "v_readlane_b32 s95, " SOLO_PGS64_DL_HI ", %[rs]\n\t"                                                            \
   "s_lshl_b32 %[ri], %[rs], 1\n\t"            /* register index of the column: 2 x row */          \
   "s_set_gpr_idx_on %[ri], gpr_idx(SRC0)\n\t"                                                      \
   "s_lshl_b64 %[t], -2, %[rs]\n\t"            /* (a scalar instruction between the mode switch and the indexed VALU instruction) */ \
-  "v_fma_f64 %[v], v[104:105], s[94:95], %[v]\n\t"  /* v += column * change (source 0 register-indexed) */ \
+  "v_fma_f64 %[v], " SOLO_PGS64_COL0 ", s[94:95], %[v]\n\t"  /* v += column * change (source 0 register-indexed) */ \
   "s_set_gpr_idx_off\n\t"                                                                          \
   "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor (and the wait state after the mode switch) */ \
-  "v_cndmask_b32_e32 v90, v90, v92, vcc\n\t"   /* lam[row] = cand[row] */                       \
-  "v_cndmask_b32_e32 v91, v91, v93, vcc\n\t"                                                    \
-  "v_max_f64 v[92:93], %[v], v[96:97]\n\t"                                                     \
-  "v_min_f64 v[92:93], v[92:93], v[98:99]\n\t"                                               \
-  "v_mul_f64 %[thr], %[tol], |v[90:91]|\n\t"                                                     \
-  "v_add_f64 v[94:95], v[92:93], -v[90:91]\n\t"                                              \
-  "v_cmp_gt_f64_e64 %[pend], |v[94:95]|, %[thr]\n\t"                                             \
+  "v_cndmask_b32_e32 " SOLO_PGS64_LAM_LO ", " SOLO_PGS64_LAM_LO ", " SOLO_PGS64_CAND_LO ", vcc\n\t"   /* lam[row] = cand[row] */                       \
+  "v_cndmask_b32_e32 " SOLO_PGS64_LAM_HI ", " SOLO_PGS64_LAM_HI ", " SOLO_PGS64_CAND_HI ", vcc\n\t"                                                    \
+  "v_max_f64 " SOLO_PGS64_CAND ", %[v], " SOLO_PGS64_LO "\n\t"                                                     \
+  "v_min_f64 " SOLO_PGS64_CAND ", " SOLO_PGS64_CAND ", " SOLO_PGS64_HI "\n\t"                                               \
+  "v_mul_f64 %[thr], %[tol], |" SOLO_PGS64_LAM "|\n\t"                                                     \
+  "v_add_f64 " SOLO_PGS64_DL ", " SOLO_PGS64_CAND ", -" SOLO_PGS64_LAM "\n\t"                                              \
+  "v_cmp_gt_f64_e64 %[pend], |" SOLO_PGS64_DL "|, %[thr]\n\t"                                             \
   SOLO_PGS_COUNT_ROW                                                                               \
   "s_and_b64 %[todo], %[pend], %[w]\n\t"
 
@@ -321,22 +374,22 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 // consecutive SLOTS, which may straddle a 16-lane row: DPP wave_shr:1 of the two dwords (x1 = the slot below), and
 // again for the slot two below (two wait states between a VALU write and the DPP read of it)
 #define SOLO_PGS_LIMITS64                                                                          \
-  "v_mov_b32_dpp v100, v90 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
-  "v_mov_b32_dpp v101, v91 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
+  "v_mov_b32_dpp " SOLO_PGS64_X1_LO ", " SOLO_PGS64_LAM_LO " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
+  "v_mov_b32_dpp " SOLO_PGS64_X1_HI ", " SOLO_PGS64_LAM_HI " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                 \
   "s_nop 0\n\t"                                                                                   \
-  "v_mov_b32_dpp v102, v100 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
-  "v_mov_b32_dpp v103, v101 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
-  "v_cndmask_b32_e64 v100, v102, v100, %[tan1]\n\t"                                                \
-  "v_cndmask_b32_e64 v101, v103, v101, %[tan1]\n\t"                                                \
-  "v_mul_f64 v[100:101], %[mu], v[100:101]\n\t"                                                    \
-  "v_cndmask_b32_e64 v96, v96, v100, %[tang]\n\t"    /* lo = -lim (the sign lives in the high dword) */ \
-  "v_cndmask_b32_e64 v97, v97, -v101, %[tang]\n\t"                                               \
-  "v_cndmask_b32_e64 v98, v98, v100, %[tang]\n\t"    /* hi = lim */                              \
-  "v_cndmask_b32_e64 v99, v99, v101, %[tang]\n\t"                                                \
-  "v_max_f64 v[92:93], %[v], v[96:97]\n\t"                                                     \
-  "v_min_f64 v[92:93], v[92:93], v[98:99]\n\t"                                               \
-  "v_add_f64 v[94:95], v[92:93], -v[90:91]\n\t"                                              \
-  "v_cmp_gt_f64_e64 %[pend], |v[94:95]|, %[thr]\n\t"
+  "v_mov_b32_dpp " SOLO_PGS64_X2_LO ", " SOLO_PGS64_X1_LO " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+  "v_mov_b32_dpp " SOLO_PGS64_X2_HI ", " SOLO_PGS64_X1_HI " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+  "v_cndmask_b32_e64 " SOLO_PGS64_X1_LO ", " SOLO_PGS64_X2_LO ", " SOLO_PGS64_X1_LO ", %[tan1]\n\t"                                                \
+  "v_cndmask_b32_e64 " SOLO_PGS64_X1_HI ", " SOLO_PGS64_X2_HI ", " SOLO_PGS64_X1_HI ", %[tan1]\n\t"                                                \
+  "v_mul_f64 " SOLO_PGS64_X1 ", %[mu], " SOLO_PGS64_X1 "\n\t"                                                    \
+  "v_cndmask_b32_e64 " SOLO_PGS64_LO_LO ", " SOLO_PGS64_LO_LO ", " SOLO_PGS64_X1_LO ", %[tang]\n\t"    /* lo = -lim (the sign lives in the high dword) */ \
+  "v_cndmask_b32_e64 " SOLO_PGS64_LO_HI ", " SOLO_PGS64_LO_HI ", -" SOLO_PGS64_X1_HI ", %[tang]\n\t"                                               \
+  "v_cndmask_b32_e64 " SOLO_PGS64_HI_LO ", " SOLO_PGS64_HI_LO ", " SOLO_PGS64_X1_LO ", %[tang]\n\t"    /* hi = lim */                              \
+  "v_cndmask_b32_e64 " SOLO_PGS64_HI_HI ", " SOLO_PGS64_HI_HI ", " SOLO_PGS64_X1_HI ", %[tang]\n\t"                                                \
+  "v_max_f64 " SOLO_PGS64_CAND ", %[v], " SOLO_PGS64_LO "\n\t"                                                     \
+  "v_min_f64 " SOLO_PGS64_CAND ", " SOLO_PGS64_CAND ", " SOLO_PGS64_HI "\n\t"                                               \
+  "v_add_f64 " SOLO_PGS64_DL ", " SOLO_PGS64_CAND ", -" SOLO_PGS64_LAM "\n\t"                                              \
+  "v_cmp_gt_f64_e64 %[pend], |" SOLO_PGS64_DL "|, %[thr]\n\t"
 
 __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, double& v, double& lam, double& cand, double& dl,
                                                 unsigned long long& pend, double& lo, double& hi, double tol, int lane, double mu,
@@ -391,16 +444,16 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, dou
       SOLO_PGS_LIMITS64
       "s_branch .Lpgs64_%=_b2\n"
       ".Lpgs64_%=_done:\n\t"
-      : [v] "+v"(v), "={v[90:91]}"(lam_o), "={v[92:93]}"(cand_o), "={v[94:95]}"(dl_o), "={v[96:97]}"(lo_o), "={v[98:99]}"(hi_o),
-        "=&{v[100:101]}"(x1), "=&{v[102:103]}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
+      : [v] "+v"(v), "={" SOLO_PGS64_LAM "}"(lam_o), "={" SOLO_PGS64_CAND "}"(cand_o), "={" SOLO_PGS64_DL "}"(dl_o), "={" SOLO_PGS64_LO "}"(lo_o), "={" SOLO_PGS64_HI "}"(hi_o),
+        "=&{" SOLO_PGS64_X1 "}"(x1), "=&{" SOLO_PGS64_X2 "}"(x2), [pend] "+s"(pend), [thr] "=&v"(thr),
         [w] "=&s"(w), [t] "=&s"(t), [todo] "=&s"(todo), [rs] "=&s"(rs), [ri] "=&s"(ri), [it] "=&s"(it)
 #ifdef SOLO_STAMPS
         , [nch] "+s"(n_changed)
 #endif
-      : "{v[90:91]}"(lam), "{v[92:93]}"(cand), "{v[94:95]}"(dl), "{v[96:97]}"(lo), "{v[98:99]}"(hi),
+      : "{" SOLO_PGS64_LAM "}"(lam), "{" SOLO_PGS64_CAND "}"(cand), "{" SOLO_PGS64_DL "}"(dl), "{" SOLO_PGS64_LO "}"(lo), "{" SOLO_PGS64_HI "}"(hi),
         [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
         [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes),
-        "{v[104:135]}"(A.a0), "{v[136:167]}"(A.a1)
+        "{" SOLO_PGS64_BANK0 "}"(A.a0), "{" SOLO_PGS64_BANK1 "}"(A.a1)
       : "vcc", "scc", "s94", "s95");
   lam = lam_o; cand = cand_o; dl = dl_o; lo = lo_o; hi = hi_o;
   (void)n_changed; (void)x1; (void)x2;

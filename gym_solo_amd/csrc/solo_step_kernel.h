@@ -133,6 +133,15 @@ namespace solo {
 #define SOLO_PRIO_SWEEPS_F64 12
 #endif
 template <typename T> constexpr int kPrioSweeps = sizeof(T) == 4 ? 8 : SOLO_PRIO_SWEEPS_F64;
+// The block of LDS that holds a step's constraint rows - f32: [64 rows][ghat 6, hhat 2] and the joint-space parts again by
+// leg slot [64][4 legs x 2]; f64 (slot space): [64 slots][ghat 6, hhat 2], the legs are tags of their own - and is the
+// scratch of whatever runs while the rows are dead: the f64 post-solve reduction (kReduceScratch) and the output
+// epilogue's reward values [SOLO_MAX_REWARD_OPS][steps of a pass].  f64: 896 reals = 28 steps per pass (at FOUR waves
+// per SIMD - the A/B build - what fits 10 KB of LDS: 25).
+#ifndef SOLO_F64_WAVES
+#define SOLO_F64_WAVES 3   // (-DSOLO_F64_WAVES=2 / 4: the A/B builds of tools/gpu_occupancy_sweep.py, never the product)
+#endif
+template <typename T> constexpr int kRowBlockReals = sizeof(T) == 4 ? 64 * 8 + 64 * 8 : (SOLO_F64_WAVES >= 4 ? 800 : 896);
 constexpr int kLegSlots = 26;  // per-leg parking lot in LDS (see physics_solve): 0-11 K, 12-14 Lp factors, 15-16 unconstrained joint rates, 17-18 q, 19-22 cos / sin of the two link angles, 23-24 P^-1 h
 
 // one lane's constraint-row constants, as the step reads them from LDS (staged from KParams::row once per launch)
@@ -217,7 +226,7 @@ __device__ __forceinline__ int pgs_solve_cpp(const ColumnBank<T>& A, T& v, T& la
 // ------------------------------------------------------------------------------------------
 template <typename T, bool kResid>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
-                                           const RowView<T>& rc, const T* s_state, T my_target, T* s_rowvec, T (*s_hext)[8],
+                                           const RowView<T>& rc, const T* s_state, T my_target, T* s_rowvec, T (*s_hext)[8], unsigned char* s_rowleg,
                                            T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& row_at, bool& target_bad,
                                            int& prio_sweeps, int& prio_steps, int& prio_rot, T warm_in = T(0), bool warm_on = false) {
   constexpr bool kCompact = ColumnBank<T>::kCompact;   // the solver runs in slot space (see "slot space" below)
@@ -665,12 +674,10 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     row_at = dst;
 #pragma unroll
     for (int i = 0; i < 6; ++i) s_rowvec[dst * kRS + i] = gh[i];
-    // the joint-space part in the slot of the row's leg, zeros in the other three (the leg of a slot changes from step
-    // to step: all eight are written - zeros first, then the pair: the DS operations of a wave execute in order)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s_hext[dst][i] = T(0);
-    s_hext[dst][2 * leg] = hh[0];
-    s_hext[dst][2 * leg + 1] = hh[1];
+    // the joint-space part behind it, and the row's leg as the slot's tag (it counts only between rows of one leg)
+    s_rowvec[dst * kRS + 6] = hh[0];
+    s_rowvec[dst * kRS + 7] = hh[1];
+    s_rowleg[dst] = (unsigned char)leg;
     const int tl = wave_push_int(sv_type | (leg << 4), dst);
     sv_v0 = wave_push(sv_v0, dst);
     sv_nid = wave_push(sv_nid, dst);
@@ -680,8 +687,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     wave_sync();
 #pragma unroll
     for (int i = 0; i < 6; ++i) sg[i] = s_rowvec[lane * kRS + i];
-    sh[0] = s_hext[lane][2 * sv_leg];
-    sh[1] = s_hext[lane][2 * sv_leg + 1];
+    sh[0] = s_rowvec[lane * kRS + 6];
+    sh[1] = s_rowvec[lane * kRS + 7];
   }
 
   SOLO_STAMP(B, 7);
@@ -695,7 +702,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // (f64: the columns of the first ColumnBank<double>::kSlots = 32 SLOTS, 64 VGPRs; a step with more live rows
   // builds none and takes the overflow path below.)
   ColumnBank<T> A;
-  A.init(sg, sh, sv_nid, lane, s_rowvec, &s_hext[0][2 * sv_leg]);  // (+ 8 r: row r's joint-space part if r is on this lane's leg, else 0)
+  if constexpr (kCompact) A.init(sg, sh, sv_nid, lane, s_rowvec, s_rowleg, sv_leg);
+  else A.init(sg, sh, sv_nid, lane, s_rowvec, &s_hext[0][2 * sv_leg]);  // (+ 8 r: row r's joint-space part if r is on this lane's leg, else 0)
   const bool overflow = kCompact && n_live > ColumnBank<T>::kSlots;  // (wave-uniform)
   if constexpr (!kCompact) {
 #pragma unroll
@@ -877,9 +885,9 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
 // post-solve half: apply the impulses (du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam -
 // K du_b), go back to world-frame velocities and integrate.  Everything is re-read from LDS.
 template <typename T>
-__device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, T* s_scratch, const T (*s_hext)[8],
+__device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state, T* s_scratch,
                                                const T* s_keep, const T (*s_leg)[kLegSlots], const T* s_math, T lam, int lane, int row_at) {
-  const T* const s_rowvec = s_scratch;  // (the row vectors; with s_hext behind them the scratch of the f64 reduction below)
+  const T* const s_rowvec = s_scratch;  // (the row vectors; the block they head is the scratch of the f64 reduction below)
   if constexpr (sizeof(T) == 8) lane = wave_opaque_lane(lane);  // (f64: per-lane LDS addresses are re-derived here - shared with physics_solve they lived across the whole solver, as a spill)
   using R = Real<T>;
   constexpr int kRS = ColumnBank<T>::kRowStride;
@@ -890,17 +898,12 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
   T z[6], yl[2];
 #pragma unroll
   for (int i = 0; i < 6; ++i) z[i] = s_rowvec[row_at * kRS + i] * lam;
-  if constexpr (ColumnBank<T>::kCompact) {  // (slot space: the row vectors carry no joint-space part; it sits in the slot of the row's leg)
-    yl[0] = s_hext[row_at][2 * leg] * lam;
-    yl[1] = s_hext[row_at][2 * leg + 1] * lam;
-  } else {
-    yl[0] = s_rowvec[row_at * kRS + 6] * lam;
-    yl[1] = s_rowvec[row_at * kRS + 7] * lam;
-  }
+  yl[0] = s_rowvec[row_at * kRS + 6] * lam;   // (the row this lane built is a row of this lane's leg)
+  yl[1] = s_rowvec[row_at * kRS + 7] * lam;
   if constexpr (ColumnBank<T>::kCompact) {
     // f64: through LDS (solo_wave_ops.h: a third of the instructions of the DPP chains) - the row-vector block is the
     // scratch: every lane has just taken what it needs of it (wave_sync: the reads above come first)
-    static_assert(64 * kRS + 64 * 8 >= kReduceScratch, "the row-vector block holds the reduction's scratch");
+    static_assert(kRowBlockReals<T> >= kReduceScratch, "the row-vector block holds the reduction's scratch");
     wave_sync();
     wave_reduce_rows_lds(z, yl, s_scratch, lane);
   } else {
@@ -971,9 +974,6 @@ __device__ __forceinline__ void physics_finish(const StepConst<T>& C, T* s_state
 // kFull = false: physics-only instantiation (flags are treated as SOLO_STEP_PHYSICS).
 // single-step launches evaluate their outputs in the step kernel itself (see the step loop): f32 only
 template <typename T, bool kFull> constexpr bool kInlineOutputs = kFull;
-#ifndef SOLO_F64_WAVES
-#define SOLO_F64_WAVES 3   // (-DSOLO_F64_WAVES=2: the A/B build of tools/gpu_occupancy_sweep.py, never the product)
-#endif
 template <typename T> constexpr int kWavesPerSimd = sizeof(T) == 4 ? 4 : SOLO_F64_WAVES;
 
 template <typename T, bool kFull, bool kResid = false, bool kMigrate = false>
@@ -986,21 +986,27 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   // physics_solve; zero except the row's own leg) and the per-row geometry [64][centre 3, radius] - the output epilogue
   // (where all three are dead) uses it as its 1024-value scratch
   constexpr int kRS = ColumnBank<T>::kRowStride;
-  constexpr int kRowsReals = 64 * kRS + 64 * 8;
-  __shared__ T s_blk[kRowsReals + 64 * 4];
-  static_assert(kRowsReals + 64 * 4 >= SOLO_MAX_REWARD_OPS * 32, "the output epilogue's scratch");
+  constexpr int kRowsReals = kRowBlockReals<T>;
+  // (the geometry table has one entry per SPHERE - a contact's three rows share it - and an all-zero entry for the rows
+  // that have none: as [64 rows][4] it was 2 KB of the f64 kernel's 13.2 KB, and 13.2 KB round up to eleven LDS
+  // allocation granules of 1280 B: ELEVEN workgroups per CU where the registers allow twelve - round 5)
+  constexpr int kGeoRows = SOLO_MAX_SPHERES + 1;
+  __shared__ T s_blk[kRowsReals + kGeoRows * 4];
+  static_assert(kRowsReals >= SOLO_MAX_REWARD_OPS * (kRowsReals / SOLO_MAX_REWARD_OPS < 32 ? kRowsReals / SOLO_MAX_REWARD_OPS : 32), "the output epilogue's scratch");
   T* const s_rowvec = s_blk;
-  T (*const s_hext)[8] = reinterpret_cast<T (*)[8]>(s_blk + 64 * kRS);
+  T (*const s_hext)[8] = ColumnBank<T>::kCompact ? nullptr : reinterpret_cast<T (*)[8]>(s_blk + 64 * kRS);
+  __shared__ unsigned char s_rowleg[64];  // (slot space: the leg of every slot's row)
   T (*const s_rowgeo)[4] = reinterpret_cast<T (*)[4]>(s_blk + kRowsReals);
-  __shared__ int32_t s_rowtype[64];  // RowConst::type | RowConst::body << 8
+  __shared__ int32_t s_rowtype[64];  // RowConst::type | RowConst::body << 8 | geometry entry << 16
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][kLegSlots];
   // termination (termination.py:38-83), one lane per termination (lanes >= SOLO_MAX_TERMS: never fire):
   // s_cnt = TimeBased step counters, s_termlim = the count above which lane t fires (-1: always - a
   // Constant(True) -, INT_MAX: never), s_termtick = 1 for the lanes whose counter ticks (TimeBased)
-  __shared__ int s_cnt[64];
-  __shared__ int s_termlim[64];
-  __shared__ int s_termtick[64];
+  // (SOLO_MAX_TERMS entries each: as [64] they were 768 B for four live entries)
+  __shared__ int s_cnt[SOLO_MAX_TERMS];
+  __shared__ int s_termlim[SOLO_MAX_TERMS];
+  __shared__ int s_termtick[SOLO_MAX_TERMS];
   // per-lane constant tables, staged ONCE per launch (a launch fuses many steps): the steps then
   // read them from LDS instead of paying a global-load latency each
   __shared__ LegConst<T> s_legc[4];
@@ -1073,10 +1079,14 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     int32_t* const_dst = reinterpret_cast<int32_t*>(&s_const);
 #pragma unroll
     for (int j = 0; j < kLegLoads; ++j) if (lane0 + 64 * j < kLegWords) leg_dst[lane0 + 64 * j] = leg_w[j];
-    s_rowtype[lane0] = row_w.type | (row_w.body << 8);
+    const bool has_geo = row_w.type >= ROW_NORMAL && row_w.type <= ROW_TAN2;   // (row_w.dof: the row's model sphere)
+    s_rowtype[lane0] = row_w.type | (row_w.body << 8) | ((has_geo ? row_w.dof : SOLO_MAX_SPHERES) << 16);
+    if (row_w.type == ROW_NORMAL) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) s_rowgeo[lane0][i] = row_w.center[i];
-    s_rowgeo[lane0][3] = row_w.radius;
+      for (int i = 0; i < 3; ++i) s_rowgeo[row_w.dof][i] = row_w.center[i];
+      s_rowgeo[row_w.dof][3] = row_w.radius;
+    }
+    if (lane0 < 4) s_rowgeo[SOLO_MAX_SPHERES][lane0] = T(0);
 #pragma unroll
     for (int j = 0; j < kConstLoads; ++j) if (lane0 + 64 * j < kConstWords) const_dst[lane0 + 64 * j] = const_w[j];
     if constexpr (Real<T>::kTabSize > 0) { if (lane0 < Real<T>::kTabSize) s_math[lane0] = math_w; }
@@ -1086,8 +1096,10 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     const int tl = lane0 & (SOLO_MAX_TERMS - 1);
     const int kind = s_const.term_kind[tl], param = s_const.term_param[tl];
     const bool mine = lane0 < s_const.num_terms;  // (num_terms <= SOLO_MAX_TERMS)
-    s_termlim[lane0] = (mine && kind == SOLO_T_TIME) ? param : ((mine && kind == SOLO_T_CONST && param != 0) ? -1 : 0x7fffffff);
-    s_termtick[lane0] = (mine && kind == SOLO_T_TIME) ? 1 : 0;
+    if (lane0 < SOLO_MAX_TERMS) {
+      s_termlim[lane0] = (mine && kind == SOLO_T_TIME) ? param : ((mine && kind == SOLO_T_CONST && param != 0) ? -1 : 0x7fffffff);
+      s_termtick[lane0] = (mine && kind == SOLO_T_TIME) ? 1 : 0;
+    }
   };
   if constexpr (kMigrate) {  // once per wave, in front of the task loop
     load_tables();
@@ -1144,7 +1156,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   const size_t rec = (size_t)env * SOLO_STATE_STRIDE;
   // (lane = row keeps the joint-space parts of dead legs' slots at zero - they are written once: here, and again after
   // an output epilogue has used the block as scratch; slot space rewrites all eight every step)
-  if constexpr (!kMigrate || !ColumnBank<T>::kCompact) {
+  if constexpr (!ColumnBank<T>::kCompact) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) s_hext[lane0][i] = T(0);
   }
@@ -1182,7 +1194,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   {
     if constexpr (!kMigrate) store_tables();
     if (lane0 < SOLO_STATE_STRIDE) s_state[lane0] = state_w;
-    s_cnt[lane0] = count_w;
+    if (lane0 < SOLO_MAX_TERMS) s_cnt[lane0] = count_w;
     // f64: the robot's friction coefficient and base-mass scale wait in LDS, not in two register pairs held across the
     // whole step loop (the f64 kernel lives on 168 VGPRs: see physics_solve, "PARK EARLY")
     if constexpr (sizeof(T) == 8) { if (lane0 == 0) { s_keep[27] = mu; s_keep[28] = mass_scale; } }
@@ -1223,7 +1235,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     const T* const actions = have_actions ? B.actions : nullptr;
     const LegConst<T>& L = s_legc[lane >> 4];
     const int row_tb = s_rowtype[lane];
-    const RowView<T> rc = {row_tb & 255, row_tb >> 8, s_rowgeo[lane]};
+    const RowView<T> rc = {row_tb & 255, (row_tb >> 8) & 255, s_rowgeo[row_tb >> 16]};
     // setJointMotorControlArray (solo8v2vanilla.py:87-90): every motor lane fetches the target of ITS
     // joint straight from global memory.  The value is consumed when the motor rows are built,
     // thousands of cycles into the step, so the load's latency is never waited for (funnelled
@@ -1261,13 +1273,13 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       const T my_target = raw_target * target_scale;
       bool target_bad = false;  // (set on a motor lane whose target is not finite)
       int row_at;  // where this lane's constraint row sits in s_rowvec / s_hext (its lane, or its slot: see physics_solve)
-      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, target_bad, prio_sweeps, prio_steps, prio_rot,
+      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_rowleg, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, target_bad, prio_sweeps, prio_steps, prio_rot,
                                              warm_in, kResid && warm_row != nullptr);
       if constexpr (kResid) if (warm_row != nullptr) {
         if constexpr (kMigrate) wave_store_shared(warm_row + (size_t)env * 64 + lane, lam);
         else warm_row[(size_t)env * 64 + lane] = lam;
       }
-      physics_finish<T>(C, s_state, s_rowvec, s_hext, s_keep, s_leg, s_math, lam, lane, row_at);
+      physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, s_math, lam, lane, row_at);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted
       const bool bad = (lane < SOLO_S_RETURN && !R::finite(s_state[lane & 31])) || (kLean ? target_bad : (motor_lane && !R::finite(my_target)));
@@ -1289,11 +1301,13 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     //      later ones are not ticked (termination.py:46-48).  Branch-free: ~14 instructions.
     bool done = false;
     if (B.flags & SOLO_STEP_DONE) {
-      const int old = s_cnt[lane];
-      const unsigned long long fired = wave_ballot(old + 1 > s_termlim[lane]);
+      const int tl = lane & (SOLO_MAX_TERMS - 1);
+      const bool term_lane = lane < SOLO_MAX_TERMS;
+      const int old = s_cnt[tl];
+      const unsigned long long fired = wave_ballot(term_lane && old + 1 > s_termlim[tl]);
       done = fired != 0ull;
       const int first = done ? __builtin_ctzll(fired) : 63;  // wave-uniform
-      s_cnt[lane] = old + ((s_termtick[lane] != 0 && lane <= first) ? 1 : 0);
+      if (term_lane) s_cnt[tl] = old + ((s_termtick[tl] != 0 && lane <= first) ? 1 : 0);
     }
     const bool restart = may_restart && (done || diverged);
     // ---- the step's record for the output epilogue (end of this kernel): the state after the step, before
@@ -1357,7 +1371,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       if (restart) {
         wave_sync();  // the record above is read from the old state first
         if (lane < SOLO_S_RETURN) s_state[lane] = wave_cold_args(Bin)->snapshot[rec + lane];
-        s_cnt[lane] = 0;
+        if (lane < SOLO_MAX_TERMS) s_cnt[lane] = 0;
         if constexpr (kResid) if (warm_row != nullptr) {  // (... and so does a robot that starts a new episode)
           if constexpr (kMigrate) wave_store_shared(warm_row + (size_t)env * 64 + lane, T(0));
           else warm_row[(size_t)env * 64 + lane] = T(0);
@@ -1368,8 +1382,10 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
           else wave_cold_args(Bin)->targets[(size_t)env * SOLO_NUM_JOINTS + lane] = C.settle_tgt[lane];
         }
       }
-      // (a launch that leaves records has its done flags written by the output epilogue, from slot 31)
-      if (B.traj == nullptr && lane == 0) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
+      // (a launch that leaves records has its done flags written by the output epilogue, from slot 31; one that keeps
+      // only the view's flag - done_stride = 0 - writes the LAST step's: in a migrating launch the steps of a robot run
+      // on waves of different XCDs, whose L2s would write their plain stores to the one byte back in any order)
+      if (B.traj == nullptr && lane == 0 && (B.done_stride != 0 || step == B.steps - 1)) B.done[(size_t)step * B.done_stride + env] = done ? 1 : 0;
     }
     SOLO_STAMP(B, 12);
     wave_sync();  // this step's LDS state is complete before the next step reads it

@@ -247,6 +247,13 @@ template <typename T> struct RowDot {
     const T a2 = __builtin_fma(g[5], rg[5], __builtin_fma(g[4], rg[4], g[3] * rg[3]));
     return (a1 + a2) + __builtin_fma(h[1], rh[1], h[0] * rh[0]);
   }
+  // the same with the joint-space part counted only between rows of ONE leg: `same` = 1 (same leg) or 0 - one fused
+  // multiply-add rounds exactly like the sum above (x 1) or leaves the base part alone (x 0)
+  __device__ __forceinline__ T dot(const T* rg, const T* rh, T same) const {
+    const T a1 = __builtin_fma(g[2], rg[2], __builtin_fma(g[1], rg[1], g[0] * rg[0]));
+    const T a2 = __builtin_fma(g[5], rg[5], __builtin_fma(g[4], rg[4], g[3] * rg[3]));
+    return __builtin_fma(same, __builtin_fma(h[1], rh[1], h[0] * rh[0]), a1 + a2);
+  }
 };
 template <> struct RowDot<float> {
   solo_f32x2 g01, g23, g45, h01;
@@ -303,42 +310,48 @@ template <> struct ColumnBank<float> {
 // and the bank holds the columns of slots 0 .. 31 only: 32 doubles per lane = 64 VGPRs -> the kernel fits the 168
 // VGPRs of THREE waves per SIMD.  A step with more than 32 live rows (a robot lying on everything it has) takes the
 // overflow path: the same iteration with every column evaluated from LDS when it is used (column(), the expression
-// build() stores) - slower per row, the same bits.  Row vectors in LDS: 6 doubles per row (the joint-space part
-// lives in the per-leg slots of s_hext only).
+// build() stores) - slower per row, the same bits.  Row vectors in LDS: 8 doubles per slot (ghat 6, hhat 2) and the
+// leg of the slot's row as a tag of its own (round 5).
 typedef double solo_f64x16 __attribute__((ext_vector_type(16)));
 template <> struct ColumnBank<double> {
   static constexpr bool kResident = true;
   static constexpr bool kCompact = true;
-  static constexpr int kSlots = 32, kRowStride = 6;
+  static constexpr int kSlots = 32, kRowStride = 8;
   static constexpr int kBanks = 2;
   static __device__ __forceinline__ constexpr unsigned long long bank_lanes(int b) { return 0xffffull << (16 * b); }
   RowDot<double> own;
   double nid;
   int lane;
-  const double* rowvec;
-  const double* hext;
+  const double* rowvec;        // [64 slots][ghat 6, hhat 2]
+  const unsigned char* rowleg;  // [64 slots]: the leg of the slot's row ("same leg" is a compare of two tags: round 5 - rounds 3-4
+  int leg;                      // kept a [64][4 legs x 2] array with the pair in the slot of the row's leg, 4 KB of LDS)
   solo_f64x16 a0, a1;
-  __device__ __forceinline__ void init(const double* gh, const double* hh, double nid_, int lane_, const double* rowvec_, const double* hext_) {
-    own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; hext = hext_;
+  __device__ __forceinline__ void init(const double* gh, const double* hh, double nid_, int lane_, const double* rowvec_, const unsigned char* rowleg_, int leg_) {
+    own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; rowleg = rowleg_; leg = leg_;
   }
-  __device__ __forceinline__ double column(int r) const { const double m = (lane == r) ? 0.0 : nid; return m * own.dot(rowvec + kRowStride * r, hext + 8 * r); }
+  __device__ __forceinline__ double same_leg(int leg_r) const { return leg_r == leg ? 1.0 : 0.0; }
+  __device__ __forceinline__ double column(int r) const {
+    const double m = (lane == r) ? 0.0 : nid;
+    return m * own.dot(rowvec + kRowStride * r, rowvec + kRowStride * r + 6, same_leg(rowleg[r]));
+  }
   __device__ __forceinline__ void build(int r) {
     const double x = column(r);
     if (r < 16) a0[r] = x; else a1[r - 16] = x;
   }
   // the same in two halves, for a build that fetches slot r + 1's row while it computes slot r's column (the LDS
   // broadcasts of the next row are in flight behind the arithmetic of this one: solo_step_kernel.h)
-  struct Row { double g[6], h[2]; };
+  struct Row { double g[6], h[2]; int leg; };
   __device__ __forceinline__ Row fetch(int r) const {
     Row x;
 #pragma unroll
     for (int i = 0; i < 6; ++i) x.g[i] = rowvec[kRowStride * r + i];
-    x.h[0] = hext[8 * r]; x.h[1] = hext[8 * r + 1];
+    x.h[0] = rowvec[kRowStride * r + 6]; x.h[1] = rowvec[kRowStride * r + 7];
+    x.leg = rowleg[r];
     return x;
   }
   __device__ __forceinline__ void build_from(int r, const Row& x) {
     const double m = (lane == r) ? 0.0 : nid;
-    const double c = m * own.dot(x.g, x.h);
+    const double c = m * own.dot(x.g, x.h, same_leg(x.leg));
     if (r < 16) a0[r] = c; else a1[r - 16] = c;
   }
   __device__ __forceinline__ double get(int bank, int r) const { return bank == 0 ? a0[r & 15] : a1[r & 15]; }
@@ -374,7 +387,13 @@ __device__ __forceinline__ float wave_load_shared(const float* p) { return __uin
 __device__ __forceinline__ double wave_load_shared(const double* p) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ void wave_store_shared(float* p, float v) { __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wave_store_shared(double* p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void wave_release_device() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// (the workgroup-scope fence is a COMPILER barrier only - on gfx950 it emits no instruction -, so the wait is written
+// out: every store and atomic this wave has issued has been acknowledged by the coherence point before anything behind
+// this line is issued.  tests/test_kernel_asm.py looks for it in front of every ring-slot publication.)
+__device__ __forceinline__ void wave_release_device() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ void wave_acquire_device() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 __device__ __forceinline__ void wave_backoff() { __builtin_amdgcn_s_sleep(8); }
 // the XCD this wave runs on (hardware register XCC_ID)

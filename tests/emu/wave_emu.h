@@ -149,6 +149,11 @@ template <typename T> struct RowDot {
     const T a2 = g[3] * rg[3] + g[4] * rg[4] + g[5] * rg[5];
     return (a1 + a2) + (h[0] * rh[0] + h[1] * rh[1]);
   }
+  T dot(const T* rg, const T* rh, T same) const {  // (slot space: the joint-space part counts between rows of one leg)
+    const T a1 = g[0] * rg[0] + g[1] * rg[1] + g[2] * rg[2];
+    const T a2 = g[3] * rg[3] + g[4] * rg[4] + g[5] * rg[5];
+    return (a1 + a2) + same * (h[0] * rh[0] + h[1] * rh[1]);
+  }
 };
 
 // the register-resident matrix of the GPU build (solo_wave_ops.h ColumnBank<T>) as a plain array.  Like the GPU
@@ -156,30 +161,41 @@ template <typename T> struct RowDot {
 template <typename T> struct ColumnBank {
   static constexpr bool kResident = true;
   static constexpr bool kCompact = sizeof(T) == 8;
-  static constexpr int kSlots = kCompact ? 32 : 64, kRowStride = kCompact ? 6 : 8;
+  static constexpr int kSlots = kCompact ? 32 : 64, kRowStride = 8;
   static constexpr int kBanks = 1;
   static constexpr unsigned long long bank_lanes(int) { return ~0ull; }
   RowDot<T> own;
   T nid;
   int lane;
   const T* rowvec;
-  const T* hext;
+  const T* hext = nullptr;                 // lane = row (f32): the joint-space parts by leg slot
+  const unsigned char* rowleg = nullptr;   // slot space (f64): the leg of every slot's row, and this lane's
+  int leg = 0;
   T a[64];
   void init(const T* gh, const T* hh, T nid_, int lane_, const T* rowvec_, const T* hext_) {
     own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; hext = hext_;
     for (int r = 0; r < 64; ++r) a[r] = std::nan("");  // a column that was never built must never be used
   }
-  T column(int r) const { const T m = (lane == r) ? T(0) : nid; return m * own.dot(rowvec + kRowStride * r, hext + 8 * r); }
+  void init(const T* gh, const T* hh, T nid_, int lane_, const T* rowvec_, const unsigned char* rowleg_, int leg_) {
+    own.set(gh, hh); nid = nid_; lane = lane_; rowvec = rowvec_; rowleg = rowleg_; leg = leg_;
+    for (int r = 0; r < 64; ++r) a[r] = std::nan("");
+  }
+  T column(int r) const {
+    const T m = (lane == r) ? T(0) : nid;
+    if (kCompact) return m * own.dot(rowvec + kRowStride * r, rowvec + kRowStride * r + 6, rowleg[r] == leg ? T(1) : T(0));
+    return m * own.dot(rowvec + kRowStride * r, hext + 8 * r);
+  }
   void build(int r) { a[r] = column(r); }
   // (the pipelined build of the slot-space kernel: solo_wave_ops.h)
-  struct Row { T g[6], h[2]; };
+  struct Row { T g[6], h[2]; int leg; };
   Row fetch(int r) const {
     Row x;
     for (int i = 0; i < 6; ++i) x.g[i] = rowvec[kRowStride * r + i];
-    x.h[0] = hext[8 * r]; x.h[1] = hext[8 * r + 1];
+    x.h[0] = rowvec[kRowStride * r + 6]; x.h[1] = rowvec[kRowStride * r + 7];
+    x.leg = rowleg[r];
     return x;
   }
-  void build_from(int r, const Row& x) { const T m = (lane == r) ? T(0) : nid; a[r] = m * own.dot(x.g, x.h); }
+  void build_from(int r, const Row& x) { const T m = (lane == r) ? T(0) : nid; a[r] = m * own.dot(x.g, x.h, x.leg == leg ? T(1) : T(0)); }
   T get(int, int r) const { return a[r]; }
 };
 

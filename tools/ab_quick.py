@@ -1,0 +1,113 @@
+"""Same-call A/B of engine-library builds on the bench workload (boxes differ by 2-3 %: only numbers from ONE gpurun
+call compare).  Every library is measured in a child process of its own (SOLO_HIP_LIB is read at import), the
+libraries alternate, REPS rounds:
+
+  gpurun -- python tools/ab_quick.py [--reps 3] [--dtype float64] [--legs k20,closed,s250] [--n 4096] libA.so libB.so ...
+
+(library names are files under gym_solo_amd/csrc; a name may carry settings: libX.so:migrate=0:streams=2:n=8192).
+Legs: k20 = the driver's geometry (ONE launch of N x 20 steps, the engine's launch policy unless migrate= is given),
+closed = one solo_engine_step launch per env step (20 steps), s250 = 1000 steps in fused launches of 250.
+Prints env-steps/s by wall clock (median of the repeats, barrier + device sync on both sides as bench.py does) and the
+kernel's duration by HIP events."""
+import argparse
+import json
+import os
+import statistics
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child(spec):
+  sys.path.insert(0, ROOT)
+  import torch
+  import bench
+  from gym_solo_amd import abi
+  dtype, n = spec['dtype'], spec['n']
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  out = {}
+  for leg in spec['legs']:
+    closed = leg == 'closed'
+    k = 1000 if leg == 's250' else 20
+    spl = 1 if closed else (250 if leg == 's250' else k)
+    kw = {}
+    if spec.get('migrate') is not None:
+      kw['migrate_steps'] = spec['migrate']
+    elif dtype == 'float64' and not closed:  # bench.py's table (round 4), until the engine chooses by itself
+      kw['migrate_steps'] = (spl + 1) // 2 if k == spl else 25
+    streams = spec.get('streams')
+    if streams is None:
+      streams = 2 if (k > spl and dtype == 'float32') else 1
+    env = bench.build_env(n, 0, dtype, steps_per_launch=spl, rollout_streams=streams, **kw)
+    eng = env.engine
+    gen = torch.Generator(device='cuda').manual_seed(1234)
+    bench.desynchronise_episodes(eng, gen)
+    pool = lambda steps: (torch.rand(steps, n, abi.NUM_JOINTS, device='cuda', dtype=tdt, generator=gen) * 2 - 1) * 6.283185307179586
+    bufs = None if closed else eng.rollout_buffers(k)
+    def run(a):
+      if closed:
+        for i in range(a.shape[0]):
+          eng.step(a[i], abi.STEP_ALL)
+      else:
+        eng.rollout(a, abi.STEP_ALL, out=bufs)
+    run(pool(k))
+    times = []
+    reps = spec['repeats'] if k == 20 else max(3, spec['repeats'] // 6)
+    for _ in range(reps):
+      a = pool(k)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      run(a)
+      torch.cuda.synchronize()
+      times.append(time.perf_counter() - t0)
+    rec = {'value': n * k / statistics.median(times), 'best': n * k / min(times)}
+    if not closed:
+      r = max(1, min(k, 1000) // spl)
+      rec['kernel_ms'] = statistics.median(eng.time_step(pool(r * spl), abi.STEP_ALL) for _ in range(5))
+    out[leg] = rec
+    env._close()
+  print('AB_RESULT ' + json.dumps(out), flush=True)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--reps', type=int, default=3)
+  ap.add_argument('--repeats', type=int, default=30, help='timed repeats per leg inside a child')
+  ap.add_argument('--dtype', default='float64')
+  ap.add_argument('--legs', default='k20,closed')
+  ap.add_argument('--n', type=int, default=4096)
+  ap.add_argument('libs', nargs='+')
+  args = ap.parse_args()
+  rows = {}
+  for rep in range(args.reps):
+    for name in args.libs:
+      parts = name.split(':')
+      spec = {'dtype': args.dtype, 'legs': args.legs.split(','), 'n': args.n, 'repeats': args.repeats}
+      for p in parts[1:]:
+        key, val = p.split('=')
+        spec[key] = val if key == 'dtype' else int(val)
+      env = dict(os.environ, SOLO_HIP_LIB=os.path.join(ROOT, 'gym_solo_amd', 'csrc', parts[0]), SOLO_AB_CHILD=json.dumps(spec))
+      try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+      except subprocess.TimeoutExpired:
+        print('%s: TIMEOUT' % name, flush=True)
+        raise SystemExit(1)  # (a hung GPU step: no further GPU step in this call)
+      line = [l for l in res.stdout.decode().splitlines() if l.startswith('AB_RESULT ')]
+      if res.returncode != 0 or not line:
+        print('%s: FAILED rc=%d\n%s' % (name, res.returncode, res.stderr.decode()[-2000:]), flush=True)
+        raise SystemExit(1)
+      out = json.loads(line[0][len('AB_RESULT '):])
+      rows.setdefault(name, []).append(out)
+      print('%-44s %s' % (name, '   '.join('%s %.4g%s' % (leg, r['value'], (' (kernel %.4f ms)' % r['kernel_ms']) if 'kernel_ms' in r else '') for leg, r in out.items())), flush=True)
+  print('---- medians over %d rounds (%s, N = %d)' % (args.reps, args.dtype, args.n))
+  for name, outs in rows.items():
+    print('%-44s %s' % (name, '   '.join('%s %.4g' % (leg, statistics.median(o[leg]['value'] for o in outs)) for leg in outs[0])), flush=True)
+
+
+if __name__ == '__main__':
+  if os.environ.get('SOLO_AB_CHILD'):
+    child(json.loads(os.environ['SOLO_AB_CHILD']))
+  else:
+    main()
