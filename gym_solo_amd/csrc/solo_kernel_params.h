@@ -27,6 +27,23 @@ enum BodyKind : int32_t { BODY_BASE = 0, BODY_UPPER = 1, BODY_LOWER = 2 };
 __host__ __device__ constexpr int motor_lane(int dof) { return 16 * (dof >> 1) + (dof & 1); }
 __host__ __device__ constexpr int sphere_lane(int s) { return 16 * (s >> 2) + 2 + 3 * (s & 3); }
 
+// The 27 base-level terms a leg contributes (lower triangle of the 6 x 6 Schur complement, row by row, then the right-hand
+// side), as LANE e of the wave evaluates them from what each leg has posted in LDS (solo_step_kernel.h, f64):
+//   term = sign * P[b] - A1[i] * A1[j] - A2[i] * A2[j]
+// P = [IO 0..5 | m c 6..8 | m_leg 9 | 0 10 | -N 11..13 | -F 14..16], A1 = [W1 0..5 | -e1], A2 = [W2 0..5 | -e2].
+// Entry: b | negate << 5 | i << 6 | j << 9.
+__host__ __device__ constexpr int leg_sum_entry(int e) {
+  constexpr int Z = 10, N = 32;   // (Z: the posted zero; N: negate)
+  constexpr int b[27] = {0, 3, 1, 4, 5, 2,                 // rows 0..2: the composite inertia about the base origin (xx yy zz xy xz yz)
+                         Z, 8, 7 | N, 9,                    // row 3: [0, m c_z, -m c_y | m]
+                         8 | N, Z, 6, Z, 9,                 // row 4: [-m c_z, 0, m c_x | 0, m]
+                         7, 6 | N, Z, Z, Z, 9,              // row 5: [m c_y, -m c_x, 0 | 0, 0, m]
+                         11, 12, 13, 14, 15, 16};           // the right-hand side
+  constexpr int i[27] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 0, 1, 2, 3, 4, 5};
+  constexpr int j[27] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 6, 6, 6, 6, 6, 6};
+  return b[e] | (i[e] << 6) | (j[e] << 9);
+}
+
 template <typename T>
 struct LegConst {
   T hip[3];     // HFE joint origin in base frame

@@ -287,9 +287,9 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 // 19 instructions per updated row (the compiler's loop over LDS-evaluated columns: ~40), no v_med3 in f64:
 // v_max_f64 + v_min_f64, exactly Real<double>::clamp.  Same rows, same order, same arithmetic as the C++ loop
 // (tests/test_gpu_pgs_asm.py compares the two bit for bit in f64 too).
-// The fixed registers of the f64 loop, by build: 168 VGPRs (three waves per SIMD: the product) - loop variables v[90:103], columns
-// v[104:167]; -DSOLO_F64_WAVES=4 (128 VGPRs: the four-waves A/B build, never the product) - v[50:63], v[64:127]
-#if defined(SOLO_F64_WAVES) && SOLO_F64_WAVES >= 4
+// The fixed registers of the f64 loop, by build: 128 VGPRs (FOUR waves per SIMD: the product since round 5) - loop variables
+// v[50:63], columns v[64:127]; -DSOLO_F64_WAVES=3 / 2 (168 / 256 VGPRs: the A/B builds) - v[90:103], v[104:167]
+#if !defined(SOLO_F64_WAVES) || SOLO_F64_WAVES >= 4
 #define SOLO_PGS64_LAM "v[50:51]"
 #define SOLO_PGS64_LAM_LO "v50"
 #define SOLO_PGS64_LAM_HI "v51"

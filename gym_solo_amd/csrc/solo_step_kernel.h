@@ -139,7 +139,7 @@ template <typename T> constexpr int kPrioSweeps = sizeof(T) == 4 ? 8 : SOLO_PRIO
 // epilogue's reward values [SOLO_MAX_REWARD_OPS][steps of a pass].  f64: 896 reals = 28 steps per pass (at FOUR waves
 // per SIMD - the A/B build - what fits 10 KB of LDS: 25).
 #ifndef SOLO_F64_WAVES
-#define SOLO_F64_WAVES 3   // (-DSOLO_F64_WAVES=2 / 4: the A/B builds of tools/gpu_occupancy_sweep.py, never the product)
+#define SOLO_F64_WAVES 4   // (round 5: FOUR waves per SIMD - 128 VGPRs, 10240 B of LDS; -DSOLO_F64_WAVES=3 / 2: the A/B builds, make w3 / w2)
 #endif
 template <typename T> constexpr int kRowBlockReals = sizeof(T) == 4 ? 64 * 8 + 64 * 8 : (SOLO_F64_WAVES >= 4 ? 800 : 896);
 constexpr int kLegSlots = 26;  // per-leg parking lot in LDS (see physics_solve): 0-11 K, 12-14 Lp factors, 15-16 unconstrained joint rates, 17-18 q, 19-22 cos / sin of the two link angles, 23-24 P^-1 h
@@ -148,6 +148,17 @@ constexpr int kLegSlots = 26;  // per-leg parking lot in LDS (see physics_solve)
 template <typename T> struct RowView {
   int type, body;   // RowType, BodyKind
   const T* geo;     // sphere centre [3] in its body frame, radius
+};
+// the per-launch tables in LDS (wave-uniform addresses): what a lane reads of them is a function of its lane number, and the
+// f64 step re-derives that at the head of the row phase instead of carrying three addresses across the dynamics phase
+template <typename T> struct StepTables {
+  const LegConst<T>* legc;    // [4]
+  const int32_t* rowtype;     // [64]: RowConst::type | RowConst::body << 4 | geometry entry << 8 | leg_sum_entry(lane) << 16
+  const T (*rowgeo)[4];       // [SOLO_MAX_SPHERES + 1]
+  __device__ __forceinline__ RowView<T> row(int lane) const {
+    const int tb = rowtype[lane];
+    return {tb & 15, (tb >> 4) & 15, rowgeo[(tb >> 8) & 255]};
+  }
 };
 
 // rows of one sweep, in solver order ([recalled] btMultiBodyConstraintSolver::solveSingleIteration):
@@ -224,31 +235,17 @@ __device__ __forceinline__ int pgs_solve_cpp(const ColumnBank<T>& A, T& v, T& la
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
 // constraint impulse; physics_finish writes s_state (new).
 // ------------------------------------------------------------------------------------------
-template <typename T, bool kResid>
-__device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const LegConst<T>& L,
-                                           const RowView<T>& rc, const T* s_state, T my_target, T* s_rowvec, T (*s_hext)[8], unsigned char* s_rowleg,
+template <typename T, bool kResid, typename FetchTarget>
+__device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const StepTables<T>& tabs,
+                                           const T* s_state, T my_target, FetchTarget&& fetch_target, T* s_rowvec, T (*s_hext)[8], unsigned char* s_rowleg,
                                            T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& row_at, bool& target_bad,
                                            int& prio_sweeps, int& prio_steps, int& prio_rot, T warm_in = T(0), bool warm_on = false) {
   constexpr bool kCompact = ColumnBank<T>::kCompact;   // the solver runs in slot space (see "slot space" below)
   constexpr int kRS = ColumnBank<T>::kRowStride;       // reals per row vector in s_rowvec
   using R = Real<T>;
-  const int leg = lane >> 4, k = lane & 15;
-  const T dt = C.dt;
-  if constexpr (sizeof(T) == 8) mass_scale = s_keep[28];  // (staged by the kernel's prologue; the friction coefficient is fetched at the solver)
-
-  // ---- base: rotation (body -> world), velocities and gravity in base coordinates ----------
-  const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
-  const T r00 = T(1) - T(2) * (qy * qy + qz * qz), r01 = T(2) * (qx * qy - qw * qz), r02 = T(2) * (qx * qz + qw * qy);
-  const T r10 = T(2) * (qx * qy + qw * qz), r11 = T(1) - T(2) * (qx * qx + qz * qz), r12 = T(2) * (qy * qz - qw * qx);
-  const T r20 = T(2) * (qx * qz - qw * qy), r21 = T(2) * (qy * qz + qw * qx), r22 = T(1) - T(2) * (qx * qx + qy * qy);
-  const V3<T> ww = {s_state[SOLO_S_ANGVEL], s_state[SOLO_S_ANGVEL + 1], s_state[SOLO_S_ANGVEL + 2]};
-  const V3<T> vw = {s_state[SOLO_S_LINVEL], s_state[SOLO_S_LINVEL + 1], s_state[SOLO_S_LINVEL + 2]};
-  const V3<T> gw = {C.gravity[0], C.gravity[1], C.gravity[2]};
-  // R^T v
-  const V3<T> om = {r00 * ww.x + r10 * ww.y + r20 * ww.z, r01 * ww.x + r11 * ww.y + r21 * ww.z, r02 * ww.x + r12 * ww.y + r22 * ww.z};
-  const V3<T> vb = {r00 * vw.x + r10 * vw.y + r20 * vw.z, r01 * vw.x + r11 * vw.y + r21 * vw.z, r02 * vw.x + r12 * vw.y + r22 * vw.z};
-  const V3<T> gb = {r00 * gw.x + r10 * gw.y + r20 * gw.z, r01 * gw.x + r11 * gw.y + r21 * gw.z, r02 * gw.x + r12 * gw.y + r22 * gw.z};
-  const V3<T> nb = {r20, r21, r22};  // world z (ground normal) in base coordinates
+  int leg = lane >> 4, k = lane & 15;
+  const LegConst<T>* Lp = &tabs.legc[leg];
+#define L (*Lp)
 
   // ---- leg-local kinematics.  Each 16-lane row works on its own leg, and the two HALVES of the
   //      row on the leg's two links: lanes k < 8 carry the upper link, k >= 8 the lower link
@@ -315,8 +312,44 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
       s_leg[leg][19] = c1; s_leg[leg][20] = s1; s_leg[leg][21] = c12; s_leg[leg][22] = s12;
     }
   }
+  // leg composite about the base origin
+  const T mleg = L.link[0][0] + L.link[1][0];
+  const V3<T> mc = both_halves(mB * c);
+  T IO[6];
+  IO[0] = both_halves(I[0] + mB * (c.y * c.y + c.z * c.z));
+  IO[1] = both_halves(I[1] + mB * (c.x * c.x + c.z * c.z));
+  IO[2] = both_halves(I[2] + mB * (c.x * c.x + c.y * c.y));
+  IO[3] = both_halves(I[3] - mB * c.x * c.y);
+  IO[4] = both_halves(I[4] - mB * c.x * c.z);
+  IO[5] = both_halves(I[5] - mB * c.y * c.z);
+  if constexpr (kPark) {
+    // ... and what the base-level sum below is made of (the row-vector block is dead here: it is the scratch of that sum)
+    if (k == 0) {
+      T* mine = s_rowvec + leg * 32;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { mine[i] = IO[i]; mine[17 + i] = W1[i]; mine[24 + i] = W2[i]; }
+      mine[6] = mc.x; mine[7] = mc.y; mine[8] = mc.z; mine[9] = mleg; mine[10] = T(0);
+    }
+    // ... and the motor lanes' targets are fetched from global memory HERE: behind the register peak, thousands of cycles
+    // in front of the motor rows that consume them
+    my_target = fetch_target(wave_fresh_lane());
+  }
 
   SOLO_STAMP(B, 3);
+  // ---- base: rotation (body -> world), velocities and gravity in base coordinates ----------
+  const T qx = s_state[SOLO_S_QUAT], qy = s_state[SOLO_S_QUAT + 1], qz = s_state[SOLO_S_QUAT + 2], qw = s_state[SOLO_S_QUAT + 3];
+  const T r00 = T(1) - T(2) * (qy * qy + qz * qz), r01 = T(2) * (qx * qy - qw * qz), r02 = T(2) * (qx * qz + qw * qy);
+  const T r10 = T(2) * (qx * qy + qw * qz), r11 = T(1) - T(2) * (qx * qx + qz * qz), r12 = T(2) * (qy * qz - qw * qx);
+  const T r20 = T(2) * (qx * qz - qw * qy), r21 = T(2) * (qy * qz + qw * qx), r22 = T(1) - T(2) * (qx * qx + qy * qy);
+  const V3<T> ww = {s_state[SOLO_S_ANGVEL], s_state[SOLO_S_ANGVEL + 1], s_state[SOLO_S_ANGVEL + 2]};
+  const V3<T> vw = {s_state[SOLO_S_LINVEL], s_state[SOLO_S_LINVEL + 1], s_state[SOLO_S_LINVEL + 2]};
+  const V3<T> gw = {C.gravity[0], C.gravity[1], C.gravity[2]};
+  // R^T v
+  const V3<T> om = {r00 * ww.x + r10 * ww.y + r20 * ww.z, r01 * ww.x + r11 * ww.y + r21 * ww.z, r02 * ww.x + r12 * ww.y + r22 * ww.z};
+  const V3<T> vb = {r00 * vw.x + r10 * vw.y + r20 * vw.z, r01 * vw.x + r11 * vw.y + r21 * vw.z, r02 * vw.x + r12 * vw.y + r22 * vw.z};
+  const V3<T> gb = {r00 * gw.x + r10 * gw.y + r20 * gw.z, r01 * gw.x + r11 * gw.y + r21 * gw.z, r02 * gw.x + r12 * gw.y + r22 * gw.z};
+  const V3<T> nb = {r20, r21, r22};  // world z (ground normal) in base coordinates
+
   // ---- bias forces of the leg: Newton-Euler with classical accelerations in the frame that
   //      coincides with the base at this instant (gravity + Bullet-style damping included) ----
   const V3<T> wU = {om.x, om.y + qd1, om.z};
@@ -350,15 +383,6 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   SOLO_STAMP(B, 4);
   // ---- base level: Schur complement S and right-hand side, summed over the four legs -------
   // leg composite about the base origin
-  const T mleg = L.link[0][0] + L.link[1][0];
-  const V3<T> mc = both_halves(mB * c);
-  T IO[6];
-  IO[0] = both_halves(I[0] + mB * (c.y * c.y + c.z * c.z));
-  IO[1] = both_halves(I[1] + mB * (c.x * c.x + c.z * c.z));
-  IO[2] = both_halves(I[2] + mB * (c.x * c.x + c.y * c.y));
-  IO[3] = both_halves(I[3] - mB * c.x * c.y);
-  IO[4] = both_halves(I[4] - mB * c.x * c.z);
-  IO[5] = both_halves(I[5] - mB * c.y * c.z);
   T S[6][6];  // lower triangle used
   S[0][0] = IO[0]; S[1][0] = IO[3]; S[1][1] = IO[1]; S[2][0] = IO[4]; S[2][1] = IO[5]; S[2][2] = IO[2];
   S[3][0] = T(0);  S[3][1] = mc.z;  S[3][2] = -mc.y;
@@ -370,7 +394,44 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // terms, lane e adds the four copies of term e, everyone reads the totals back as broadcasts
   // (~30 instructions; 27 in-register cross-row sums cost six each).  The row-vector array is
   // not live yet and serves as the scratch: part[4][28], tot[28].
-  {
+  if constexpr (kPark) {
+    // f64 (round 5): the legs post what the terms are MADE of (31 values) and lane e evaluates term e of all four legs
+    // (leg_sum_entry, solo_kernel_params.h): 3 fused multiply-adds per leg on 27 lanes instead of 60 on all 64 - and W1,
+    // W2, the composite inertia and the bias wrench stop being live in every lane across this phase
+    T* part = s_rowvec;           // [4][32]
+    T* tot = part + 4 * 32;
+    if (k == 0) {   // (the inertia part was posted when it was computed, above)
+      T* mine = part + leg * 32;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) mine[11 + i] = rhs[i];
+      mine[23] = -e1; mine[30] = -e2;
+    }
+    wave_sync();
+    // (the lane number - and with it every per-lane LDS address - is derived afresh here: nothing of the kind is live
+    // across the leg phase's register peak)
+    const int ls = wave_fresh_lane();
+    lane = ls; leg = ls >> 4; k = ls & 15;
+    if (ls < 27) {
+      const int tb = tabs.rowtype[ls] >> 16;
+      const int bi = tb & 31, ii = (tb >> 6) & 7, jj = (tb >> 9) & 7;
+      T t[4];
+#pragma unroll
+      for (int l2 = 0; l2 < 4; ++l2) {
+        const T* p = part + 32 * l2;
+        const T b = (tb & 32) ? -p[bi] : p[bi];
+        t[l2] = R::fma(-p[24 + ii], p[24 + jj], R::fma(-p[17 + ii], p[17 + jj], b));
+      }
+      tot[ls] = (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    wave_sync();
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) S[i][j] = tot[o++];
+      rhs[i] = tot[21 + i];
+    }
+  } else {
     T* part = s_rowvec;
     T* tot = part + 4 * 28;
     if (k == 0) {
@@ -396,6 +457,8 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     // (the sync after parking the factors below orders these reads before the row phase's writes)
   }
   // the base body itself (mass / inertia scaled per env for domain randomisation)
+  if constexpr (sizeof(T) == 8) mass_scale = s_keep[28];  // (staged by the kernel's prologue; the friction coefficient is fetched at the solver)
+  const T dt = C.dt;
   {
     const T m0 = C.base_mass * mass_scale;
     T I0[6];
@@ -491,6 +554,10 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   V3<T> nbr = nb, p1 = o1, p2 = o2;
   T ck1 = c1, sk1 = s1, ck12 = c12, sk12 = s12, qa1 = q1, qa2 = q2;
   if constexpr (kPark) {
+    // (f64: the lane number - and with it every per-lane table address - is derived afresh: nothing of the kind is live
+    // across the dynamics phase)
+    lane = wave_fresh_lane(); leg = lane >> 4; k = lane & 15;
+    Lp = &tabs.legc[leg];
     const T ux = s_state[SOLO_S_QUAT], uy = s_state[SOLO_S_QUAT + 1], uz = s_state[SOLO_S_QUAT + 2], uw = s_state[SOLO_S_QUAT + 3];
     m00 = T(1) - T(2) * (uy * uy + uz * uz); m01 = T(2) * (ux * uy - uw * uz); m02 = T(2) * (ux * uz + uw * uy);
     m10 = T(2) * (ux * uy + uw * uz); m11 = T(1) - T(2) * (ux * ux + uz * uz); m12 = T(2) * (uy * uz - uw * ux);
@@ -500,6 +567,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     p1 = V3<T>{L.hip[0], L.hip[1], L.hip[2]};
     p2 = p1 + roty(ck1, sk1, V3<T>{L.knee[0], L.knee[1], L.knee[2]});
   }
+  const RowView<T> rc = tabs.row(lane);
   const int type = rc.type;
   const bool is_motor = type == ROW_MOTOR, is_contact = type >= ROW_NORMAL && type <= ROW_TAN2, is_limit = type == ROW_LIMIT;
   V3<T> cb = {rc.geo[0], rc.geo[1], rc.geo[2]};
@@ -738,6 +806,18 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     // (software-pipelined by one slot: the row of slot r + 1 is fetched - eight LDS broadcasts - in front of the arithmetic
     // of slot r, across the tests too: a wave alone on its SIMD, the slow robot at the end of a launch, otherwise sits
     // out an LDS round trip at the head of every triple)
+    if constexpr (SOLO_F64_WAVES >= 4) {
+      // (four waves per SIMD - the A/B build: 128 VGPRs have no room for a second row in flight)
+      A.build(0); A.build(1);
+#pragma unroll
+      for (int j = 2; j < ColumnBank<T>::kSlots; j += 3) {
+        if (n_live > j) {
+          A.build(j);
+          if (j + 1 < ColumnBank<T>::kSlots) A.build(j + 1);
+          if (j + 2 < ColumnBank<T>::kSlots) A.build(j + 2);
+        }
+      }
+    } else {
     typename ColumnBank<T>::Row cur = A.fetch(0);
     {
       const typename ColumnBank<T>::Row n1 = A.fetch(1);
@@ -757,6 +837,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
           if (j + 2 < ColumnBank<T>::kSlots) A.build_from(j + 2, n2);
         }
       }
+    }
     }
   }
   (void)touching; (void)limited;
@@ -880,6 +961,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   wave_set_priority_level(prio_sweeps > kPrioSweeps<T> * prio_steps ? 3 : prio_rot);
   SOLO_STAMP(B, 9);
   return lamv;
+#undef L
 }
 
 // post-solve half: apply the impulses (du_b = C^-T sum ghat lam ; dqd_l = Lp^-T sum hhat lam -
@@ -997,7 +1079,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   T (*const s_hext)[8] = ColumnBank<T>::kCompact ? nullptr : reinterpret_cast<T (*)[8]>(s_blk + 64 * kRS);
   __shared__ unsigned char s_rowleg[64];  // (slot space: the leg of every slot's row)
   T (*const s_rowgeo)[4] = reinterpret_cast<T (*)[4]>(s_blk + kRowsReals);
-  __shared__ int32_t s_rowtype[64];  // RowConst::type | RowConst::body << 8 | geometry entry << 16
+  __shared__ int32_t s_rowtype[64];  // (StepTables::rowtype)
   __shared__ T s_keep[32];
   __shared__ T s_leg[4][kLegSlots];
   // termination (termination.py:38-83), one lane per termination (lanes >= SOLO_MAX_TERMS: never fire):
@@ -1080,7 +1162,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
 #pragma unroll
     for (int j = 0; j < kLegLoads; ++j) if (lane0 + 64 * j < kLegWords) leg_dst[lane0 + 64 * j] = leg_w[j];
     const bool has_geo = row_w.type >= ROW_NORMAL && row_w.type <= ROW_TAN2;   // (row_w.dof: the row's model sphere)
-    s_rowtype[lane0] = row_w.type | (row_w.body << 8) | ((has_geo ? row_w.dof : SOLO_MAX_SPHERES) << 16);
+    s_rowtype[lane0] = row_w.type | (row_w.body << 4) | ((has_geo ? row_w.dof : SOLO_MAX_SPHERES) << 8) | (leg_sum_entry(lane0 < 27 ? lane0 : 0) << 16);
     if (row_w.type == ROW_NORMAL) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) s_rowgeo[row_w.dof][i] = row_w.center[i];
@@ -1230,29 +1312,31 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     // target is used (physics_solve) instead of keeping it to the end of the step, and physics_finish re-derives its
     // LDS addresses.  f32 (0 spills without any of it, 1 % slower with it) keeps its code.
     constexpr bool kLean = sizeof(T) == 8;
-    const int lane = kLean ? wave_fresh_lane() : wave_opaque_lane(lane0);
+    int lane = kLean ? wave_fresh_lane() : wave_opaque_lane(lane0);
     const bool have_actions = kLean ? wave_opaque_bits((unsigned long long)B.actions) != 0ull : B.actions != nullptr;
     const T* const actions = have_actions ? B.actions : nullptr;
-    const LegConst<T>& L = s_legc[lane >> 4];
-    const int row_tb = s_rowtype[lane];
-    const RowView<T> rc = {row_tb & 255, (row_tb >> 8) & 255, s_rowgeo[row_tb >> 16]};
+    const StepTables<T> tabs = {s_legc, s_rowtype, s_rowgeo};
     // setJointMotorControlArray (solo8v2vanilla.py:87-90): every motor lane fetches the target of ITS
     // joint straight from global memory.  The value is consumed when the motor rows are built,
     // thousands of cycles into the step, so the load's latency is never waited for (funnelled
     // through LDS at the top of the step - or prefetched a step ahead into a register the compiler
     // then copies at once - it cost an exposed global-memory round trip per step).
-    const bool motor_lane = rc.type == ROW_MOTOR;
-    const size_t tgt_at = (size_t)env * SOLO_NUM_JOINTS + (size_t)(3 * (lane >> 4) + (lane & 15));  // pybullet joint index
-    T raw_target = T(0);
+    // (f64, round 5: the load is issued INSIDE physics_solve, behind the leg phase - the step's register peak - and still
+    // ~3000 cycles in front of its use; at the top of the step its register pair was the first thing the 128-VGPR kernel
+    // spilled)
+    bool motor_lane = (s_rowtype[lane] & 15) == ROW_MOTOR;
     // (the robot's motor targets are written from several chunks - the last step's action, an auto-reset's settle pose -
     // and read back when a launch brings no actions: device-coherent accesses in a migrating launch, like its record)
-    if (motor_lane) {
-      if (actions != nullptr) raw_target = actions[(size_t)step * B.action_stride + tgt_at];
-      else if constexpr (kMigrate) raw_target = wave_load_shared(wave_cold_args(Bin)->targets + tgt_at);
-      else raw_target = wave_cold_args(Bin)->targets[tgt_at];
-    }
-    // action de-normalisation (solo8v2vanilla.py:84-85), applied where the target is used
-    const T target_scale = actions != nullptr ? C.action_scale : T(1);
+    auto fetch_target = [&](int ln) -> T {   // action de-normalisation (solo8v2vanilla.py:84-85) included
+      const size_t tgt_at = (size_t)env * SOLO_NUM_JOINTS + (size_t)(3 * (ln >> 4) + (ln & 15));  // pybullet joint index
+      T raw_target = T(0);
+      if ((ln & 15) < 2) {   // (the motor rows: k = 0, 1 of every leg - solo_kernel_params.h)
+        if (actions != nullptr) raw_target = actions[(size_t)step * B.action_stride + tgt_at];
+        else if constexpr (kMigrate) raw_target = wave_load_shared(wave_cold_args(Bin)->targets + tgt_at);
+        else raw_target = wave_cold_args(Bin)->targets[tgt_at];
+      }
+      return raw_target * (actions != nullptr ? s_const.action_scale : T(1));
+    };
     if (actions != nullptr && step == B.steps - 1 && lane < SOLO_NUM_JOINTS) {  // the view's targets: all 12 entries
       const T tv = actions[(size_t)step * B.action_stride + (size_t)env * SOLO_NUM_JOINTS + lane] * C.action_scale;
       if constexpr (kMigrate) wave_store_shared(wave_cold_args(Bin)->targets + (size_t)env * SOLO_NUM_JOINTS + lane, tv);
@@ -1270,15 +1354,16 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     SOLO_STAMP(B, 1);
     bool diverged = false;
     if (B.flags & SOLO_STEP_PHYSICS) {
-      const T my_target = raw_target * target_scale;
+      const T my_target = kLean ? T(0) : fetch_target(lane);
       bool target_bad = false;  // (set on a motor lane whose target is not finite)
       int row_at;  // where this lane's constraint row sits in s_rowvec / s_hext (its lane, or its slot: see physics_solve)
-      const T lam = physics_solve<T, kResid>(C, B, L, rc, s_state, my_target, s_rowvec, s_hext, s_rowleg, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, target_bad, prio_sweeps, prio_steps, prio_rot,
+      const T lam = physics_solve<T, kResid>(C, B, tabs, s_state, my_target, fetch_target, s_rowvec, s_hext, s_rowleg, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, target_bad, prio_sweeps, prio_steps, prio_rot,
                                              warm_in, kResid && warm_row != nullptr);
       if constexpr (kResid) if (warm_row != nullptr) {
         if constexpr (kMigrate) wave_store_shared(warm_row + (size_t)env * 64 + lane, lam);
         else warm_row[(size_t)env * 64 + lane] = lam;
       }
+      if constexpr (kLean) lane = wave_fresh_lane();   // (nothing lane-derived lives across physics_solve)
       physics_finish<T>(C, s_state, s_rowvec, s_keep, s_leg, s_math, lam, lane, row_at);
       // a robot whose state went non-finite - or that was handed a non-finite target, which the
       // solver's clamps would otherwise swallow silently - is restored from its snapshot and counted
