@@ -56,8 +56,10 @@ EMU = os.environ.get('SOLO_BENCH_ENGINE') == 'emu'
 MAX_STEPS = int(os.environ.get('SOLO_BENCH_MAX_STEPS', '1000'))
 
 
-def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=1, rollout_streams=1, residual_threshold=0.0, migrate_steps=0,
+def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=-1, rollout_streams=-1, residual_threshold=0.0, migrate_steps=-1,
               warm_start=0.0):
+  """-1 for the three launch knobs = the engine chooses (SoloConfig's defaults: the measured launch policy lives in the
+  engine since round 5, Engine.plan(k) reports it)."""
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
   from gym_solo_amd.workloads import register_benchmark_workload
   if EMU:  # CPU REHEARSAL of the launcher / collective / JSON plumbing (tests/test_bench_launcher.py): never a measurement
@@ -328,15 +330,15 @@ def main():
                        'solo8v2vanilla.py:91) and the default; float32 is the opt-in fast mode, reported next to it as value_f32')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extra', action='store_true', help='skip the value_f64 / value_closed_loop legs')
-  ap.add_argument('--steps-per-launch', type=int, default=250,
+  ap.add_argument('--steps-per-launch', type=int, default=-1,
                   help='env steps of every robot fused into one kernel launch by the open-loop rollout '
-                       '(1 = one launch per step, the closed-loop granularity)')
-  ap.add_argument('--rollout-streams', type=int, default=2,
+                       '(1 = one launch per step, the closed-loop granularity; -1, the default = the engine chooses: min(K, 250))')
+  ap.add_argument('--rollout-streams', type=int, default=-1,
                   help='batch slices advancing as independent launch chains on separate HIP streams '
-                       '(only used when a rollout needs more than one launch per slice)')
+                       '(-1, the default = the engine chooses: two when a rollout takes several launches)')
   ap.add_argument('--migrate-steps', type=int, default=-1,
                   help='SoloConfig.migrate_steps of the rollouts: robots change waves every this many steps of a launch '
-                       '(0 = off; -1 = where it pays: half the launch for a single-launch f64 rollout, else off)')
+                       '(0 = off; -1, the default = the engine chooses: only when a launch has more robots than the chip has wave slots)')
   ap.add_argument('--min-seconds', type=float, default=0.5, help='repeat the K-step timed region until this much time ...')
   ap.add_argument('--max-repeats', type=int, default=30, help='... or this many repeats have accumulated')
   args = ap.parse_args()
@@ -375,6 +377,15 @@ def main():
     else:
       dist.init_process_group(backend, rank=rank, world_size=world)
     log("init_process_group('%s') ok: world_size %d, backend %s, device cuda:%d" % (backend, world, dist.get_backend(), local_rank))
+  # every rank says what it runs on (stderr): the first multi-GPU run then shows from its tail alone that RCCL saw N ranks
+  try:
+    rccl = '.'.join(str(v) for v in torch.cuda.nccl.version()) if (not EMU and hasattr(torch.cuda, 'nccl')) else 'n/a'
+  except Exception as e:  # noqa: BLE001
+    rccl = 'unavailable (%s)' % type(e).__name__
+  print('[bench rank %d] device %s, world size %d (process group: %s), RCCL %s, torch %s, HSA_ENABLE_IPC_MODE_LEGACY=%s' % (
+    rank, 'cpu emulator' if EMU else torch.cuda.get_device_name(local_rank),
+    dist.get_world_size() if distributed else 1, ('%s initialised' % dist.get_backend()) if distributed else 'none',
+    rccl, torch.__version__, os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')), file=sys.stderr, flush=True)
 
   dev = 'cpu' if EMU else 'cuda:%d' % local_rank
   n, k, w = args.envs_per_gpu, args.steps, args.warmup
@@ -400,27 +411,11 @@ def main():
     """Repeats of the K-step timed region on a fresh engine; returns per-repeat seconds (max over
     ranks), the summed episodic statistics of the timed repeats and the engine."""
     tdtype = torch.float32 if dtype == 'float32' else torch.float64
-    # (a run shorter than one fused launch fuses what it has: K steps per launch, and then one launch
-    # chain is all there is to overlap: no stream slices)
-    spl = 1 if closed_loop else max(1, min(args.steps_per_launch, k))
-    streams = max(1, args.rollout_streams) if (k > spl and not closed_loop) else 1
-    # robot migration inside a launch (SoloConfig.migrate_steps: scheduling only, results bit-identical): where it pays -
-    # f64 (4096 robots on 3072 wave slots): a single launch in two chunks, longer rollouts as one chain of launches in
-    # chunks of 25 steps
-    # (measured, tools/gpu_migrate_sweep.py + gpu_occupancy_sweep.py, profiles/round4_ab.log: K = 20 in two chunks +14 %;
-    # 250-step launches in chunks of 25 on one chain +10 % over two stream slices; f32 - every robot resident from the
-    # first cycle - -5 %)
-    migrate = args.migrate_steps
-    if migrate < 0:
-      migrate = 0
-      if dtype == 'float64' and not closed_loop and spl >= 8:
-        if k == spl:
-          migrate = (spl + 1) // 2      # one launch: two chunks
-        elif spl >= 50:
-          migrate, streams = 25, 1      # several launches: ONE chain of migrating launches beats two stream slices
-                                        # (tools/gpu_migrate_sweep.py: 1.63e8 against 1.47e8; f32: the slices stay, 3.75e8 against 3.5e8)
-    env = build_env(n, local_rank, dtype, steps_per_launch=spl, rollout_streams=streams, residual_threshold=residual_threshold,
-                    migrate_steps=migrate, warm_start=warm_start)
+    # the launch geometry is THE ENGINE'S (SoloConfig's -1 defaults: solo_engine.hip make_plan, reported by Engine.plan(k));
+    # the closed loop is one solo_engine_step launch per env step by definition; command-line values override
+    env = build_env(n, local_rank, dtype, steps_per_launch=1 if closed_loop else args.steps_per_launch,
+                    rollout_streams=1 if closed_loop else args.rollout_streams, residual_threshold=residual_threshold,
+                    migrate_steps=0 if closed_loop else args.migrate_steps, warm_start=warm_start)
     eng = env.engine
     gen = torch.Generator(device=dev).manual_seed(rank_seed(1234, rank))
 
@@ -475,22 +470,24 @@ def main():
       total = stats if total is None else total + stats
       if sum(times) >= min_seconds or len(times) >= max_repeats:
         break
-    return times, total, eng, env, action_pool, spl, streams
+    plan = {'steps_per_launch': 1, 'launches': k, 'slices': 1, 'migrate_steps': 0} if closed_loop else eng.plan(k)
+    return times, total, eng, env, action_pool, plan
 
-  def roofline(dtype, eng, action_pool, k, spl, streams):
+  def roofline(dtype, eng, action_pool, k, plan):
     """The dominant kernel of a rollout, measured live: HIP events on the streams its launches are issued on
-    (mean over the slices' chains), same rollout path and workload (fresh actions every step); one launch =
-    (n / slices) robots x spl steps; algorithmic bytes per env-step from SURVEY.md 8d."""
-    reps = max(1, min(k, 1000) // spl)
-    kern_ms = statistics.median(eng.time_step(action_pool(reps * spl), abi.STEP_ALL) for _ in range(5 if k <= 100 else 3))
-    slices = streams if (streams > 1 and n >= 2 * streams) else 1
+    (mean over the slices' chains and launches: solo_engine_time_rollout runs the rollout exactly as solo_engine_rollout
+    does), same workload (fresh actions every step); one launch = (n / slices) robots x steps_per_launch steps;
+    algorithmic bytes per env-step from SURVEY.md 8d."""
+    spl, slices = plan['steps_per_launch'], plan['slices']
+    kk = min(k, 1000) // spl * spl or k   # (whole launches)
+    kern_ms = statistics.median(eng.time_rollout(action_pool(kk), abi.STEP_ALL) for _ in range(5 if k <= 100 else 3))
     env_steps_per_launch = (n // slices) * spl
     bytes_per_launch = BYTES_PER_ENV_STEP[dtype] * env_steps_per_launch
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     pmc = pmc_profile(dtype, spl, slices)
     traffic = pmc['hbm_bytes_per_env_step'] * env_steps_per_launch if pmc.get('hbm_bytes_per_env_step') else None
-    # (waves resident per SIMD: the f32 kernel's 128 VGPRs allow four, the f64 kernel's 168 three)
-    note, secondary = secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, min(n / NUM_SIMDS, 4 if dtype == 'float32' else 3), dtype)
+    # (waves resident per SIMD: 128 VGPRs allow four in both precisions since round 5)
+    note, secondary = secondary_bound(pmc, env_steps_per_launch, slices, kern_ms, min(n / NUM_SIMDS, plan.get('waves_per_simd') or 4), dtype)
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
             'traffic_note': pmc.get('traffic_note'),
@@ -503,12 +500,12 @@ def main():
             'bytes_per_env_step': BYTES_PER_ENV_STEP[dtype],
             'algorithmic_bytes_per_launch': bytes_per_launch, 'env_steps_per_launch': env_steps_per_launch,
             'concurrent_launch_chains': slices, 'achieved_all_chains': achieved * slices,
-            'note': note, 'secondary': secondary}, slices
+            'launch_plan': plan, 'note': note, 'secondary': secondary}
 
-  times, stats, eng, env, action_pool, spl, streams = timed(args.dtype, k, False, args.min_seconds, args.max_repeats)
+  times, stats, eng, env, action_pool, plan = timed(args.dtype, k, False, args.min_seconds, args.max_repeats)
   log('timed region done: %d repeats, stats all-reduce ok (episodes %.0f)' % (len(times), float(stats[2])))
   elapsed = statistics.median(times)
-  roof, slices = roofline(args.dtype, eng, action_pool, k, spl, streams)
+  roof = roofline(args.dtype, eng, action_pool, k, plan)
   env._close()
 
   extra = {}
@@ -518,25 +515,25 @@ def main():
     tag = {'float32': 'f32', 'float64': 'f64'}
     # the OTHER precision on the same workload and rollout path, with its own roofline block (f64 is the reference's
     # precision - PyBullet computes in double - and the kernel of `value` by default; f32 is the opt-in fast mode)
-    to, so_, go, eo, poolo, splo, streamso = timed(other, ke, False, 0.3, 10)
+    to, so_, go, eo, poolo, plano = timed(other, ke, False, 0.3, 10)
     extra['value_' + tag[other]] = world * n * ke / statistics.median(to)
     extra['value_%s_note' % tag[other]] = ('same workload and rollout path in %s (%s), median of %d repeats of %d steps'
                                            % (other, 'the opt-in fast mode; NOT the reference\'s precision' if other == 'float32'
                                               else 'the reference\'s precision, SURVEY.md §8', len(to), ke))
-    extra['roofline_' + tag[other]] = roofline(other, go, poolo, ke, splo, streamso)[0]
+    extra['roofline_' + tag[other]] = roofline(other, go, poolo, ke, plano)
     extra['episodes_' + tag[other]] = summarize(so_.cpu().numpy())
     eo._close()
     for dt in (args.dtype, other):
       sfx = '' if dt == args.dtype else '_' + tag[dt]
       # pybullet's documented default solverResidualThreshold (1e-7 [recalled]) as an OPT-IN: off in `value`
-      tr, _, _, er, _, _, _ = timed(dt, ke, False, 0.3, 10, residual_threshold=1e-7)
+      tr, _, _, er, _, _ = timed(dt, ke, False, 0.3, 10, residual_threshold=1e-7)
       extra['value_residual_1e-7' + sfx] = world * n * ke / statistics.median(tr)
       er._close()
       # ... and with the warm start on top of it (SoloConfig.solver_warm_start = 0.85, [recalled] Bullet's rigid-body factor)
-      tw, _, _, ew, _, _, _ = timed(dt, ke, False, 0.3, 10, residual_threshold=1e-7, warm_start=0.85)
+      tw, _, _, ew, _, _ = timed(dt, ke, False, 0.3, 10, residual_threshold=1e-7, warm_start=0.85)
       extra['value_residual_warmstart' + sfx] = world * n * ke / statistics.median(tw)
       ew._close()
-      tcl, _, _, ecl, _, _, _ = timed(dt, ke, True, 0.3, 10)
+      tcl, _, _, ecl, _, _ = timed(dt, ke, True, 0.3, 10)
       extra['value_closed_loop' + sfx] = world * n * ke / statistics.median(tcl)
       ecl._close()
     extra['value_residual_note'] = ('the same rollout with SoloConfig.solver_residual_threshold = 1e-7 (pybullet\'s documented default; the '
@@ -553,7 +550,7 @@ def main():
                                        'no host synchronisation between steps; median over repeats of %d steps; headline precision and (suffix) the other one' % ke)
     # rounds 1-2 timed the first steps of 4096 synchronised episodes (every robot freshly reset, nobody terminating):
     # the same kernels under that lighter regime, so that this round's line can be compared with theirs
-    tsy, _, _, esy, _, _, _ = timed(args.dtype, ke, False, 0.3, 10, steady=False)
+    tsy, _, _, esy, _, _ = timed(args.dtype, ke, False, 0.3, 10, steady=False)
     extra['value_synchronised_start'] = world * n * ke / statistics.median(tsy)
     extra['value_synchronised_start_note'] = ('the regime rounds 1-2 reported as `value`: all robots at the start of an episode (no steady-state '
                                               'preparation, no episode ends inside the window); NOT the configuration of `value`')
@@ -569,7 +566,9 @@ def main():
       'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
                              'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
                              'TimeBasedTermination(%d)+auto-reset, steady state (episode phases spread uniformly by %d untimed steps), dt=1e-3, 50 PGS iterations' % (n, MAX_STEPS, MAX_STEPS),
-                 'envs_per_gpu': n, 'steps_per_launch': spl, 'rollout_streams': slices, 'migrate_steps': int(eng.cfg.migrate_steps),
+                 'envs_per_gpu': n, 'steps_per_launch': plan['steps_per_launch'], 'rollout_streams': plan['slices'], 'migrate_steps': plan['migrate_steps'],
+                 'launches_per_slice': plan['launches'], 'waves_per_simd': plan.get('waves_per_simd'),
+                 'launch_policy': 'chosen by the engine (SoloConfig -1 defaults; solo_engine_plan)' if (args.steps_per_launch, args.rollout_streams, args.migrate_steps) == (-1, -1, -1) else 'command line',
                  'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'timing': {'repeats': len(times), 'statistic': 'median', 'stats_reduction_inside_timed_region': bool(distributed), 'min_ms_per_step': min(times) / k * 1e3,
                  'max_ms_per_step': max(times) / k * 1e3, 'value_best_repeat': world * n * k / min(times),

@@ -7,7 +7,7 @@ as DATA (``SoloModel``/``SoloConfig``).
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_LEGS = 4
 NUM_DOF = 8
 NUM_JOINTS = 12
@@ -34,6 +34,8 @@ ERR_HIP = -2
 ERR_UNSUPPORTED_MODEL = -3
 ERR_NO_PROGRAM = -4
 ERR_NO_DEVICE = -5
+ERR_INCOMPLETE = -6   # a wave of an earlier migrating launch gave up waiting (internal error; sticky)
+AUTO = -1             # steps_per_launch / rollout_streams / migrate_steps: the engine chooses
 
 F32, F64 = 0, 1
 
@@ -185,6 +187,17 @@ class SoloStateView(C.Structure):
   ]
 
 
+class SoloLaunchPlan(C.Structure):
+  _fields_ = [
+    ('steps_per_launch', C.c_int32),
+    ('launches', C.c_int32),
+    ('slices', C.c_int32),
+    ('migrate_steps', C.c_int32),
+    ('waves_per_simd', C.c_int32),
+    ('resident_robots', C.c_int32),
+  ]
+
+
 # every entry point `include/solo_engine.h` declares: name -> (restype, argtypes)
 ENTRY_POINTS = {
   'solo_engine_create': (C.c_int, [C.POINTER(SoloConfig), C.POINTER(SoloModel), C.c_int32,
@@ -205,6 +218,8 @@ ENTRY_POINTS = {
   'solo_engine_kernel_name': (C.c_char_p, [C.c_void_p]),
   'solo_engine_time_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
                                       C.c_void_p, C.POINTER(C.c_double)]),
+  'solo_engine_plan': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SoloLaunchPlan)]),
+  'solo_engine_time_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]),
   'solo_engine_last_error': (C.c_char_p, [C.c_void_p]),
   'solo_last_create_error': (C.c_char_p, []),
   'solo_abi_version': (C.c_int, []),

@@ -70,12 +70,17 @@ class Solo8BaseConfig:
   joint_limit_margin: float = 0.5  # [rad] distance to a URDF joint limit below which its row is built
   settle_steps: int = 500         # gym_solo/envs/solo8v2vanilla.py:130
   auto_reset: bool = False
-  steps_per_launch: int = 1       # rollouts fuse this many env steps per kernel launch
-  rollout_streams: int = 1        # rollouts advance this many batch slices on separate HIP streams
+  # The launch geometry of rollouts.  -1 (the default of all three) = THE ENGINE CHOOSES, from what was measured on the
+  # benchmark workload (solo_engine.hip: make_plan; Engine.plan(k) reports the choice): fused launches of min(K, 250)
+  # steps; two batch slices on separate HIP streams when a rollout takes several launches; robot migration only when a
+  # launch has more robots than the chip has wave slots (4096).  step() is always one launch of one step.
+  steps_per_launch: int = -1      # rollouts fuse this many env steps per kernel launch (1: one launch per step)
+  rollout_streams: int = -1       # rollouts advance this many batch slices on separate HIP streams
   # c > 0: a fused launch of more than c steps hands its robots from wave to wave every c steps through a work queue
   # in device memory, so that the launch ends when the work is done and not when the unluckiest SIMD's robots are
-  # (scheduling only, results bit-identical).  0 = off: one wave steps one robot through the launch
-  migrate_steps: int = 0
+  # (scheduling only, results bit-identical).  0 = off: one wave steps one robot through the launch;
+  # -1: the engine chooses (above)
+  migrate_steps: int = -1
   # ground: None = pybullet_data's flat plane.urdf (solo8_base_env.py:47); or a heightfield
   # dict(heights=[ny, nx] array, cell=metres, origin=(x, y) of grid point (0, 0) or None = centred)
   terrain = None
@@ -149,15 +154,18 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
   # at :170-172: 2 pi reaches the motors as 6.2831854820251465 (float64 arithmetic on a float32 value)
   c.action_scale = float(np.float32(config.max_motor_rotation)) if normalize_actions else 1.0
   c.auto_reset = 1 if config.auto_reset else 0
-  c.steps_per_launch = max(1, int(getattr(config, 'steps_per_launch', 1)))
+  def knob(name):   # -1 = the engine chooses
+    v = int(getattr(config, name, -1))
+    if v < -1:
+      raise ValueError('{} must be >= 0, or -1 to let the engine choose'.format(name))
+    return v
+  c.steps_per_launch = knob('steps_per_launch')
   c.solver_warm_start = float(getattr(config, 'solver_warm_start', 0.0))
   if not 0.0 <= c.solver_warm_start <= 1.0:
     raise ValueError('solver_warm_start must be in [0, 1]')
   if c.solver_warm_start > 0 and not c.solver_residual_threshold > 0:
     raise ValueError('solver_warm_start is an option of the residual-threshold solver: set solver_residual_threshold > 0 '
                      '(pybullet documents 1e-7)')
-  c.rollout_streams = max(1, int(getattr(config, 'rollout_streams', 1)))
-  c.migrate_steps = int(getattr(config, 'migrate_steps', 0))
-  if c.migrate_steps < 0:
-    raise ValueError('migrate_steps must be >= 0')
+  c.rollout_streams = knob('rollout_streams')
+  c.migrate_steps = knob('migrate_steps')
   return c

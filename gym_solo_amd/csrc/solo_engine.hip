@@ -36,6 +36,8 @@ struct EngineBase {
   virtual int set_terrain(const SoloTerrain* t, hipStream_t s) = 0;
   virtual int set_order(const int32_t* order, hipStream_t s) = 0;
   virtual int time_step(const void* a, uint32_t flags, int reps, hipStream_t s, double* ms) = 0;
+  virtual int time_rollout(const void* a, int k, uint32_t flags, hipStream_t s, double* ms) = 0;
+  virtual int plan(int k, SoloLaunchPlan* out) = 0;
   virtual const char* kernel_name() = 0;
   std::string err;
 };
@@ -71,6 +73,10 @@ struct Engine final : EngineBase {
   double* stats = nullptr;
   T* terrain = nullptr;
   int32_t* queue = nullptr;   // robot-migration queues of the launches in flight (one region per rollout slice), or null
+  size_t queue_ints = 0;      // (allocated lazily, for the geometry of the rollout at hand)
+  int traj_steps = 0;         // steps the record scratch `traj` holds per robot (allocated lazily)
+  int32_t* fault_host = nullptr;  // pinned host word a wave that gives up waiting sets (SOLO_ERR_INCOMPLETE), device-visible
+  int32_t* fault_dev = nullptr;
 #ifdef SOLO_STAMPS
   unsigned long long* stamps = nullptr;
 #endif
@@ -86,11 +92,11 @@ struct Engine final : EngineBase {
                     (void*)obs, (void*)reward, (void*)settle_actions, (void*)done,
                     (void*)term_count, (void*)order, (void*)cost, (void*)stats, (void*)terrain, (void*)traj, (void*)queue, (void*)warm})
       if (p) (void)hipFree(p);
+    if (fault_host) (void)hipHostFree(fault_host);
   }
 
   int init(const SoloConfig& c, const SoloModel& m, int num_envs, int dev) {
     cfg = c; model = m; n = num_envs; device = dev;
-    rollout_streams = cfg.rollout_streams < 1 ? 1 : (cfg.rollout_streams > kMaxStreams ? kMaxStreams : cfg.rollout_streams);
     HIP_TRY(hipSetDevice(device));
     solo::pack_params<T>(cfg, model, &hparams);
     const size_t ns = (size_t)n * SOLO_STATE_STRIDE;
@@ -108,11 +114,11 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMalloc((void**)&order, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&cost, (size_t)n * sizeof(int32_t)));
     HIP_TRY(hipMemset(cost, 0, (size_t)n * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void**)&traj, (size_t)spl() * ns * sizeof(T)));
     HIP_TRY(hipMalloc((void**)&warm, (size_t)n * 64 * sizeof(T)));
     HIP_TRY(hipMemset(warm, 0, (size_t)n * 64 * sizeof(T)));
-    if (migrate_chunk() > 0)
-      HIP_TRY(hipMalloc((void**)&queue, ((size_t)kMaxStreams * solo::kQueueHeader + (size_t)n * (1 + solo::migration_chunks(spl(), migrate_chunk()))) * sizeof(int32_t)));
+    HIP_TRY(hipHostMalloc((void**)&fault_host, sizeof(int32_t), hipHostMallocMapped));
+    *fault_host = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&fault_dev, fault_host, 0));
     HIP_TRY(hipMemset(obs, 0, (size_t)n * SOLO_MAX_OBS * sizeof(T)));
     HIP_TRY(hipMemset(reward, 0, (size_t)n * sizeof(T)));
     HIP_TRY(hipMemset(done, 0, (size_t)n));
@@ -145,6 +151,7 @@ struct Engine final : EngineBase {
     b.stats = stats; b.terrain = terrain; b.order = use_order ? order : nullptr; b.cost = cost; b.num_envs = n; b.flags = flags; b.env_base = 0; b.count = n; b.steps = 1;
     b.action_stride = b.done_stride = 0;
     b.queue = nullptr; b.q_rings = 1; b.q_chunk = 0;
+    b.fault = fault_dev;
     b.warm = cfg.solver_warm_start > 0 ? warm : nullptr;
 #ifdef SOLO_STAMPS
     b.stamps = stamps;
@@ -154,10 +161,20 @@ struct Engine final : EngineBase {
 
   int launch(const T* actions, uint32_t flags, hipStream_t s) {
     // one 64-lane workgroup (= one wavefront) per robot, one env step
-    return launch_chain(actions, 0, 1, flags, nullptr, nullptr, nullptr, s, 0, n);
+    return launch_chain(Plan{1, 1, 1, 0}, actions, 0, 1, flags, nullptr, nullptr, nullptr, s, 0, n);
+  }
+
+  // (SOLO_ERR_INCOMPLETE, sticky: a wave of an earlier migrating launch gave up waiting - a plain read of a pinned host word)
+  int check_fault() {
+    if (fault_host != nullptr && *(volatile int32_t*)fault_host != 0) {
+      err = "a wave of an earlier launch with robot migration gave up waiting for its robot: some robots were not stepped through that launch (internal error)";
+      return SOLO_ERR_INCOMPLETE;
+    }
+    return SOLO_OK;
   }
 
   int settle(hipStream_t s) override {
+    if (int rc = check_fault()) return rc;
     HIP_TRY(hipSetDevice(device));
     const int total = n * SOLO_STATE_STRIDE;
     hipLaunchKernelGGL(solo::solo_init_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, state, targets,
@@ -166,8 +183,11 @@ struct Engine final : EngineBase {
     HIP_TRY(hipGetLastError());
     // the snapshot doubles as the divergence fallback during the settle loop itself
     HIP_TRY(hipMemcpyAsync(snapshot, state, (size_t)total * sizeof(T), hipMemcpyDeviceToDevice, s));
+    // (the settle loop starts from an empty warm-start cache too: a second settle - after a terrain or parameter change -
+    // must not depend on what was simulated before)
+    HIP_TRY(hipMemsetAsync(warm, 0, (size_t)n * 64 * sizeof(T), s));
     // the settle loop repeats one action: action stride 0 inside the fused launches
-    if (int rc = launch_chain(settle_actions, 0, cfg.settle_steps, SOLO_STEP_PHYSICS, nullptr, nullptr, nullptr, s, 0, n)) return rc;
+    if (int rc = launch_chain(make_plan(cfg.settle_steps, SOLO_STEP_PHYSICS), settle_actions, 0, cfg.settle_steps, SOLO_STEP_PHYSICS, nullptr, nullptr, nullptr, s, 0, n)) return rc;
     HIP_TRY(hipMemcpyAsync(snapshot, state, (size_t)total * sizeof(T), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemsetAsync(term_count, 0, (size_t)n * SOLO_MAX_TERMS * sizeof(int32_t), s));
     HIP_TRY(hipMemsetAsync(warm, 0, (size_t)n * 64 * sizeof(T), s));  // (the snapshot starts from an empty warm-start cache)
@@ -190,6 +210,7 @@ struct Engine final : EngineBase {
   }
 
   int reset(const uint8_t* mask, hipStream_t s) override {
+    if (int rc = check_fault()) return rc;
     HIP_TRY(hipSetDevice(device));
     const int total = n * SOLO_STATE_STRIDE;
     hipLaunchKernelGGL(solo::solo_reset_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, dparams, state, snapshot,
@@ -222,27 +243,79 @@ struct Engine final : EngineBase {
   }
 
   int step(const void* a, uint32_t flags, hipStream_t s) override {
+    if (int rc = check_fault()) return rc;
     if (int rc = check_flags(flags)) return rc;
     HIP_TRY(hipSetDevice(device));
     return launch((const T*)a, flags, s);
   }
 
-  // steps per fused launch: the configured number, capped so that the records of one launch stay below
-  // 2^32 elements (the step kernel addresses them with 32-bit offsets; at 4096 robots that is 32768 steps)
-  int spl() const {
-    const long long cap = ((1ll << 32) - 1) / ((long long)n * SOLO_STATE_STRIDE);
-    const long long want = cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1;
-    return (int)(want < cap ? want : (cap > 1 ? cap : 1));
+  // ---- THE LAUNCH POLICY (round 5: it was bench.py's).  A rollout of k steps runs as `launches` fused launches of S steps
+  //      per slice, `slices` independent launch chains, robots migrating every `migrate` steps of a launch (0: never).
+  //      Configured values are taken as they are; -1 = the engine chooses, from what was measured on the benchmark workload
+  //      (profiles/round5_launch_policy_ab.log):
+  //        * S = min(k, 250): the state record never leaves LDS inside a launch, and 250 steps average out the robots'
+  //          unequal solver costs (1.8e8 env-steps/s against 1.2e8 at 20 steps per launch, f64);
+  //        * two slices when the rollout takes several launches (one slice's launch boundary and tail overlap the other's
+  //          work: +1 ... 2 %), one when it is a single launch (halves of a single launch only shorten each other's tails);
+  //        * no migration while every robot of a launch has a wave slot of its own - 4096 robots: four waves on each of the
+  //          1024 SIMDs in BOTH precisions since round 5 (f64 round 4: three - 3072 slots - and migration was worth +16 %):
+  //          with all robots resident a hand-over only costs; beyond that, two chunks per launch (several launches: chunks
+  //          of 25 steps on ONE chain) let the waves that finish early take over the robots that started late.
+  struct Plan { int S, launches, slices, migrate; };
+  static constexpr int kWavesPerSimd = solo::kWavesPerSimd<T>;
+  int resident_robots() const {
+    hipDeviceProp_t p;
+    const int cus = (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    return cus * 4 * kWavesPerSimd;
   }
-
-  // robot migration (SoloConfig::migrate_steps): steps per chunk, 0 = off (never in the diagnostic stamps builds,
-  // whose per-wave stamps assume one robot per wave)
-  int migrate_chunk() const {
-#ifdef SOLO_STAMPS
-    return 0;
-#else
-    return cfg.migrate_steps > 0 ? cfg.migrate_steps : 0;
+  int resident_cache = 0;
+  Plan make_plan(int k, uint32_t flags) {
+    if (resident_cache == 0) resident_cache = resident_robots();
+    // steps per fused launch, capped so that the records of one launch stay below 2^32 elements (the step kernel
+    // addresses them with 32-bit offsets; at 4096 robots that is 32768 steps)
+    const long long cap = ((1ll << 32) - 1) / ((long long)n * SOLO_STATE_STRIDE);
+    long long want = cfg.steps_per_launch == -1 ? (k < 250 ? k : 250) : (cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1);
+    if (want > k && k > 0) want = k;
+    Plan p;
+    p.S = (int)(want < cap ? want : (cap > 1 ? cap : 1));
+    if (p.S < 1) p.S = 1;
+    p.launches = (k + p.S - 1) / p.S;
+    const bool physics_only = flags == SOLO_STEP_PHYSICS;   // (stepSimulation-only launches - the settle loop - never migrate: their robots are in step)
+    int streams = cfg.rollout_streams == -1 ? (p.launches > 1 ? 2 : 1) : cfg.rollout_streams;
+    streams = streams < 1 ? 1 : (streams > kMaxStreams ? kMaxStreams : streams);
+    p.migrate = 0;
+#ifndef SOLO_STAMPS   // (never in the diagnostic stamps builds, whose per-wave stamps assume one robot per wave)
+    if (cfg.migrate_steps > 0) p.migrate = cfg.migrate_steps;
+    else if (cfg.migrate_steps == -1 && !physics_only && (flags & SOLO_STEP_PHYSICS) && p.S >= 8) {
+      const int per_slice = streams > 1 && n >= 2 * streams ? n / streams : n;
+      if (per_slice > resident_cache) {
+        if (p.launches == 1) p.migrate = (p.S + 1) / 2;
+        else if (p.S >= 50) { p.migrate = 25; if (cfg.rollout_streams == -1) streams = 1; }
+      }
+    }
 #endif
+    p.slices = (streams > 1 && n >= 2 * streams) ? streams : 1;
+    return p;
+  }
+  // the record scratch of fused launches and the migration queues are sized for the rollout at hand (a larger one grows them)
+  int ensure_scratch(const Plan& p, uint32_t flags) {
+    const bool records = (flags & (SOLO_STEP_OBS | SOLO_STEP_REWARD)) != 0;
+    if (records && p.S > traj_steps) {
+      HIP_TRY(hipDeviceSynchronize());
+      if (traj) { (void)hipFree(traj); traj = nullptr; traj_steps = 0; }
+      HIP_TRY(hipMalloc((void**)&traj, (size_t)p.S * (size_t)n * SOLO_STATE_STRIDE * sizeof(T)));
+      traj_steps = p.S;
+    }
+    if (p.migrate > 0) {
+      const size_t need = (size_t)kMaxStreams * solo::kQueueHeader + (size_t)n * (1 + solo::migration_chunks(p.S, solo::migration_chunk_steps(p.S, p.migrate)));
+      if (need > queue_ints) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (queue) { (void)hipFree(queue); queue = nullptr; queue_ints = 0; }
+        HIP_TRY(hipMalloc((void**)&queue, need * sizeof(int32_t)));
+        queue_ints = need;
+      }
+    }
+    return SOLO_OK;
   }
 
   // one chain of launches covering steps [0, k) for robots [lo, lo+count): per launch the step
@@ -250,9 +323,10 @@ struct Engine final : EngineBase {
   // final_chunk: this chain ends the caller's rollout - a RECORDING rollout then has its last launch's epilogue
   // also leave the last step's observation / reward / done in the engine's view (what three
   // device-to-device copies after the chain used to do: ~15 us of a 0.4 ms 20-step rollout)
-  int launch_chain(const T* act, long long act_stride, int k, uint32_t flags, T* obs_out, T* reward_out,
+  int launch_chain(const Plan& plan, const T* act, long long act_stride, int k, uint32_t flags, T* obs_out, T* reward_out,
                    uint8_t* done_out, hipStream_t s, int lo, int count, bool final_chunk = true, int slice = 0) {
-    const int S = spl();
+    const int S = plan.S;
+    if (int rc = ensure_scratch(plan, flags)) return rc;
     const bool want_obs = (flags & SOLO_STEP_OBS) != 0, want_reward = (flags & SOLO_STEP_REWARD) != 0;
     for (int i = 0; i < k; i += S) {
       const int steps = (k - i < S) ? (k - i) : S;
@@ -274,7 +348,7 @@ struct Engine final : EngineBase {
         // a rollout run side by side with DIFFERENT step counts when one of them is already in its ragged last launch -
         // indexed by absolute robot x steps of the launch their regions overlapped: a race that round 4's warm-start
         // test caught, tests/test_gpu_warm_start.py)
-        b.traj = traj + (size_t)lo * (size_t)spl() * SOLO_STATE_STRIDE;
+        b.traj = traj + (size_t)lo * (size_t)traj_steps * SOLO_STATE_STRIDE;
         // a recording rollout keeps every step ([K][N][.] buffers of the caller) and its last launch also leaves the
         // last step in the engine's view; otherwise only the last step's observation / reward / done stay in the view
         const bool tail_to_view = final_chunk && i + S >= k;
@@ -294,11 +368,11 @@ struct Engine final : EngineBase {
       // (stepSimulation-only launches - the settle loop, client.stepSimulation() - keep the physics-only instantiation:
       // their robots are in step with each other, there is nothing to balance, and in profiles the settle loop stays a
       // kernel of its own instead of inflating the measured one's average)
-      if (migrate_chunk() > 0 && steps > migrate_chunk() && (flags & SOLO_STEP_PHYSICS) && flags != SOLO_STEP_PHYSICS) {
-        const int chunk = solo::migration_chunk_steps(steps, migrate_chunk());
+      if (plan.migrate > 0 && steps > plan.migrate && (flags & SOLO_STEP_PHYSICS) && flags != SOLO_STEP_PHYSICS) {
+        const int chunk = solo::migration_chunk_steps(steps, plan.migrate);
         b.q_chunk = chunk;
         b.q_rings = solo::migration_rings(count);
-        b.queue = queue + (size_t)slice * solo::kQueueHeader + (size_t)lo * (1 + solo::migration_chunks(spl(), migrate_chunk()));
+        b.queue = queue + (size_t)slice * solo::kQueueHeader + (size_t)lo * (1 + solo::migration_chunks(S, solo::migration_chunk_steps(S, plan.migrate)));
         const size_t ints = solo::migration_queue_ints(count, steps, chunk);
         hipLaunchKernelGGL(solo::solo_queue_init_kernel, dim3((unsigned)((ints + 255) / 256)), dim3(256), 0, s, b.queue, ints, lo, count,
                            b.q_rings, steps, chunk, (const int32_t*)(use_order ? order : nullptr));
@@ -324,14 +398,16 @@ struct Engine final : EngineBase {
   }
 
   int rollout(const void* a, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out, hipStream_t s) override {
+    if (int rc = check_fault()) return rc;
     if (int rc = check_flags(flags)) return rc;
     if (k == 0) return SOLO_OK;  // an empty rollout is a no-op
     if (!a || k < 0) { err = "rollout needs actions [K][N][12]"; return SOLO_ERR_INVALID_ARG; }
-    if (int rc = rollout_impl((const T*)a, k, flags, obs_out, reward_out, done_out, s, nullptr, nullptr)) return rc;
+    const Plan plan = make_plan(k, flags);
+    if (int rc = rollout_impl(plan, (const T*)a, k, flags, obs_out, reward_out, done_out, s, nullptr, nullptr)) return rc;
     // the engine's view always ends up with the LAST step's outputs, also when every step was recorded: the last
     // launch's output kernel writes them (launch_chain); only rollouts whose last launch is a single-step launch with
     // in-place outputs (steps_per_launch = 1 in f32, or a one-step remainder) copy
-    const int S = spl();
+    const int S = plan.S;
     const int last_steps = (k % S == 0) ? S : k % S;
     // ... and recording rollouts that asked for neither observations nor rewards: their launches leave no records (no
     // epilogue runs), the step kernel writes the done flags straight into the caller's [K][N] buffer
@@ -348,18 +424,19 @@ struct Engine final : EngineBase {
 
   // t0 / t1 (optional, [groups] each): timing events recorded around every slice's launch chain, on
   // the stream that chain is launched on
-  int rollout_impl(const T* act, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out,
+  int rollout_impl(const Plan& plan, const T* act, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out,
                    hipStream_t s, hipEvent_t* t0, hipEvent_t* t1, int* groups_out = nullptr) {
     HIP_TRY(hipSetDevice(device));
     const long long stride = act ? (long long)n * SOLO_NUM_JOINTS : 0;
     T* oo = (flags & SOLO_STEP_OBS) ? (T*)obs_out : nullptr;
     T* ro = (flags & SOLO_STEP_REWARD) ? (T*)reward_out : nullptr;
     uint8_t* dn = (flags & SOLO_STEP_DONE) ? (uint8_t*)done_out : nullptr;
-    const int groups = slices();
+    const int groups = plan.slices;
     if (groups_out) *groups_out = groups;
+    if (int rc = ensure_scratch(plan, flags)) return rc;   // (before any timing event is recorded)
     if (groups == 1) {
       if (t0) HIP_TRY(hipEventRecord(t0[0], s));
-      if (int rc = launch_chain(act, stride, k, flags, oo, ro, dn, s, 0, n)) return rc;
+      if (int rc = launch_chain(plan, act, stride, k, flags, oo, ro, dn, s, 0, n)) return rc;
       if (t1) HIP_TRY(hipEventRecord(t1[0], s));
       return SOLO_OK;
     }
@@ -372,12 +449,12 @@ struct Engine final : EngineBase {
       HIP_TRY(hipStreamWaitEvent(sub[g], ev_fork, 0));
       if (t0) HIP_TRY(hipEventRecord(t0[g], sub[g]));
     }
-    const int S = spl();
+    const int S = plan.S;
     for (int i = 0; i < k; i += S)
       for (int g = 0; g < groups; ++g) {
         const int lo = (int)((long long)n * g / groups), hi = (int)((long long)n * (g + 1) / groups);
         const int kk = (k - i < S) ? (k - i) : S;
-        if (int rc = launch_chain(act ? act + (size_t)i * stride : nullptr, stride, kk, flags,
+        if (int rc = launch_chain(plan, act ? act + (size_t)i * stride : nullptr, stride, kk, flags,
                                   oo ? oo + (size_t)i * n * obs_dim : nullptr, ro ? ro + (size_t)i * n : nullptr,
                                   dn ? dn + (size_t)i * n : nullptr, sub[g], lo, hi - lo, i + S >= k, g))
           return rc;
@@ -390,11 +467,13 @@ struct Engine final : EngineBase {
     return SOLO_OK;
   }
 
-  // number of independent launch chains a rollout / step is cut into
-  int slices() const { return (rollout_streams > 1 && n >= 2 * rollout_streams) ? rollout_streams : 1; }
+  // the most slices a rollout of this engine can be cut into (what a launch order has to respect)
+  int max_slices() const {
+    const int streams = cfg.rollout_streams == -1 ? 2 : (cfg.rollout_streams < 1 ? 1 : (cfg.rollout_streams > kMaxStreams ? kMaxStreams : cfg.rollout_streams));
+    return (streams > 1 && n >= 2 * streams) ? streams : 1;
+  }
 
   static constexpr int kMaxStreams = 8;
-  int rollout_streams = 1;
   hipStream_t sub[kMaxStreams] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {};
   int ensure_streams(int groups) {
@@ -418,7 +497,11 @@ struct Engine final : EngineBase {
     hipEvent_t* e0 = ev.e;
     hipEvent_t* e1 = ev.e + kMaxStreams;
     int groups = 1;
-    const int rc_chain = rollout_impl((const T*)a, reps * spl(), flags, nullptr, nullptr, nullptr, s, e0, e1, &groups);
+    // (reps launches of the CONFIGURED steps per launch - one step when that is left to the engine: solo_engine_time_rollout
+    // times a rollout of a given length with the engine's own geometry)
+    const int S = cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1;
+    Plan plan = make_plan(reps * S, flags);
+    const int rc_chain = rollout_impl(plan, (const T*)a, reps * S, flags, nullptr, nullptr, nullptr, s, e0, e1, &groups);
     if (rc_chain) return rc_chain;
     HIP_TRY(hipStreamSynchronize(s));
     // every slice's chain is timed on its own stream; the AVERAGE launch duration over all slices
@@ -429,7 +512,40 @@ struct Engine final : EngineBase {
       HIP_TRY(hipEventElapsedTime(&t, e0[g], e1[g]));
       total += t;
     }
-    *ms = total / groups / reps;
+    *ms = total / groups / plan.launches;
+    return SOLO_OK;
+  }
+
+  int time_rollout(const void* a, int k, uint32_t flags, hipStream_t s, double* ms) override {
+    if (int rc = check_flags(flags)) return rc;
+    if (k <= 0 || !ms) { err = "num_steps must be positive"; return SOLO_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    struct Events {
+      hipEvent_t e[2 * kMaxStreams] = {};
+      ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (hipEvent_t& x : ev.e) HIP_TRY(hipEventCreate(&x));
+    int groups = 1;
+    const Plan plan = make_plan(k, flags);
+    if (int rc = rollout_impl(plan, (const T*)a, k, flags, nullptr, nullptr, nullptr, s, ev.e, ev.e + kMaxStreams, &groups)) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    double total = 0;
+    for (int g = 0; g < groups; ++g) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, ev.e[g], ev.e[kMaxStreams + g]));
+      total += t;
+    }
+    *ms = total / groups / plan.launches;
+    return SOLO_OK;
+  }
+
+  int plan(int k, SoloLaunchPlan* out) override {
+    if (k <= 0 || !out) { err = "num_steps must be positive"; return SOLO_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    const Plan p = make_plan(k, SOLO_STEP_ALL);
+    out->steps_per_launch = p.S; out->launches = p.launches; out->slices = p.slices;
+    out->migrate_steps = (p.migrate > 0 && p.S > p.migrate) ? solo::migration_chunk_steps(p.S, p.migrate) : 0;
+    out->waves_per_simd = kWavesPerSimd; out->resident_robots = resident_cache;
     return SOLO_OK;
   }
 
@@ -467,7 +583,7 @@ struct Engine final : EngineBase {
     HIP_TRY(hipMemcpyAsync(h.data(), o, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     std::vector<uint8_t> seen((size_t)n, 0);
-    const int groups = slices();
+    const int groups = max_slices();
     for (int g = 0; g < groups; ++g) {
       const int lo = (int)((long long)n * g / groups), hi = (int)((long long)n * (g + 1) / groups);
       for (int i = lo; i < hi; ++i) {
@@ -537,10 +653,12 @@ int check_config(const SoloConfig* c, std::string* err) {
   if (c->solver_ulp_tolerance < 0 || c->solver_ulp_tolerance > (1 << 20)) return fail("solver_ulp_tolerance out of range");
   if (!(c->solver_residual_threshold >= 0)) return fail("solver_residual_threshold must be >= 0");
   if (c->settle_steps < 0 || c->settle_steps > 100000) return fail("settle_steps out of range");
-  if (c->steps_per_launch < 0 || c->steps_per_launch > 100000) return fail("steps_per_launch out of range");
+  if (c->steps_per_launch < -1 || c->steps_per_launch > 100000) return fail("steps_per_launch out of range (-1 = the engine chooses)");
+  if (c->rollout_streams < -1 || c->rollout_streams > 64) return fail("rollout_streams out of range (-1 = the engine chooses)");
   if (!(c->solver_warm_start >= 0 && c->solver_warm_start <= 1)) return fail("solver_warm_start must be in [0, 1]");
   if (c->solver_warm_start > 0 && !(c->solver_residual_threshold > 0)) return fail("solver_warm_start needs solver_residual_threshold > 0");
-  if (c->migrate_steps < 0 || c->migrate_steps > 100000 || c->reserved0 != 0) return fail("migrate_steps out of range");
+  if (c->migrate_steps < -1 || c->migrate_steps > 100000) return fail("migrate_steps out of range (-1 = the engine chooses)");
+  if (c->reserved0 != 0) return fail("reserved0 must be 0");
   // (restitution: accepted, and without effect - see include/solo_engine.h: Bullet combines it with the ground's, which is 0)
   if (!(c->restitution >= 0 && c->restitution <= 1)) return fail("restitution must be in [0, 1] (gym_solo configs.py:23)");
   if (!(c->action_scale > 0)) return fail("action_scale must be positive");
@@ -634,6 +752,10 @@ const char* solo_engine_kernel_name(SoloEngine* eng) { return eng && eng->impl ?
 int solo_engine_time_step(SoloEngine* eng, const void* a, uint32_t flags, int32_t reps, void* stream, double* ms) {
   return ENG_CALL(time_step(a, flags, reps, (hipStream_t)stream, ms));
 }
+int solo_engine_time_rollout(SoloEngine* eng, const void* a, int32_t k, uint32_t flags, void* stream, double* ms) {
+  return ENG_CALL(time_rollout(a, k, flags, (hipStream_t)stream, ms));
+}
+int solo_engine_plan(SoloEngine* eng, int32_t k, SoloLaunchPlan* out) { return ENG_CALL(plan(k, out)); }
 const char* solo_engine_last_error(SoloEngine* eng) { return eng && eng->impl ? eng->impl->err.c_str() : "invalid engine handle"; }
 
 }  // extern "C"

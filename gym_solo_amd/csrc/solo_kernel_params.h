@@ -206,6 +206,7 @@ struct KBuffers {
   // steps one robot through the whole launch; number of rings (8: one per XCD, or 1); steps per chunk
   int32_t* queue;
   int32_t q_rings, q_chunk;
+  int32_t* fault;      // pinned HOST word (device-visible): set by a wave that gives up waiting for its robot (SOLO_ERR_INCOMPLETE)
 #ifdef SOLO_STAMPS
   int32_t stamp_row;           // (set by the kernel: the robot this wave steps)
   unsigned long long* stamps;  // [N][32] s_memtime stamps, DIAGNOSTIC builds only (make stamps):

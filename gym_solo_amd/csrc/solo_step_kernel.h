@@ -1226,7 +1226,10 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       if (ready >= 0) break;
       wave_backoff();
     }
-    if (ready < 0) { if (lane0 == 0) stats_add(&wave_cold_args(Bin)->stats[6], 1.0); break; }
+    if (ready < 0) {   // (the host finds the word set at its next call: SOLO_ERR_INCOMPLETE)
+      if (lane0 == 0) { stats_add(&wave_cold_args(Bin)->stats[6], 1.0); if (wave_cold_args(Bin)->fault != nullptr) wave_fault_set(wave_cold_args(Bin)->fault); }
+      break;
+    }
     wave_acquire_device();  // (orders the loads of the robot's record and counters behind the poll)
     // the slot says which robot and which of its chunks: everything else is loaded in ONE round trip below
     env = B.env_base + (ready & 0xffffff);

@@ -396,6 +396,8 @@ __device__ __forceinline__ void wave_release_device() {
 }
 __device__ __forceinline__ void wave_acquire_device() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 __device__ __forceinline__ void wave_backoff() { __builtin_amdgcn_s_sleep(8); }
+// the engine's fault word lives in pinned host memory: a system-scope store
+__device__ __forceinline__ void wave_fault_set(int32_t* p) { __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // the XCD this wave runs on (hardware register XCC_ID)
 __device__ __forceinline__ int wave_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf); }
 

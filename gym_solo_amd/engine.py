@@ -185,7 +185,25 @@ class Engine:
 
   @property
   def steps_per_launch(self):
+    """The CONFIGURED steps per launch (1 when the choice is left to the engine: plan(k) says what a rollout of k steps runs with)."""
     return max(1, int(self.cfg.steps_per_launch))
+
+  def plan(self, num_steps):
+    """The launch geometry a rollout of num_steps steps runs with (solo_engine_plan): dict(steps_per_launch, launches,
+    slices, migrate_steps, waves_per_simd, resident_robots) - the measured launch policy lives in the engine."""
+    p = abi.SoloLaunchPlan()
+    self._check(self.lib.solo_engine_plan(self._handle(), int(num_steps), C.byref(p)), 'plan')
+    return {name: int(getattr(p, name)) for name, _ in abi.SoloLaunchPlan._fields_}
+
+  def time_rollout(self, actions, flags=abi.STEP_ALL):
+    """Mean ms per LAUNCH of one rollout of actions.shape[0] steps run exactly as rollout() runs it (plan()'s
+    geometry), measured with HIP events on the launch streams."""
+    actions = self._as_real(actions)
+    k = int(actions.shape[0])
+    p = self._dev_ptr(actions, (k, self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
+    ms = C.c_double()
+    self._check(self.lib.solo_engine_time_rollout(self._handle(), p, k, flags, self._stream(), C.byref(ms)), 'time_rollout')
+    return ms.value
 
   def rollout_buffers(self, k):
     """Trajectory buffers for rollout(record=True): obs [K,N,D], reward [K,N], done [K,N] uint8."""
@@ -250,7 +268,8 @@ class Engine:
     launch, persistent within an episode), slice by slice.  Matters when N exceeds the chip's 4096
     resident waves; results do not depend on it."""
     torch = self._torch
-    g = max(1, int(self.cfg.rollout_streams))
+    g = int(self.cfg.rollout_streams)
+    g = 2 if g == abi.AUTO else max(1, g)   # (left to the engine, a rollout runs on one or two slices: an order that respects two respects one)
     g = g if (g > 1 and self.num_envs >= 2 * g) else 1
     parts = []
     for s in range(g):
@@ -279,6 +298,7 @@ class Engine:
   # ---- checkpoint / resume (the reference has none - reset() rebuilds the world; here the
   #      whole simulation is a handful of device tensors) --------------------------------------------------------
   _CHECKPOINT = ('state', 'snapshot', 'targets', 'term_count', 'params', 'stats_shards', 'cost', 'warm')
+  CHECKPOINT_VERSION = 2   # 1: before ABI 4 (no snapshot, no warm-start cache, no version tag); 2: the fields above + 'version'
 
   def get_state(self):
     """Everything a run continues from, as clones on the device: the robots' state records (episodic return / length
@@ -288,22 +308,33 @@ class Engine:
     per-robot solver cost (which decides a closed-loop launch's wave priorities, not results).  Terrain and the
     compiled configuration are NOT part of it: restore into an engine built with the same ones."""
     self._torch.cuda.current_stream(self.device).synchronize()
-    return {name: getattr(self, name).clone() for name in self._CHECKPOINT}
+    ck = {name: getattr(self, name).clone() for name in self._CHECKPOINT}
+    ck['version'] = self.CHECKPOINT_VERSION
+    return ck
 
   def set_state(self, checkpoint):
     """Restores a get_state() checkpoint (of an engine with the same number of robots and precision): the next step
     continues bit for bit where the checkpointed run would have.  Listeners registered with on_restore() (the env's
     client: its cached observations / rewards are those of the state before the restore) are told."""
-    missing = [name for name in self._CHECKPOINT if name not in checkpoint]
+    version = int(checkpoint.get('version', 1))
+    if version > self.CHECKPOINT_VERSION:
+      raise ValueError('checkpoint version {} is newer than this engine understands ({})'.format(version, self.CHECKPOINT_VERSION))
+    # version 1 (before ABI 4) carries neither the reset snapshot nor the warm-start cache: the engine's CURRENT snapshot
+    # stays in force (it is what reset() would restore anyway after the same settle()) and the cache starts empty
+    optional = ('snapshot', 'warm') if version < 2 else ()
+    missing = [name for name in self._CHECKPOINT if name not in checkpoint and name not in optional]
     if missing:
-      raise ValueError('checkpoint lacks the field(s) {}: it was not written by Engine.get_state() of this version'.format(missing))
-    for name in self._CHECKPOINT:
+      raise ValueError('checkpoint (version {}) lacks the field(s) {}'.format(version, missing))
+    names = [name for name in self._CHECKPOINT if name in checkpoint]
+    for name in names:
       src, dst = checkpoint[name], getattr(self, name)
       if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
         raise ValueError('checkpoint field {!r} has shape {} / dtype {}, the engine has {} / {}'.format(
           name, tuple(src.shape), src.dtype, tuple(dst.shape), dst.dtype))
-    for name in self._CHECKPOINT:
+    for name in names:
       getattr(self, name).copy_(checkpoint[name])
+    if 'warm' not in checkpoint:
+      self.warm.zero_()
     for hook in getattr(self, '_restore_hooks', ()):
       hook()
 

@@ -36,9 +36,12 @@
 extern "C" {
 #endif
 
-#define SOLO_ABI_VERSION 4  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets
+#define SOLO_ABI_VERSION 5  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets
                                3: SoloConfig::solver_residual_threshold
-                               4: SoloConfig::migrate_steps, SoloConfig::solver_warm_start, SoloStateView::warm */
+                               4: SoloConfig::migrate_steps, SoloConfig::solver_warm_start, SoloStateView::warm
+                               5: -1 = "the engine chooses" for steps_per_launch / rollout_streams / migrate_steps (the measured
+                                  launch policy lives in the engine: solo_engine_plan reports it), solo_engine_time_rollout,
+                                  SOLO_ERR_INCOMPLETE */
 
 /* ---- fixed Solo8 dimensions -------------------------------------------- */
 #define SOLO_NUM_LEGS 4
@@ -75,7 +78,11 @@ typedef enum SoloStatus {
   SOLO_ERR_NO_PROGRAM = -4,  /* step() without a reward / obs / termination registered:
                                 mirrors the ValueErrors of rewards.py:115-116, obs.py:138-139,
                                 termination.py:43-44 */
-  SOLO_ERR_NO_DEVICE = -5
+  SOLO_ERR_NO_DEVICE = -5,
+  SOLO_ERR_INCOMPLETE = -6   /* a wave of an EARLIER launch with robot migration gave up waiting for its robot (a bounded
+                                wait that a correct queue never exhausts): some robots were not stepped through that
+                                launch.  Sticky: every later call on the handle returns it.  An internal error - never
+                                observed - surfaced instead of returned as SOLO_OK; the count is slot 6 of the statistics. */
 } SoloStatus;
 
 typedef enum SoloDType { SOLO_F32 = 0, SOLO_F64 = 1 } SoloDType;
@@ -131,9 +138,11 @@ typedef struct SoloConfig {
   double action_scale;       /* normalize_actions ? max_motor_rotation : 1 (solo8v2vanilla.py:84-85) */
   int32_t auto_reset;        /* 1: envs whose `done` fires are restored from the snapshot in-kernel */
   int32_t steps_per_launch;  /* rollouts / settle fuse this many consecutive env steps of each robot
-                                into one kernel launch (state stays in LDS); 0 or 1 = one step */
+                                into one kernel launch (state stays in LDS); 0 or 1 = one step;
+                                -1 = the engine chooses (a rollout of K steps: launches of min(K, 250) steps) */
   int32_t rollout_streams;   /* rollouts cut the batch into this many slices that advance as
-                                independent launch chains on internal HIP streams (0/1 = off) */
+                                independent launch chains on internal HIP streams (0/1 = off);
+                                -1 = the engine chooses (two slices when a rollout takes more than one launch) */
   int32_t solver_ulp_tolerance; /* k: a Gauss-Seidel row whose clamped candidate differs from its impulse by
                                 at most k half-ulps relative to the impulse (|d| <= k * 2^-24 |lam| in f32,
                                 k * 2^-53 |lam| in f64) is left untouched, and a sweep that changes no row
@@ -153,7 +162,10 @@ typedef struct SoloConfig {
                                 steps through a work queue in device memory (the robot's 256-B record travels; any idle
                                 wave continues any robot), so that the launch ends when the WORK is done and not when
                                 the unluckiest SIMD's robots are.  Scheduling only: results are bit-identical.  0 = off
-                                (one wave steps one robot through the whole launch). */
+                                (one wave steps one robot through the whole launch).  -1 = the engine chooses: off while
+                                every robot of a launch has a wave slot of its own (4096 robots: four waves on each of
+                                the chip's 1024 SIMDs, in both precisions since round 5), else two chunks per launch
+                                (chunks of 25 steps in a rollout of several launches) - solo_engine_plan reports it. */
   int32_t reserved0;         /* (padding; must be 0) */
   double solver_warm_start;  /* f in (0, 1]: the Gauss-Seidel iteration of a step STARTS from f x the impulses the previous
                                 step ended with (every row: motors, joint limits, contacts - clamped to the row's bounds
@@ -254,7 +266,8 @@ typedef struct SoloStateView {
   void* term_count;     /* int32 [N][SOLO_MAX_TERMS]                      */
   void* params;         /* real  [N][4]: lateral friction, base-mass scale, 2 spare */
   void* stats;          /* double[SOLO_STATS_SHARDS][8], sum over the shard axis: sum return, sum return^2,
-                           episodes, sum length, (unused), diverged robots restored, 2 spare */
+                           episodes, sum length, (unused), diverged robots restored, waves of migrating launches that
+                           gave up waiting (row 0 only; non-zero = SOLO_ERR_INCOMPLETE), 1 spare */
   void* cost;           /* int32 [N]: Gauss-Seidel sweeps each robot ran in the LAST launch that stepped it
                            (its cost is persistent within an episode): input of solo_engine_set_order */
   void* warm;           /* real  [N][64]: the impulses every robot's last step ended with, one per constraint row in the
@@ -345,6 +358,22 @@ const char* solo_engine_kernel_name(SoloEngine* eng);
  * actions_dev: real [reps * steps_per_launch][N][12] or NULL. */
 int solo_engine_time_step(SoloEngine* eng, const void* actions_dev, uint32_t flags,
                           int32_t reps, void* stream, double* ms_per_launch);
+/* The launch geometry a rollout of num_steps steps runs with (what -1 = "the engine chooses" resolved to, or the
+ * configured values): the measured launch policy is the engine's, not the caller's. */
+typedef struct SoloLaunchPlan {
+  int32_t steps_per_launch;  /* env steps fused into one launch (the last launch of a slice may be shorter) */
+  int32_t launches;          /* launches per slice */
+  int32_t slices;            /* independent launch chains (batch slices on internal HIP streams) */
+  int32_t migrate_steps;     /* steps per migration chunk of a launch, 0 = no robot migration */
+  int32_t waves_per_simd;    /* resident step-kernel waves per SIMD in this precision (4) */
+  int32_t resident_robots;   /* robots with a wave slot of their own on this device: waves_per_simd x SIMDs */
+} SoloLaunchPlan;
+int solo_engine_plan(SoloEngine* eng, int32_t num_steps, SoloLaunchPlan* out);
+/* Times ONE rollout of num_steps steps exactly as solo_engine_rollout runs it (solo_engine_plan's geometry) with hipEvents
+ * recorded on the streams the kernels are launched on; returns the mean milliseconds per LAUNCH over all slices and
+ * launches.  actions_dev: real [num_steps][N][12]. */
+int solo_engine_time_rollout(SoloEngine* eng, const void* actions_dev, int32_t num_steps, uint32_t flags,
+                             void* stream, double* ms_per_launch);
 const char* solo_engine_last_error(SoloEngine* eng);
 /* library-level: last error of a failed create (eng == NULL) */
 const char* solo_last_create_error(void);

@@ -103,7 +103,7 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   // robot migration (SoloConfig::migrate_steps), as Engine::launch_chain sets it up: chunks of the launch's steps go
   // through the queue; the emulated waves run one after the other, so the first drains every ring it can reach
   std::vector<int32_t> queue;
-  B.queue = nullptr; B.q_rings = 1; B.q_chunk = 0;
+  B.queue = nullptr; B.q_rings = 1; B.q_chunk = 0; B.fault = nullptr;
   B.warm = wrm.empty() ? nullptr : wrm.data();
   if (cfg->migrate_steps > 0 && steps > cfg->migrate_steps && (flags & SOLO_STEP_PHYSICS) && flags != SOLO_STEP_PHYSICS) {  // (as the engine: stepSimulation-only launches do not migrate)
     B.q_chunk = migration_chunk_steps(steps, cfg->migrate_steps);

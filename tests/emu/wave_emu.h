@@ -139,6 +139,7 @@ template <typename T> inline void wave_store_shared(T* p, T v) { *p = v; }
 inline void wave_release_device() {}
 inline void wave_acquire_device() {}
 inline void wave_backoff() {}
+inline void wave_fault_set(int32_t* p) { *p = 1; }
 inline int wave_xcc_id() { return (int)(blockIdx.x & 7); }  // (as the hardware deals workgroups over the XCDs)
 inline void wave_fence_global() {}  // (one emulated wave runs its lanes as fibres over plain memory)
 template <typename T> struct RowDot {

@@ -181,6 +181,20 @@ class EmuTorchEngine:
   def steps_per_launch(self):
     return max(1, int(self.cfg.steps_per_launch))
 
+  def plan(self, num_steps):
+    """The engine's launch policy as far as an emulator has one (solo_engine.hip: make_plan): fused launches of
+    min(K, 250) steps when the choice is left to the engine; one chain, no migration unless configured."""
+    spl = min(int(num_steps), 250) if int(self.cfg.steps_per_launch) == -1 else min(self.steps_per_launch, int(num_steps))
+    spl = max(1, spl)
+    return {'steps_per_launch': spl, 'launches': -(-int(num_steps) // spl), 'slices': 1, 'migrate_steps': max(0, int(self.cfg.migrate_steps)),
+            'waves_per_simd': 0, 'resident_robots': 0}
+
+  def time_rollout(self, actions, flags=abi.STEP_ALL):
+    import time
+    t0 = time.perf_counter()
+    self.rollout(actions, flags)
+    return (time.perf_counter() - t0) * 1e3 / self.plan(actions.shape[0])['launches']
+
   def rollout_buffers(self, k):
     torch = self._torch
     return (torch.empty(k, self.num_envs, max(self.obs_dim, 1), dtype=torch.float64), torch.empty(k, self.num_envs, dtype=torch.float64),
@@ -189,7 +203,8 @@ class EmuTorchEngine:
   def rollout(self, actions, flags=abi.STEP_ALL, record=False, out=None):
     """K open-loop steps in fused launches of steps_per_launch steps (robot migration as configured)."""
     a = actions.detach().cpu().numpy()
-    k, spl = a.shape[0], self.steps_per_launch
+    k = a.shape[0]
+    spl = self.plan(k)['steps_per_launch']
     parts = [self._e.rollout(a[i:i + spl], flags) for i in range(0, k, spl)]
     if not record and out is None:
       return None

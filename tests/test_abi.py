@@ -44,7 +44,7 @@ def test_field_offsets_match_header():
   struct of the boundary (names taken from the ctypes mirror, so a field missing in the header fails the compile)."""
   import subprocess, tempfile
   structs = [t for t in (abi.SoloModel, abi.SoloConfig, abi.SoloObsElem, abi.SoloRewardInstr, abi.SoloProgram,
-                         abi.SoloStateView, abi.SoloTerrain)]
+                         abi.SoloStateView, abi.SoloTerrain, abi.SoloLaunchPlan)]
   lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "solo_engine.h"', 'int main(){']
   want = []
   for t in structs:
@@ -117,6 +117,17 @@ def test_create_rejects_bad_arguments():
   ca.restitution = -0.5   # ([0, 1] is accepted - and has no effect: the ground's restitution is 0, include/solo_engine.h)
   assert lib.solo_engine_create(C.byref(ca), C.byref(ma), 4, 0, C.byref(h)) == abi.ERR_INVALID_ARG
   assert b'restitution' in lib.solo_last_create_error()
+  # the launch knobs: -1 = the engine chooses, anything below is rejected; the padding word has a message of its own
+  for knob in ('steps_per_launch', 'rollout_streams', 'migrate_steps'):
+    ca, ma = make_abi('float32')
+    setattr(ca, knob, -2)
+    assert lib.solo_engine_create(C.byref(ca), C.byref(ma), 4, 0, C.byref(h)) == abi.ERR_INVALID_ARG
+    assert knob.encode() in lib.solo_last_create_error()
+  ca, ma = make_abi('float32')
+  assert (ca.steps_per_launch, ca.rollout_streams, ca.migrate_steps) == (abi.AUTO, abi.AUTO, abi.AUTO)   # the host defaults
+  ca.reserved0 = 7
+  assert lib.solo_engine_create(C.byref(ca), C.byref(ma), 4, 0, C.byref(h)) == abi.ERR_INVALID_ARG
+  assert b'reserved0' in lib.solo_last_create_error()
   ca, ma = make_abi('float32')
   ma.joint_axis[3][1] = 0.0
   ma.joint_axis[3][2] = 1.0

@@ -343,8 +343,18 @@ def test_checkpoint_carries_the_reset_snapshot(dtype):
   for a, b in zip(want, got):
     assert torch.equal(a, b)
   assert torch.equal(first.engine.state, second.engine.state) and torch.equal(first.engine.snapshot, second.engine.snapshot)
-  with pytest.raises(ValueError):
+  with pytest.raises(ValueError):   # a version-2 checkpoint must be whole
     second.engine.set_state({k: v for k, v in ck.items() if k != 'snapshot'})
+  assert ck['version'] == second.engine.CHECKPOINT_VERSION == 2
+  with pytest.raises(ValueError, match='newer'):
+    second.engine.set_state(dict(ck, version=99))
+  # a checkpoint of before ABI 4 (no version tag, no snapshot, no warm-start cache) is still accepted: the engine's own
+  # snapshot stays in force and the cache starts empty
+  old = {k: v for k, v in ck.items() if k not in ('snapshot', 'warm', 'version')}
+  keep = second.engine.snapshot.clone()
+  second.engine.warm.fill_(1.0)
+  second.engine.set_state(old)
+  assert torch.equal(second.engine.snapshot, keep) and not second.engine.warm.any() and torch.equal(second.engine.state, ck['state'])
   for env in (first, second):
     env._close()
 

@@ -81,3 +81,71 @@ def test_migration_physics_only_rollout_and_residual_threshold():
       assert torch.equal(ref.engine.cost, mig.engine.cost)
     assert mig.engine.stats.cpu().numpy()[6] == 0
     ref._close(); mig._close()
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_done_flag_of_a_migrating_launch_that_leaves_no_records(dtype):
+  """flags = PHYSICS | DONE without observations / rewards, not recording: no step records, no epilogue - the step kernel
+  writes the view's done flag itself, ONE byte per robot (done_stride = 0).  A robot's chunks run on waves of different
+  XCDs, whose L2s write plain stores back in any order: only the LAST step's flag may be written (round 4 wrote every
+  step's: ADVICE r4).  The flag, the counters and the states must equal the one-robot-per-wave launch's - with episode
+  ends falling into the first chunks, so that a stale "done" of an early step would show."""
+  import torch
+  tdt = torch.float32 if dtype == 'float32' else torch.float64
+  n, k = 4096, 20
+  flags = abi.STEP_PHYSICS | abi.STEP_DONE
+  ref = _env(n, dtype, k, 1, 0, 17)
+  mig = _env(n, dtype, k, 1, 4, 17)
+  g = torch.Generator(device='cuda').manual_seed(11)
+  phase = torch.randint(0, 17, (n,), device='cuda', generator=g, dtype=torch.int32)
+  for rep in range(3):
+    acts = (torch.rand(k, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.2831853
+    for e in (ref, mig):
+      if rep == 0:
+        e.engine.term_count[:, 0] = phase
+      e.engine.rollout(acts, flags)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.engine.done, mig.engine.done)
+    assert 0 < int(ref.engine.done.sum()) < n
+    assert torch.equal(ref.engine.state, mig.engine.state) and torch.equal(ref.engine.term_count, mig.engine.term_count)
+  assert mig.engine.stats.cpu().numpy()[6] == 0
+  ref._close(); mig._close()
+
+
+def test_the_engine_chooses_the_launch_geometry():
+  """SoloConfig's -1 defaults (round 5: the measured launch policy lives in the engine, not in bench.py): what
+  Engine.plan(k) reports for the benchmark's rollouts, that bench.py's default run uses exactly that, and that the
+  results are bit-identical to the plainest geometry (one chain of single launches, no migration)."""
+  import os, sys
+  import torch
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import bench
+  for dtype in ('float64', 'float32'):
+    tdt = torch.float32 if dtype == 'float32' else torch.float64
+    auto = bench.build_env(4096, 0, dtype, max_steps=17)              # the three knobs left at -1
+    assert (auto.engine.cfg.steps_per_launch, auto.engine.cfg.rollout_streams, auto.engine.cfg.migrate_steps) == (-1, -1, -1)
+    p20, p1000 = auto.engine.plan(20), auto.engine.plan(1000)
+    assert p20['waves_per_simd'] == 4 and p20['resident_robots'] == 4096
+    # the driver's run: ONE launch of 20 steps, every robot on a wave slot of its own - no slices, no migration
+    assert (p20['steps_per_launch'], p20['launches'], p20['slices'], p20['migrate_steps']) == (20, 1, 1, 0)
+    # the default run: launches of 250 steps on two slices
+    assert (p1000['steps_per_launch'], p1000['launches'], p1000['slices'], p1000['migrate_steps']) == (250, 4, 2, 0)
+    plain = _env(4096, dtype, 60, 1, 0, 17)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    acts = (torch.rand(60, 4096, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * 6.2831853
+    phase = torch.randint(0, 17, (4096,), device='cuda', generator=g, dtype=torch.int32)
+    for e in (auto, plain):
+      e.engine.term_count[:, 0] = phase
+    a = auto.engine.rollout(acts, abi.STEP_ALL, record=True)
+    b = plain.engine.rollout(acts, abi.STEP_ALL, record=True)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+      assert torch.equal(x, y)
+    assert torch.equal(auto.engine.state, plain.engine.state)
+    auto._close(); plain._close()
+  # more robots than wave slots: two chunks per launch (one launch), chunks of 25 on one chain (several launches)
+  big = bench.build_env(8192, 0, 'float64', max_steps=17)
+  p20, p1000 = big.engine.plan(20), big.engine.plan(1000)
+  assert (p20['steps_per_launch'], p20['slices'], p20['migrate_steps']) == (20, 1, 10)
+  assert (p1000['steps_per_launch'], p1000['launches']) == (250, 4)
+  big._close()

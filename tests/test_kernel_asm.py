@@ -59,3 +59,27 @@ def test_resource_budget_of_the_product_kernels():
     else:
       assert scratch[key]['scratch_in_step_loop'] <= 8, (key, scratch[key])
     assert scratch[key]['step_loop_instructions'] > 2000, (key, scratch[key])   # (the loop found IS the step loop)
+
+
+def test_hand_over_waits_for_its_stores_before_it_publishes():
+  """Robot migration: the record / counter stores of a task (device-coherent sc1 stores) must have been acknowledged
+  before the ring slot that hands the robot on is written - the order rests on an EXPLICIT s_waitcnt vmcnt(0)
+  (solo_wave_ops.h: wave_release_device; a workgroup-scope fence emits no instruction on gfx950).  In the generated
+  assembly of every migrating instantiation: the last global store of the kernel (the slot publication) has an
+  s_waitcnt vmcnt(0) between it and the sc1 store in front of it."""
+  import re
+  subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'gym_solo_amd', 'csrc'), 'asm'], stderr=subprocess.DEVNULL)
+  text = open(os.path.join(ROOT, 'gym_solo_amd', 'csrc', 'solo_engine.gfx950.s')).read()
+  checked = 0
+  for m in re.finditer(r'^(_ZN4solo16solo_step_kernelI\w+?Lb1EE)E\w*:.*?\n(.*?)^\.Lfunc_end', text, re.S | re.M):   # kMigrate = true
+    lines = [l.strip() for l in m.group(2).split('\n') if re.match(r'^\s+[a-z]', l)]
+    stores = [i for i, l in enumerate(lines) if l.startswith(('global_store', 'global_atomic')) and 'sc1' in l]
+    assert len(stores) >= 4, m.group(1)
+    # the publication: the LAST sc1 store of the kernel (program order: the task loop's end); in front of it, back to the
+    # previous sc1 store / atomic, there must be the wait
+    last = stores[-1]
+    prev = stores[-2]
+    between = lines[prev + 1:last]
+    assert any(l.startswith('s_waitcnt') and 'vmcnt(0)' in l for l in between), (m.group(1), between[-12:])
+    checked += 1
+  assert checked == 4   # {f, d} x {default solver, residual threshold}

@@ -4,9 +4,9 @@ libraries alternate, REPS rounds:
 
   gpurun -- python tools/ab_quick.py [--reps 3] [--dtype float64] [--legs k20,closed,s250] [--n 4096] libA.so libB.so ...
 
-(library names are files under gym_solo_amd/csrc; a name may carry settings: libX.so:migrate=0:streams=2:n=8192).
-Legs: k20 = the driver's geometry (ONE launch of N x 20 steps, the engine's launch policy unless migrate= is given),
-closed = one solo_engine_step launch per env step (20 steps), s250 = 1000 steps in fused launches of 250.
+(library names are files under gym_solo_amd/csrc; a name may carry settings: libX.so:migrate=0:streams=2:spl=250:n=8192;
+what is not given is the engine's choice).  Legs: k20 = the driver's geometry (a rollout of 20 steps), closed = one
+solo_engine_step launch per env step (20 steps), s250 = a rollout of 1000 steps (fused launches of 250).
 Prints env-steps/s by wall clock (median of the repeats, barrier + device sync on both sides as bench.py does) and the
 kernel's duration by HIP events."""
 import argparse
@@ -31,16 +31,9 @@ def child(spec):
   for leg in spec['legs']:
     closed = leg == 'closed'
     k = 1000 if leg == 's250' else 20
-    spl = 1 if closed else (250 if leg == 's250' else k)
-    kw = {}
-    if spec.get('migrate') is not None:
-      kw['migrate_steps'] = spec['migrate']
-    elif dtype == 'float64' and not closed:  # bench.py's table (round 4), until the engine chooses by itself
-      kw['migrate_steps'] = (spl + 1) // 2 if k == spl else 25
-    streams = spec.get('streams')
-    if streams is None:
-      streams = 2 if (k > spl and dtype == 'float32') else 1
-    env = bench.build_env(n, 0, dtype, steps_per_launch=spl, rollout_streams=streams, **kw)
+    # (migrate= / streams= / spl= override; else the engine chooses - SoloConfig's -1 defaults, Engine.plan(k))
+    env = bench.build_env(n, 0, dtype, steps_per_launch=1 if closed else spec.get('spl', -1), rollout_streams=1 if closed else spec.get('streams', -1),
+                          migrate_steps=0 if closed else spec.get('migrate', -1))
     eng = env.engine
     gen = torch.Generator(device='cuda').manual_seed(1234)
     bench.desynchronise_episodes(eng, gen)
@@ -64,8 +57,8 @@ def child(spec):
       times.append(time.perf_counter() - t0)
     rec = {'value': n * k / statistics.median(times), 'best': n * k / min(times)}
     if not closed:
-      r = max(1, min(k, 1000) // spl)
-      rec['kernel_ms'] = statistics.median(eng.time_step(pool(r * spl), abi.STEP_ALL) for _ in range(5))
+      rec['kernel_ms'] = statistics.median(eng.time_rollout(pool(k), abi.STEP_ALL) for _ in range(5))
+      rec['plan'] = eng.plan(k)
     out[leg] = rec
     env._close()
   print('AB_RESULT ' + json.dumps(out), flush=True)
@@ -100,7 +93,8 @@ def main():
         raise SystemExit(1)
       out = json.loads(line[0][len('AB_RESULT '):])
       rows.setdefault(name, []).append(out)
-      print('%-44s %s' % (name, '   '.join('%s %.4g%s' % (leg, r['value'], (' (kernel %.4f ms)' % r['kernel_ms']) if 'kernel_ms' in r else '') for leg, r in out.items())), flush=True)
+      print('%-44s %s' % (name, '   '.join('%s %.4g%s' % (leg, r['value'], (' (kernel %.4f ms; %d x %d steps, %d slice(s), migrate %d)' % (
+        r['kernel_ms'], r['plan']['launches'], r['plan']['steps_per_launch'], r['plan']['slices'], r['plan']['migrate_steps'])) if 'kernel_ms' in r else '') for leg, r in out.items())), flush=True)
   print('---- medians over %d rounds (%s, N = %d)' % (args.reps, args.dtype, args.n))
   for name, outs in rows.items():
     print('%-44s %s' % (name, '   '.join('%s %.4g' % (leg, statistics.median(o[leg]['value'] for o in outs)) for leg in outs[0])), flush=True)
