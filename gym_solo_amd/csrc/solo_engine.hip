@@ -287,8 +287,9 @@ struct Engine final : EngineBase {
 #ifndef SOLO_STAMPS   // (never in the diagnostic stamps builds, whose per-wave stamps assume one robot per wave)
     if (cfg.migrate_steps > 0) p.migrate = cfg.migrate_steps;
     else if (cfg.migrate_steps == -1 && !physics_only && (flags & SOLO_STEP_PHYSICS) && p.S >= 8) {
-      const int per_slice = streams > 1 && n >= 2 * streams ? n / streams : n;
-      if (per_slice > resident_cache) {
+      // (8192 robots, f64, profiles/round5_baseline_configs_f64.log: one launch of 20 steps 1.485e8 in two chunks against
+      // 1.474e8 without; 1000 steps 1.995e8 as one chain in chunks of 25 against 1.956e8 on two slices, 1.76e8 on one chain)
+      if (n > resident_cache) {
         if (p.launches == 1) p.migrate = (p.S + 1) / 2;
         else if (p.S >= 50) { p.migrate = 25; if (cfg.rollout_streams == -1) streams = 1; }
       }

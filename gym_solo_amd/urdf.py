@@ -9,9 +9,18 @@ out in the same format (used by the round-trip test).
 
 Supported: the Solo8 topology — one base link and four legs ``{FL,FR,HL,HR}_{HFE,KFE}`` revolute
 about +y plus a fixed ``*_ANKLE`` joint (welded into the lower leg); ``<inertial>`` with origin xyz/rpy;
-``<collision>`` is only read when it is a ``<sphere>`` (meshes cannot be used by the sphere/ground
-contact model; the built-in sphere set is used otherwise).
+``<collision>`` is only read when it is a ``<sphere>`` ON A FOOT LINK (meshes cannot be used by the
+sphere/ground contact model; the built-in sphere set is used otherwise).
+
+What the loader does NOT take from the file it SAYS (round 5): every ``<collision>`` that is not the one
+sphere of a foot link - meshes (``package://`` paths are never opened), boxes, cylinders, second and
+further collisions of a link, spheres on links whose sphere the model does not take from the file - is
+recorded in ``UrdfSolo8Model.ignored_collisions`` and ``parse_urdf`` emits ONE ``UrdfGeometryWarning``
+naming the links whose contact geometry is the built-in assumption of ``gym_solo_amd/model.py``; a
+``continuous`` joint (no limits in the file) gets the built-in +-10 rad and is listed in
+``assumed_limits``.
 """
+import warnings
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -37,8 +46,16 @@ def _rpy_matrix(rpy):
                    [-sp, cp * sr, cp * cr]])
 
 
+class UrdfGeometryWarning(UserWarning):
+  """The URDF's collision geometry (or part of it) was not used: the built-in sphere set stands in for it."""
+
+
 class UrdfSolo8Model:
-  """Solo8 constants parsed from a URDF; same accessor interface as ``model.Solo8Model``."""
+  """Solo8 constants parsed from a URDF; same accessor interface as ``model.Solo8Model``.
+
+  ``ignored_collisions``: {link name: [description of every <collision> the contact model did not take]};
+  ``sphere_sources``: for each of the 16 collision spheres, 'urdf' or 'built-in';
+  ``assumed_limits``: the revolute joints whose limits are the built-in +-10 rad (continuous, or no <limit lower upper>)."""
 
   def __init__(self, links, joints, fallback=None):
     self._links, self._joints = links, joints
@@ -65,6 +82,32 @@ class UrdfSolo8Model:
         raise ValueError(leg + '_KFE must hang off the upper leg')
       if joints[leg + '_ANKLE']['parent'] != joints[leg + '_KFE']['child']:
         raise ValueError(leg + '_ANKLE must hang off the lower leg')
+    # ---- what of the file's geometry is NOT used (the module's head says why)
+    foot_links = {joints[leg + '_ANKLE']['child'] for leg in LEGS}
+    self.ignored_collisions = {}
+    for name, link in links.items():
+      ignored = list(link.get('ignored', []))
+      if link.get('sphere') is not None and name not in foot_links:
+        ignored.insert(0, 'sphere (only a FOOT link\'s sphere is taken from the file)')
+      if ignored:
+        self.ignored_collisions[name] = ignored
+    self.sphere_sources = ['built-in'] * abi.MAX_SPHERES
+    for leg in range(abi.NUM_LEGS):
+      if links[joints[LEGS[leg] + '_ANKLE']['child']].get('sphere') is not None:
+        self.sphere_sources[4 * leg + 1] = 'urdf'
+    self.assumed_limits = [jn for leg in LEGS for jn in (leg + '_HFE', leg + '_KFE')
+                           if joints[jn]['type'] != 'revolute' or joints[jn].get('limit') is None]
+
+  def geometry_report(self):
+    """One paragraph: which links' collision geometry was ignored, and what stands in for it (None: nothing was)."""
+    if not self.ignored_collisions:
+      return None
+    parts = ['{} ({})'.format(name, '; '.join(what)) for name, what in sorted(self.ignored_collisions.items())]
+    n_file = sum(1 for s_ in self.sphere_sources if s_ == 'urdf')
+    return ('URDF collision geometry NOT used by the sphere / ground contact model: ' + ', '.join(parts) +
+            '.  Contact uses {} sphere(s) from the file and {} built-in sphere(s) of gym_solo_amd/model.py '
+            '(an assumption, two of its parameters calibrated: DESIGN.md section 6) - mesh files are never opened.'.format(
+              n_file, abi.MAX_SPHERES - n_file))
 
   def _inertial(self, link_name):
     return self._links[link_name]['inertial']
@@ -146,13 +189,20 @@ def parse_urdf(text, fallback=None) -> UrdfSolo8Model:
       I = _sym(*(float(i.get(k, 0.0)) for k in ('ixx', 'iyy', 'izz', 'ixy', 'ixz', 'iyz')))
       Rm = _rpy_matrix(rpy)
       inertial = LinkInertial(float(ine.find('mass').get('value')), xyz, Rm @ I @ Rm.T)
-    sphere = None
-    col = el.find('collision')
-    if col is not None and col.find('geometry') is not None and col.find('geometry').find('sphere') is not None:
-      corg = col.find('origin')
-      sphere = (_floats(corg.get('xyz') if corg is not None else None, 3, (0, 0, 0)),
-                float(col.find('geometry').find('sphere').get('radius')))
-    links[el.get('name')] = {'inertial': inertial, 'sphere': sphere}
+    sphere, ignored = None, []
+    for col in el.findall('collision'):
+      geo = col.find('geometry')
+      kind = geo[0].tag if geo is not None and len(geo) else 'empty'
+      if kind == 'sphere' and sphere is None:
+        corg = col.find('origin')
+        sphere = (_floats(corg.get('xyz') if corg is not None else None, 3, (0, 0, 0)), float(geo[0].get('radius')))
+      elif kind == 'mesh':
+        ignored.append('mesh {}'.format(geo[0].get('filename', '?')))
+      elif kind == 'sphere':
+        ignored.append('a second sphere (one per link is read)')
+      else:
+        ignored.append(kind)
+    links[el.get('name')] = {'inertial': inertial, 'sphere': sphere, 'ignored': ignored}
   for el in root.findall('joint'):
     org = el.find('origin')
     ax = el.find('axis')
@@ -163,7 +213,11 @@ def parse_urdf(text, fallback=None) -> UrdfSolo8Model:
       'axis': _floats(ax.get('xyz') if ax is not None else None, 3, (1, 0, 0)),
       'limit': (None if el.find('limit') is None or el.find('limit').get('lower') is None else
                 (float(el.find('limit').get('lower')), float(el.find('limit').get('upper'))))}
-  return UrdfSolo8Model(links, joints, fallback)
+  model = UrdfSolo8Model(links, joints, fallback)
+  report = model.geometry_report()
+  if report is not None:
+    warnings.warn(report, UrdfGeometryWarning, stacklevel=2)
+  return model
 
 
 def load_urdf(path, fallback=None) -> UrdfSolo8Model:

@@ -147,5 +147,5 @@ def test_the_engine_chooses_the_launch_geometry():
   big = bench.build_env(8192, 0, 'float64', max_steps=17)
   p20, p1000 = big.engine.plan(20), big.engine.plan(1000)
   assert (p20['steps_per_launch'], p20['slices'], p20['migrate_steps']) == (20, 1, 10)
-  assert (p1000['steps_per_launch'], p1000['launches']) == (250, 4)
+  assert (p1000['steps_per_launch'], p1000['launches'], p1000['slices'], p1000['migrate_steps']) == (250, 4, 1, 25)
   big._close()
