@@ -142,6 +142,9 @@ template <typename T> constexpr int kPrioSweeps = sizeof(T) == 4 ? 8 : SOLO_PRIO
 #define SOLO_F64_WAVES 4   // (round 5: FOUR waves per SIMD - 128 VGPRs, 10240 B of LDS; -DSOLO_F64_WAVES=3 / 2: the A/B builds, make w3 / w2)
 #endif
 template <typename T> constexpr int kRowBlockReals = sizeof(T) == 4 ? 64 * 8 + 64 * 8 : (SOLO_F64_WAVES >= 4 ? 800 : 896);
+#ifndef SOLO_W4_PIPELINED_BUILD
+#define SOLO_W4_PIPELINED_BUILD 0
+#endif
 constexpr int kLegSlots = 26;  // per-leg parking lot in LDS (see physics_solve): 0-11 K, 12-14 Lp factors, 15-16 unconstrained joint rates, 17-18 q, 19-22 cos / sin of the two link angles, 23-24 P^-1 h
 
 // one lane's constraint-row constants, as the step reads them from LDS (staged from KParams::row once per launch)
@@ -806,7 +809,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     // (software-pipelined by one slot: the row of slot r + 1 is fetched - eight LDS broadcasts - in front of the arithmetic
     // of slot r, across the tests too: a wave alone on its SIMD, the slow robot at the end of a launch, otherwise sits
     // out an LDS round trip at the head of every triple)
-    if constexpr (SOLO_F64_WAVES >= 4) {
+    if constexpr (SOLO_F64_WAVES >= 4 && !SOLO_W4_PIPELINED_BUILD) {
       // (four waves per SIMD - the A/B build: 128 VGPRs have no room for a second row in flight)
       A.build(0); A.build(1);
 #pragma unroll

@@ -1,7 +1,7 @@
 """MEASUREMENT: cost-balanced launch order (Engine.balance: costliest robots first) vs the identity,
 for batches at and above the chip's 4096 resident waves.  usage: gpu_balance.py [N ...]"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from gym_solo_amd import abi

@@ -3,7 +3,7 @@ DRIVER's geometry - one K = 20 launch - where the batch exceeds the resident wav
 (two waves per SIMD: 2048 slots, every slot runs two robots one after the other) and f32 at N = 8192.
 usage: gpu_balance_k20.py"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from gym_solo_amd import abi

@@ -2,7 +2,7 @@
 costliest robots first, by the sweeps of their last step; the argsort and the order upload are INSIDE the timed region).
   python tools/gpu_closed_loop_balance.py float64 0 8 32 128"""
 import sys, os, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench

@@ -1,7 +1,7 @@
 """MEASUREMENT: host time per closed-loop step (python -> ctypes -> one kernel launch) against the
 device time per step, N = 4096, f32, one solo_engine_step launch per env step."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from gym_solo_amd import abi

@@ -3,7 +3,7 @@ own wave: solo_step_kernel.h) costs at the driver's geometry - the same K-step l
 by one.  Kernel time by HIP events, steady state of the benchmark workload, median of 9.
   MIGRATE=10 python tools/gpu_epilogue_cost.py float64 20 4096"""
 import sys, os, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench

@@ -2,7 +2,7 @@
 stream (queue init + step kernel), with and without recording every step's outputs, against the wall clock of
 rollout + device synchronisation."""
 import sys, os, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench

@@ -4,7 +4,7 @@ Host-side orders (set_order before every launch, outside the timed region) as th
 identity | full sort by the previous launch's sweeps | two classes (sweeps per step above a threshold first).
 usage: gpu_lpt_probe.py [float64] [K]"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from gym_solo_amd import abi

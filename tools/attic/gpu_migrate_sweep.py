@@ -2,7 +2,7 @@
 of K steps with S steps per launch on G stream slices, over a list of chunk lengths (0 = off).
   python tools/gpu_migrate_sweep.py float64 K S G  m1 m2 ..."""
 import sys, os, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench

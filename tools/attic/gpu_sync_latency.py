@@ -3,7 +3,7 @@ synchronisation against the launch chain's HIP events, for three ways of waiting
 query spin (hipStreamQuery through torch's stream.query()) in front of it, and an event-query spin.
   python tools/gpu_sync_latency.py            (ROC_ACTIVE_WAIT_TIMEOUT=us in the environment changes the runtime's own wait)"""
 import sys, os, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench

@@ -2,7 +2,7 @@
 impulse changes of <= k half-ulps, relative, count as converged; 0 = exact), f32 bench workload.
 Diagnostic: the default (2) is the f32 rounding level; this shows what looser settings would buy."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from gym_solo_amd import abi

@@ -3,7 +3,7 @@
 #   gpurun --timeout 1150 -- bash tools/refresh_profiles.sh round3_a f32 f32_k20
 #   gpurun --timeout 1150 -- bash tools/refresh_profiles.sh round3_a f64 f64_k20
 # One CONFIG = a dtype and a launch geometry of the bench workload:
-#   f32 / f64          python bench.py --dtype ...: K = 3000 steps, 250 per launch, two stream slices
+#   f32 / f64          python bench.py --dtype ...: K = 3000 steps, the engine's geometry (250 per launch, two stream slices)
 #   f32_k20 / f64_k20  the driver's command, python bench.py --gpus 1 --steps 20 --warmup 5 (f64 is its default precision): ONE 4096 x 20 launch
 # Per config: the bench line, a rocprofv3 --kernel-trace --stats summary of the SAME command (the step kernel's
 # average duration must agree with the line's roofline.kernel_ms) and the PMC passes (separate runs of
@@ -19,10 +19,11 @@ mkdir -p $O
 cd $R
 for CFG in $CONFIGS; do
   case $CFG in
-    f32)     DT=float32; BARGS="--dtype float32";                                  PENV="SPL=250 STREAMS=2 STEPS=2000 REPEATS=1";;
-    f32_k20) DT=float32; BARGS="--dtype float32 --gpus 1 --steps 20 --warmup 5";    PENV="SPL=20 STREAMS=1 STEPS=20 REPEATS=40";;
-    f64)     DT=float64; BARGS="--dtype float64";                   PENV="SPL=250 STREAMS=1 STEPS=2000 REPEATS=1";;   # (8 launches: pmc_summary averages the last 6; bench.py's choice for f64: one chain, migration chunks of 25)
-    f64_k20) DT=float64; BARGS="--dtype float64 --gpus 1 --steps 20 --warmup 5"; PENV="SPL=20 STREAMS=1 STEPS=20 REPEATS=40";;
+    # (the launch geometry is the ENGINE'S in bench.py and in tools/prof_driver.py alike: round 5)
+    f32)     DT=float32; BARGS="--dtype float32";                                  PENV="STEPS=2000 REPEATS=1";;
+    f32_k20) DT=float32; BARGS="--dtype float32 --gpus 1 --steps 20 --warmup 5";    PENV="STEPS=20 REPEATS=40";;
+    f64)     DT=float64; BARGS="--dtype float64";                                  PENV="STEPS=2000 REPEATS=1";;   # (8 launches of 250 steps on two slices: pmc_summary averages the last 6)
+    f64_k20) DT=float64; BARGS="--dtype float64 --gpus 1 --steps 20 --warmup 5";    PENV="STEPS=20 REPEATS=40";;
     *) echo "unknown config $CFG"; exit 2;;
   esac
   cd $R
