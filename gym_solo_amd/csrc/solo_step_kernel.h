@@ -132,6 +132,15 @@ namespace solo {
 #ifndef SOLO_PRIO_SWEEPS_F64
 #define SOLO_PRIO_SWEEPS_F64 12
 #endif
+#ifndef SOLO_PRIO_BY_ROWS
+#define SOLO_PRIO_BY_ROWS 1   // (f64 - the slot-space solver knows its row count; 0: the A/B build)
+#endif
+#ifndef SOLO_PRIO_ROWS_1
+#define SOLO_PRIO_ROWS_1 11
+#define SOLO_PRIO_ROWS_2 17
+#define SOLO_PRIO_ROWS_3 23
+#endif
+__device__ __forceinline__ int priority_by_rows(int rows) { return rows > SOLO_PRIO_ROWS_3 ? 3 : (rows > SOLO_PRIO_ROWS_2 ? 2 : (rows > SOLO_PRIO_ROWS_1 ? 1 : 0)); }
 template <typename T> constexpr int kPrioSweeps = sizeof(T) == 4 ? 8 : SOLO_PRIO_SWEEPS_F64;
 // The block of LDS that holds a step's constraint rows - f32: [64 rows][ghat 6, hhat 2] and the joint-space parts again by
 // leg slot [64][4 legs x 2]; f64 (slot space): [64 slots][ghat 6, hhat 2], the legs are tags of their own - and is the
@@ -772,6 +781,18 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // (s_set_gpr_idx_on + v_mov) instead of an LDS round trip and a dot product on its serial chain.
   // (f64: the columns of the first ColumnBank<double>::kSlots = 32 SLOTS, 64 VGPRs; a step with more live rows
   // builds none and takes the overflow path below.)
+#if SOLO_PRIO_BY_ROWS
+  // Issue priority BY LIVE ROWS (round 5): the number of live rows is the best predictor of a robot-step's solver cost that
+  // exists before the solve (mean sweeps 5 with one touching sphere, 20 with eight; the cost of the robot's previous steps
+  // predicts next to nothing - rank correlation 0.2, profiles/round5_cost_persistence.log) - and what follows, the column
+  // build (proportional to the rows) and the Gauss-Seidel iteration, is where robot-steps differ: the more rows, the higher
+  // the wave's priority from here to the end of the solve (which sets the rotation / the slow robot's level again).
+  // K = 20 +4 %, one launch per step and 250-step launches unchanged (profiles/round5_prio_by_rows_ab.log); thresholds
+  // 8 / 14 / 20 and 14 / 20 / 26 measured the same and 3 % less.
+  if constexpr (kCompact) {
+    wave_set_priority_level(prio_sweeps > kPrioSweeps<T> * prio_steps ? 3 : priority_by_rows(n_live));
+  }
+#endif
   ColumnBank<T> A;
   if constexpr (kCompact) A.init(sg, sh, sv_nid, lane, s_rowvec, s_rowleg, sv_leg);
   else A.init(sg, sh, sv_nid, lane, s_rowvec, &s_hext[0][2 * sv_leg]);  // (+ 8 r: row r's joint-space part if r is on this lane's leg, else 0)
@@ -941,8 +962,10 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     // sweeps | touching spheres << 16 | XCC id << 24 | HW_ID[19:0] (wave, simd, pipe, cu, sh, se, tg) << 28 | row updates << 48
     const unsigned long long hw = (unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xfffff), xcc = (unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf);
     B.stamps[(size_t)B.stamp_row * 32 + 15] = (unsigned long long)(it & 0xffff) | ((unsigned long long)__builtin_popcountll(touching) << 16) | (xcc << 24) | (hw << 28) | ((unsigned long long)(n_changed & 0xffff) << 48);
+#ifndef SOLO_STAMPS_LIGHT
     B.acc[15] += (unsigned long long)it;
     B.acc[0] += (unsigned long long)n_changed;
+#endif
   }
 #endif
   (void)n_changed;
@@ -1129,10 +1152,12 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   }
 #ifdef SOLO_STAMPS
   B.stamp_row = env;
+#ifndef SOLO_STAMPS_LIGHT   // (the light build keeps the product's LDS footprint - 10240 B in f64: sixteen workgroups per CU - and its residency)
   __shared__ unsigned long long s_acc[17];
   if (lane0 < 17) s_acc[lane0] = lane0 == 16 ? __builtin_amdgcn_s_memtime() : 0ull;
   B.acc = s_acc;
   wave_sync();
+#endif
 #endif
   SOLO_STAMP(B, 0);
   // episodic statistics are sharded over SOLO_STATS_SHARDS rows: all robots of a batch finish
@@ -1569,7 +1594,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     else wave_cold_args(Bin)->state[rec + lane1] = s_state[lane1];
   }
   SOLO_STAMP(B, 14);
-#ifdef SOLO_STAMPS
+#if defined(SOLO_STAMPS) && !defined(SOLO_STAMPS_LIGHT)
   wave_sync();
   if (lane1 < 16) B.stamps[(size_t)env * 32 + 16 + lane1] = s_acc[lane1];
 #endif

@@ -13,7 +13,7 @@ from gym_solo_amd import abi
 dtype = sys.argv[1] if len(sys.argv) > 1 else 'float64'
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 tdt = torch.float32 if dtype == 'float32' else torch.float64
-slots = 1024 * (4 if dtype == 'float32' else 3)
+slots = 1024 * 4   # (four waves per SIMD in both precisions since round 5; the light stamps build keeps the product's residency)
 for n in [int(x) for x in sys.argv[3:]] or [4096]:
   env = bench.build_env(n, 0, dtype, steps_per_launch=k, rollout_streams=1, migrate_steps=0)
   eng = env.engine
