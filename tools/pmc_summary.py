@@ -5,7 +5,7 @@ usage: pmc_summary.py out.json pmc_dir [pmc_dir ...]
 Families: step = solo_step_kernel<T, true>, outputs = solo_outputs_kernel, returns =
 solo_returns_kernel.  Per family only the dispatches with the largest grid are kept (the fused
 full-length launches of the timed rollout; the settle loop and the short tail launch have
-other names / sizes) and the last 6 of them are averaged."""
+other names / sizes): per family the dispatches with the grid of the LAST dispatch are kept and the last 6 of them averaged."""
 import collections, csv, glob, json, os, sys
 
 
@@ -30,7 +30,9 @@ for d in sys.argv[2:]:
         rows[(fam, r['Counter_Name'])].append((int(r['Grid_Size']), float(r['Counter_Value']),
                                                 int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
     for (fam, counter), v in rows.items():
-      gmax = max(g for g, _, _ in v)
+      # (the measured launches are the LAST ones of the run - the steady-state preparation in front of them may use
+      # another geometry, since round 5 even a larger grid: one slice of 100-step launches)
+      gmax = v[-1][0]
       full = [(x, t) for g, x, t in v if g == gmax][-6:]
       out[fam][counter] = sum(x for x, _ in full) / len(full)
       out[fam].setdefault('_dispatches_averaged', len(full))
