@@ -80,7 +80,7 @@ def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=-1,
   return env
 
 
-def desynchronise_episodes(eng, generator, max_steps=MAX_STEPS, advance=True):
+def desynchronise_episodes(eng, generator, max_steps=MAX_STEPS, advance=True, chunk=None):
   """Brings the batch into the STEADY STATE of the workload before anything is timed.  All robots are created
   in the same post-reset pose with their 1000-step episodes in phase: a 20-step window right after that would
   never see a termination, an auto-reset or a real number in the statistics all-reduce, and would time 4096
@@ -103,7 +103,9 @@ def desynchronise_episodes(eng, generator, max_steps=MAX_STEPS, advance=True):
   eng.state[:, abi.S_EPLEN] = phase.to(eng.tdtype)
   if not advance:
     return
-  chunk = min(100, max_steps)
+  # (chunk: steps per untimed rollout - bench.py passes the length whose launches have the geometry of the timed region, so
+  # that a profile of the run holds ONE kind of step-kernel launch and its --stats average compares with roofline.kernel_ms)
+  chunk = min(chunk or 100, max_steps)
   for _ in range(0, max_steps, chunk):
     a = (torch.rand(chunk, n, abi.NUM_JOINTS, device=dev, dtype=eng.tdtype, generator=generator) * 2 - 1) * (2 * 3.141592653589793)
     eng.rollout(a, abi.STEP_ALL)
@@ -431,7 +433,8 @@ def main():
         eng.rollout(acts, abi.STEP_ALL, out=out)
 
     if steady:
-      desynchronise_episodes(eng, gen)
+      p0 = {'launches': 1} if closed_loop else eng.plan(k)
+      desynchronise_episodes(eng, gen, chunk=(1 if closed_loop else k) if p0['launches'] == 1 else 2 * p0['steps_per_launch'])
     out = None if closed_loop else eng.rollout_buffers(k)  # every step's obs / reward / done goes to HBM
     if w > 0:
       run(action_pool(w), None if closed_loop else eng.rollout_buffers(w))

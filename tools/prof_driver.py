@@ -16,7 +16,7 @@ eng = env.engine
 plan = eng.plan(steps)
 tdt = torch.float32 if dtype == 'float32' else torch.float64
 g = torch.Generator(device='cuda').manual_seed(1234)
-desynchronise_episodes(eng, g)  # as bench.py does: terminations / auto-resets inside every window
+desynchronise_episodes(eng, g, chunk=steps if plan['launches'] == 1 else 2 * plan['steps_per_launch'])  # as bench.py does: terminations / auto-resets inside every window; launches of the measured geometry
 acts = (torch.rand(steps, n, 12, device='cuda', dtype=tdt, generator=g) * 2 - 1) * (2 * np.pi)
 out = eng.rollout_buffers(acts.shape[0])
 for _ in range(int(os.environ.get('REPEATS', '1'))):   # (short geometries: several launches to average over)
