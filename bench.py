@@ -45,8 +45,8 @@ VALU_CYCLES_SHARED = 2                                  # wave64 VALU instructio
 VALU_CYCLES_ALONE = 4                                   # the SIMD; 4 for one wave alone (MI355X_MICROARCH.md constants)
 # f64 arithmetic issues at half the f32 rate (MI355X: 78.6 vs 157.3 vector TFLOP/s -> 4 cycles per wave64 instruction); 61 %
 # of the f64 step kernel's VALU instructions are f64 arithmetic (static count of the product assembly, tools/isa_line_profile.py d:
-# 1560 of 2562), the rest - moves, DPP, selects, integer, compares on 32-bit halves - 32-bit operations
-F64_ARITH_SHARE = 0.61
+# 1845 of 3162 in round 5's 128-VGPR kernel), the rest - moves, DPP, selects, integer, compares on 32-bit halves - 32-bit operations
+F64_ARITH_SHARE = 0.58
 SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICROARCH.md chip table
 METRIC = 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X'
 # REHEARSAL knobs (never set by the driver; tests/test_bench_launcher.py): SOLO_BENCH_ENGINE=emu runs the whole script -
@@ -257,7 +257,7 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd, 
   simd_cycles = NUM_SIMDS * kern_ms * 1e-3 * clock
   util = chains * valu * env_steps_per_launch * cyc / simd_cycles
   return ('latency bound, not HBM bound: %.0f VALU instructions per env-step (rocprofv3 --pmc SQ_INSTS_VALU, '
-          'profiles/pmc_traffic.json) x %.1f cycles (wave64 on a SIMD-32 shared by %.0f waves, MI355X_MICROARCH.md; f64 arithmetic - 61 %% of the f64 kernel\'s VALU instructions - at half rate) x %d '
+          'profiles/pmc_traffic.json) x %.1f cycles (wave64 on a SIMD-32 shared by %.0f waves, MI355X_MICROARCH.md; f64 arithmetic - 58 %% of the f64 kernel\'s VALU instructions - at half rate) x %d '
           'env-steps x %d concurrent launch chains = %.2f of the %d SIMDs\' VALU issue capacity over the measured launch '
           'duration at %.1f GHz; what binds is the issue rate of ONE wave per robot - 4.1 cycles per independent instruction, '
           '6.2 per instruction of the solver\'s serial row-update chain (tools/microbench/simd_rate.hip), %s instructions per '
