@@ -483,7 +483,8 @@ def main():
     algorithmic bytes per env-step from SURVEY.md 8d."""
     spl, slices = plan['steps_per_launch'], plan['slices']
     kk = min(k, 1000) // spl * spl or k   # (whole launches)
-    kern_ms = statistics.median(eng.time_rollout(action_pool(kk), abi.STEP_ALL) for _ in range(5 if k <= 100 else 3))
+    bufs = eng.rollout_buffers(kk)   # (every step's outputs recorded: the timed region's own call)
+    kern_ms = statistics.median(eng.time_rollout(action_pool(kk), abi.STEP_ALL, out=bufs) for _ in range(5 if k <= 100 else 3))
     env_steps_per_launch = (n // slices) * spl
     bytes_per_launch = BYTES_PER_ENV_STEP[dtype] * env_steps_per_launch
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9

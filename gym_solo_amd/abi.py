@@ -219,7 +219,8 @@ ENTRY_POINTS = {
   'solo_engine_time_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32,
                                       C.c_void_p, C.POINTER(C.c_double)]),
   'solo_engine_plan': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SoloLaunchPlan)]),
-  'solo_engine_time_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]),
+  'solo_engine_time_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_double)]),
   'solo_engine_last_error': (C.c_char_p, [C.c_void_p]),
   'solo_last_create_error': (C.c_char_p, []),
   'solo_abi_version': (C.c_int, []),

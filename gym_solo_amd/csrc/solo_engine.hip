@@ -36,7 +36,7 @@ struct EngineBase {
   virtual int set_terrain(const SoloTerrain* t, hipStream_t s) = 0;
   virtual int set_order(const int32_t* order, hipStream_t s) = 0;
   virtual int time_step(const void* a, uint32_t flags, int reps, hipStream_t s, double* ms) = 0;
-  virtual int time_rollout(const void* a, int k, uint32_t flags, hipStream_t s, double* ms) = 0;
+  virtual int time_rollout(const void* a, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out, hipStream_t s, double* ms) = 0;
   virtual int plan(int k, SoloLaunchPlan* out) = 0;
   virtual const char* kernel_name() = 0;
   std::string err;
@@ -517,7 +517,7 @@ struct Engine final : EngineBase {
     return SOLO_OK;
   }
 
-  int time_rollout(const void* a, int k, uint32_t flags, hipStream_t s, double* ms) override {
+  int time_rollout(const void* a, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out, hipStream_t s, double* ms) override {
     if (int rc = check_flags(flags)) return rc;
     if (k <= 0 || !ms) { err = "num_steps must be positive"; return SOLO_ERR_INVALID_ARG; }
     HIP_TRY(hipSetDevice(device));
@@ -528,7 +528,7 @@ struct Engine final : EngineBase {
     for (hipEvent_t& x : ev.e) HIP_TRY(hipEventCreate(&x));
     int groups = 1;
     const Plan plan = make_plan(k, flags);
-    if (int rc = rollout_impl(plan, (const T*)a, k, flags, nullptr, nullptr, nullptr, s, ev.e, ev.e + kMaxStreams, &groups)) return rc;
+    if (int rc = rollout_impl(plan, (const T*)a, k, flags, obs_out, reward_out, done_out, s, ev.e, ev.e + kMaxStreams, &groups)) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     double total = 0;
     for (int g = 0; g < groups; ++g) {
@@ -753,8 +753,9 @@ const char* solo_engine_kernel_name(SoloEngine* eng) { return eng && eng->impl ?
 int solo_engine_time_step(SoloEngine* eng, const void* a, uint32_t flags, int32_t reps, void* stream, double* ms) {
   return ENG_CALL(time_step(a, flags, reps, (hipStream_t)stream, ms));
 }
-int solo_engine_time_rollout(SoloEngine* eng, const void* a, int32_t k, uint32_t flags, void* stream, double* ms) {
-  return ENG_CALL(time_rollout(a, k, flags, (hipStream_t)stream, ms));
+int solo_engine_time_rollout(SoloEngine* eng, const void* a, int32_t k, uint32_t flags, void* obs_out, void* reward_out, void* done_out,
+                             void* stream, double* ms) {
+  return ENG_CALL(time_rollout(a, k, flags, obs_out, reward_out, done_out, (hipStream_t)stream, ms));
 }
 int solo_engine_plan(SoloEngine* eng, int32_t k, SoloLaunchPlan* out) { return ENG_CALL(plan(k, out)); }
 const char* solo_engine_last_error(SoloEngine* eng) { return eng && eng->impl ? eng->impl->err.c_str() : "invalid engine handle"; }

@@ -195,14 +195,22 @@ class Engine:
     self._check(self.lib.solo_engine_plan(self._handle(), int(num_steps), C.byref(p)), 'plan')
     return {name: int(getattr(p, name)) for name, _ in abi.SoloLaunchPlan._fields_}
 
-  def time_rollout(self, actions, flags=abi.STEP_ALL):
+  def time_rollout(self, actions, flags=abi.STEP_ALL, out=None):
     """Mean ms per LAUNCH of one rollout of actions.shape[0] steps run exactly as rollout() runs it (plan()'s
-    geometry), measured with HIP events on the launch streams."""
+    geometry; out = rollout_buffers(K): every step's outputs recorded, as a rollout collector's call does), measured with
+    HIP events on the launch streams."""
     actions = self._as_real(actions)
     k = int(actions.shape[0])
     p = self._dev_ptr(actions, (k, self.num_envs, abi.NUM_JOINTS), self.tdtype, 'actions')
+    outs = [None, None, None]
+    if out is not None:
+      obs, rew, done = out
+      self._dev_ptr(obs, (k, self.num_envs, max(self.obs_dim, 1)), self.tdtype, 'obs_out')
+      self._dev_ptr(rew, (k, self.num_envs), self.tdtype, 'reward_out')
+      self._dev_ptr(done, (k, self.num_envs), self._torch.uint8, 'done_out')
+      outs = [C.c_void_p(t.data_ptr()) for t in out]
     ms = C.c_double()
-    self._check(self.lib.solo_engine_time_rollout(self._handle(), p, k, flags, self._stream(), C.byref(ms)), 'time_rollout')
+    self._check(self.lib.solo_engine_time_rollout(self._handle(), p, k, flags, outs[0], outs[1], outs[2], self._stream(), C.byref(ms)), 'time_rollout')
     return ms.value
 
   def rollout_buffers(self, k):

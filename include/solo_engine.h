@@ -369,11 +369,11 @@ typedef struct SoloLaunchPlan {
   int32_t resident_robots;   /* robots with a wave slot of their own on this device: waves_per_simd x SIMDs */
 } SoloLaunchPlan;
 int solo_engine_plan(SoloEngine* eng, int32_t num_steps, SoloLaunchPlan* out);
-/* Times ONE rollout of num_steps steps exactly as solo_engine_rollout runs it (solo_engine_plan's geometry) with hipEvents
- * recorded on the streams the kernels are launched on; returns the mean milliseconds per LAUNCH over all slices and
- * launches.  actions_dev: real [num_steps][N][12]. */
+/* Times ONE rollout of num_steps steps exactly as solo_engine_rollout_record runs it (solo_engine_plan's geometry; the
+ * output buffers as there: NULL = that output is not recorded) with hipEvents recorded on the streams the kernels are
+ * launched on; returns the mean milliseconds per LAUNCH over all slices and launches.  actions_dev: real [num_steps][N][12]. */
 int solo_engine_time_rollout(SoloEngine* eng, const void* actions_dev, int32_t num_steps, uint32_t flags,
-                             void* stream, double* ms_per_launch);
+                             void* obs_out, void* reward_out, void* done_out, void* stream, double* ms_per_launch);
 const char* solo_engine_last_error(SoloEngine* eng);
 /* library-level: last error of a failed create (eng == NULL) */
 const char* solo_last_create_error(void);

@@ -189,10 +189,10 @@ class EmuTorchEngine:
     return {'steps_per_launch': spl, 'launches': -(-int(num_steps) // spl), 'slices': 1, 'migrate_steps': max(0, int(self.cfg.migrate_steps)),
             'waves_per_simd': 0, 'resident_robots': 0}
 
-  def time_rollout(self, actions, flags=abi.STEP_ALL):
+  def time_rollout(self, actions, flags=abi.STEP_ALL, out=None):
     import time
     t0 = time.perf_counter()
-    self.rollout(actions, flags)
+    self.rollout(actions, flags, out=out)
     return (time.perf_counter() - t0) * 1e3 / self.plan(actions.shape[0])['launches']
 
   def rollout_buffers(self, k):

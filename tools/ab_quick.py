@@ -57,7 +57,7 @@ def child(spec):
       times.append(time.perf_counter() - t0)
     rec = {'value': n * k / statistics.median(times), 'best': n * k / min(times)}
     if not closed:
-      rec['kernel_ms'] = statistics.median(eng.time_rollout(pool(k), abi.STEP_ALL) for _ in range(5))
+      rec['kernel_ms'] = statistics.median(eng.time_rollout(pool(k), abi.STEP_ALL, out=bufs) for _ in range(5))
       rec['plan'] = eng.plan(k)
     out[leg] = rec
     env._close()
