@@ -484,7 +484,7 @@ def main():
     spl, slices = plan['steps_per_launch'], plan['slices']
     kk = min(k, 1000) // spl * spl or k   # (whole launches)
     bufs = eng.rollout_buffers(kk)   # (every step's outputs recorded: the timed region's own call)
-    kern_ms = statistics.median(eng.time_rollout(action_pool(kk), abi.STEP_ALL, out=bufs) for _ in range(5 if k <= 100 else 3))
+    kern_ms = statistics.median(eng.time_rollout(action_pool(kk), abi.STEP_ALL, out=bufs) for _ in range(15 if k <= 100 else 3))   # (a 20-step launch lasts as long as its slowest robot: 0.59 ... 0.98 ms from sample to sample - fifteen of them)
     env_steps_per_launch = (n // slices) * spl
     bytes_per_launch = BYTES_PER_ENV_STEP[dtype] * env_steps_per_launch
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
