@@ -20,8 +20,8 @@ episodic-return statistics vector at the end of the interval (inside the timed r
 
 Timing: after W warm-up steps, EXACTLY K steps are timed between barrier + device synchronisation
 on both sides, max over ranks.  A K-step region can be as short as half a millisecond (the driver
-uses K = 20), so it is repeated (fresh actions, the simulation simply continues) until 0.5 s or 30
-repeats have accumulated; `value` / `ms_per_step` are the MEDIAN repeat, min / max / count are
+uses K = 20), so it is repeated (fresh actions, the simulation simply continues) until 0.5 s (or 1000
+repeats) have accumulated; `value` / `ms_per_step` are the MEDIAN repeat, min / max / count are
 reported next to it.  Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline`; the same run
 also measures the reference-precision figure (`value_f64`) and the reference-granularity figure
 (`value_closed_loop`: one solo_engine_step launch per env step, as Solo8VanillaEnv.step issues it).
@@ -342,7 +342,7 @@ def main():
                   help='SoloConfig.migrate_steps of the rollouts: robots change waves every this many steps of a launch '
                        '(0 = off; -1, the default = the engine chooses: only when a launch has more robots than the chip has wave slots)')
   ap.add_argument('--min-seconds', type=float, default=0.5, help='repeat the K-step timed region until this much time ...')
-  ap.add_argument('--max-repeats', type=int, default=30, help='... or this many repeats have accumulated')
+  ap.add_argument('--max-repeats', type=int, default=1000, help='... or this many repeats have accumulated (round 4: 30 - twenty milliseconds of GPU work at K = 20)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))

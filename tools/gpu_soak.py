@@ -20,8 +20,8 @@ N = 4096
 CHUNKS = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 res = {}
 for dtype in ('float32', 'float64'):
-  # (the geometries bench.py uses: f32 on two stream slices, f64 as one chain of launches with robot migration in chunks of 25)
-  env = build_env(N, 0, dtype, steps_per_launch=250, rollout_streams=2 if dtype == 'float32' else 1, migrate_steps=0 if dtype == 'float32' else 25)
+  # (the launch geometry is the engine's, as in bench.py; SOAK_MIGRATE=c forces robot migration in chunks of c steps - the queue under load)
+  env = build_env(N, 0, dtype, migrate_steps=int(os.environ.get('SOAK_MIGRATE', '-1')), rollout_streams=1 if os.environ.get('SOAK_MIGRATE') else -1)
   eng = env.engine
   g = torch.Generator(device='cuda').manual_seed(20261004)
   t0 = time.perf_counter()
