@@ -149,3 +149,31 @@ def test_the_engine_chooses_the_launch_geometry():
   assert (p20['steps_per_launch'], p20['slices'], p20['migrate_steps']) == (20, 1, 10)
   assert (p1000['steps_per_launch'], p1000['launches'], p1000['slices'], p1000['migrate_steps']) == (250, 4, 1, 25)
   big._close()
+
+
+def test_scratch_and_queues_grow_with_the_rollouts():
+  """The record scratch of fused launches and the migration queues are sized for the rollout at hand and grow when a longer
+  one comes (round 5): rollouts of 5, 40 and 300 steps on ONE engine - the engine's own geometry, and the same with robot
+  migration forced - against an engine that runs one launch per step; bit-identical outputs and states throughout."""
+  import torch
+  n = 1024
+  auto = _env(n, 'float64', -1, -1, -1, 17)
+  forced = _env(n, 'float64', -1, 1, 7, 17)
+  plain = _env(n, 'float64', 1, 1, 0, 17)
+  g = torch.Generator(device='cuda').manual_seed(21)
+  phase = torch.randint(0, 17, (n,), device='cuda', generator=g, dtype=torch.int32)
+  for e in (auto, forced, plain):
+    e.engine.term_count[:, 0] = phase
+  for k in (5, 40, 300):
+    acts = (torch.rand(k, n, 12, device='cuda', dtype=torch.float64, generator=g) * 2 - 1) * 6.2831853
+    want = plain.engine.rollout(acts, abi.STEP_ALL, record=True)
+    for e in (auto, forced):
+      got = e.engine.rollout(acts, abi.STEP_ALL, record=True)
+      torch.cuda.synchronize()
+      for x, y in zip(want, got):
+        assert torch.equal(x, y), k
+      assert torch.equal(plain.engine.state, e.engine.state), k
+  assert auto.engine.plan(300)['steps_per_launch'] == 250 and forced.engine.plan(300)['migrate_steps'] == 7
+  assert forced.engine.stats.cpu().numpy()[6] == 0
+  for e in (auto, forced, plain):
+    e._close()
