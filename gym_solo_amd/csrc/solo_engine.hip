@@ -502,6 +502,7 @@ struct Engine final : EngineBase {
     // times a rollout of a given length with the engine's own geometry)
     const int S = cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1;
     Plan plan = make_plan(reps * S, flags);
+    if (cfg.steps_per_launch == -1) { plan.S = 1; plan.launches = reps; plan.migrate = 0; }   // (reps launches of ONE step, whatever the engine would choose for a rollout of reps steps)
     const int rc_chain = rollout_impl(plan, (const T*)a, reps * S, flags, nullptr, nullptr, nullptr, s, e0, e1, &groups);
     if (rc_chain) return rc_chain;
     HIP_TRY(hipStreamSynchronize(s));

@@ -350,8 +350,9 @@ int solo_engine_set_terrain(SoloEngine* eng, const SoloTerrain* terrain, void* s
 int solo_engine_set_order(SoloEngine* eng, const int32_t* order_dev, void* stream);
 /* name of the dominant kernel (for rocprof cross-checks) and its last launch geometry */
 const char* solo_engine_kernel_name(SoloEngine* eng);
-/* Times a rollout of reps * steps_per_launch steps exactly as solo_engine_rollout runs it (same
- * slicing, same fused launches; the step kernel, its output epilogue included) with hipEvents
+/* Times a rollout of reps * steps_per_launch steps - the CONFIGURED steps per launch; one step per launch when that is
+ * left to the engine (solo_engine_time_rollout times a rollout with the engine's own geometry) - as solo_engine_rollout
+ * runs it (same slicing, same fused launches; the step kernel, its output epilogue included) with hipEvents
  * recorded ON THE STREAMS THE KERNELS ARE LAUNCHED ON (every slice's internal stream when
  * rollout_streams > 1, else `stream`) and returns the mean milliseconds per LAUNCH over all slices;
  * one launch covers N / max(1, rollout_streams) robots x steps_per_launch steps.
