@@ -622,8 +622,10 @@ struct Engine final : EngineBase {
 
   const char* kernel_name() override {
     const bool resid = cfg.solver_residual_threshold > 0;
-    if (sizeof(T) == 4) return resid ? "solo_step_kernel<float, true, true>" : "solo_step_kernel<float, true, false>";
-    return resid ? "solo_step_kernel<double, true, true>" : "solo_step_kernel<double, true, false>";
+    // (the instantiation of a launch whose robots do not migrate - every launch of up to 4096 robots under the engine's own
+    // policy; a migrating launch's last template argument is `true`)
+    if (sizeof(T) == 4) return resid ? "solo_step_kernel<float, true, true, false>" : "solo_step_kernel<float, true, false, false>";
+    return resid ? "solo_step_kernel<double, true, true, false>" : "solo_step_kernel<double, true, false, false>";
   }
 };
 

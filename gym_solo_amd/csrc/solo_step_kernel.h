@@ -132,8 +132,11 @@ namespace solo {
 #ifndef SOLO_PRIO_SWEEPS_F64
 #define SOLO_PRIO_SWEEPS_F64 12
 #endif
+#ifndef SOLO_QUEUE_SPINS
+#define SOLO_QUEUE_SPINS (1 << 22)   // polls of a ring slot before a wave gives up (SOLO_ERR_INCOMPLETE); the CPU emulator's fault-injection test builds with fewer
+#endif
 #ifndef SOLO_PRIO_BY_ROWS
-#define SOLO_PRIO_BY_ROWS 1   // (f64 - the slot-space solver knows its row count; 0: the A/B build)
+#define SOLO_PRIO_BY_ROWS 1   // (0: the A/B build)
 #endif
 #ifndef SOLO_PRIO_ROWS_1
 #define SOLO_PRIO_ROWS_1 11
@@ -787,10 +790,11 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   // predicts next to nothing - rank correlation 0.2, profiles/round5_cost_persistence.log) - and what follows, the column
   // build (proportional to the rows) and the Gauss-Seidel iteration, is where robot-steps differ: the more rows, the higher
   // the wave's priority from here to the end of the solve (which sets the rotation / the slow robot's level again).
-  // K = 20 +4 %, one launch per step and 250-step launches unchanged (profiles/round5_prio_by_rows_ab.log); thresholds
-  // 8 / 14 / 20 and 14 / 20 / 26 measured the same and 3 % less.
-  if constexpr (kCompact) {
-    wave_set_priority_level(prio_sweeps > kPrioSweeps<T> * prio_steps ? 3 : priority_by_rows(n_live));
+  // K = 20 +4 % in f64 and in f32, one launch per step and 250-step launches unchanged (profiles/round5_prio_by_rows_ab.log);
+  // thresholds 8 / 14 / 20 and 14 / 20 / 26 measured the same and 3 % less.
+  {
+    const int rows_now = kCompact ? n_live : __builtin_popcountll(wave_ballot(live));   // (lane = row, f32: the live lanes)
+    wave_set_priority_level(prio_sweeps > kPrioSweeps<T> * prio_steps ? 3 : priority_by_rows(rows_now));
   }
 #endif
   ColumnBank<T> A;
@@ -1248,7 +1252,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     // BOUNDED wait: a wave that gives up counts itself in slot 6 of the statistics and leaves (never observed; a
     // launch must not hang on a bug)
     int ready = -1;
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+    for (int spin = 0; spin < SOLO_QUEUE_SPINS; ++spin) {
       if (lane0 == 0) ready = wave_atomic_load(ring_slots + (size_t)q_ring * ring_len + ticket);
       ready = wave_readlane_int(ready, 0);
       if (ready >= 0) break;

@@ -33,6 +33,8 @@ using namespace solo;
 
 // Gauss-Seidel sweeps each robot ran in the last emulated launch (view.cost of the engine)
 static std::vector<int32_t> g_last_cost;
+static int32_t g_fault = 0;      // the engine's fault word (KBuffers::fault), as the emulator sees it
+static int g_sabotage = 0;
 extern "C" int solo_emu_last_cost(int32_t* out, int n) {
   const int m = (int)g_last_cost.size() < n ? (int)g_last_cost.size() : n;
   for (int i = 0; i < m; ++i) out[i] = g_last_cost[i];
@@ -103,13 +105,17 @@ static int run(const SoloConfig* cfg, const SoloModel* mdl, const SoloProgram* p
   // robot migration (SoloConfig::migrate_steps), as Engine::launch_chain sets it up: chunks of the launch's steps go
   // through the queue; the emulated waves run one after the other, so the first drains every ring it can reach
   std::vector<int32_t> queue;
-  B.queue = nullptr; B.q_rings = 1; B.q_chunk = 0; B.fault = nullptr;
+  B.queue = nullptr; B.q_rings = 1; B.q_chunk = 0; B.fault = &g_fault;
   B.warm = wrm.empty() ? nullptr : wrm.data();
   if (cfg->migrate_steps > 0 && steps > cfg->migrate_steps && (flags & SOLO_STEP_PHYSICS) && flags != SOLO_STEP_PHYSICS) {  // (as the engine: stepSimulation-only launches do not migrate)
     B.q_chunk = migration_chunk_steps(steps, cfg->migrate_steps);
     B.q_rings = n == 16 ? 8 : migration_rings(n);  // (16 robots: eight rings of two, so that the CPU suite walks several rings too)
-    queue.resize(migration_queue_ints(n, steps, B.q_chunk));
-    for (size_t i = 0; i < queue.size(); ++i) migration_queue_init(queue.data(), i, 0, n, B.q_rings, steps, B.q_chunk, nullptr);
+    queue.resize(migration_queue_ints(n, steps, B.q_chunk) + 1);
+    for (size_t i = 0; i + 1 < queue.size(); ++i) migration_queue_init(queue.data(), i, 0, n, B.q_rings, steps, B.q_chunk, nullptr);
+    queue.back() = -1;
+    // FAULT INJECTION (tests/test_emu_kernel.py): ring 0's tail starts one slot too far - its first chunk-1 slot is never
+    // published, the wave that holds that slot's ticket must give up (bounded wait), count itself and set the fault word
+    if (g_sabotage) queue[16] += 1;
     B.queue = queue.data();
   }
   const KParams<T>* Pp = &P;
@@ -155,3 +161,7 @@ extern "C" int solo_emu_rollout(const SoloConfig* cfg, const SoloModel* mdl, con
   return run<double>(cfg, mdl, prog, n, state, snapshot, actions, targets, params, obs, reward,
                      done, term_count, stats, flags, steps, terrain, warm);
 }
+
+// the fault word a wave sets when it gives up waiting for a ring slot (and clears it); fault injection on / off
+extern "C" int solo_emu_take_fault(void) { const int f = g_fault; g_fault = 0; return f; }
+extern "C" void solo_emu_sabotage_queue(int on) { g_sabotage = on; }

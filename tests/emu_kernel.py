@@ -31,6 +31,8 @@ def load(variant=''):
                                    C.c_void_p, dp, C.c_uint32, C.c_void_p, dp]
   lib.solo_emu_last_cost.restype = C.c_int
   lib.solo_emu_last_cost.argtypes = [C.c_void_p, C.c_int]
+  lib.solo_emu_take_fault.restype = C.c_int      # the fault word a wave sets when it gives up waiting (KBuffers::fault); reading clears it
+  lib.solo_emu_sabotage_queue.argtypes = [C.c_int]
   return lib
 
 

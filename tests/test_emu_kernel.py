@@ -108,6 +108,35 @@ def test_robot_migration_is_scheduling_only(dtype, n, k, chunk):
   assert out[1][2][4].all()  # TimeBased(4): every robot ends its first episode on the fifth step
 
 
+def test_a_wave_that_gives_up_waiting_says_so():
+  """The migration queue's waits are bounded (a launch must not hang on a bug) - and a wave that gives up must not pass
+  for success: it counts itself in slot 6 of the statistics and sets the engine's fault word, which the
+  C-ABI turns into SOLO_ERR_INCOMPLETE on every later call.  FAULT INJECTION on the emulator: ring 0's tail starts one
+  slot too far, so the first chunk-1 slot is never published; the wave holding that ticket gives up, every other ticket
+  is served, and exactly one robot of the launch is left half stepped."""
+  prog = bench_program()
+  n, k, chunk = 4, 8, 4
+  rng = np.random.default_rng(3)
+  acts = rng.uniform(-6, 6, (k, n, 12))
+  ca, ma = make_abi('float64', auto_reset=True, settle_steps=40, migrate_steps=chunk)
+  e = EmuEngine(ca, ma, n, program=prog)
+  e.settle()
+  start = (e.state.copy(), e.snapshot.copy())
+  e.rollout(acts)
+  good = e.state.copy()
+  assert e.lib.solo_emu_take_fault() == 0 and e.stats[:, 6].sum() == 0
+  e.state[:], e.snapshot[:] = start
+  e.term_count[:] = 0
+  e.lib.solo_emu_sabotage_queue(1)
+  try:
+    e.rollout(acts)
+  finally:
+    e.lib.solo_emu_sabotage_queue(0)
+  assert e.lib.solo_emu_take_fault() == 1 and e.stats[:, 6].sum() == 1
+  left_behind = [r for r in range(n) if not np.array_equal(e.state[r], good[r])]
+  assert len(left_behind) == 1, left_behind
+
+
 def test_ubsan_build_runs_clean():
   """-fsanitize=undefined,bounds-strict build of the kernel source: aborts on the first report."""
   ca, ma = make_abi('float32', settle_steps=30)
