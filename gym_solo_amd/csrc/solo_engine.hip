@@ -259,8 +259,9 @@ struct Engine final : EngineBase {
   //          work: +1 ... 2 %), one when it is a single launch (halves of a single launch only shorten each other's tails);
   //        * no migration while every robot of a launch has a wave slot of its own - 4096 robots: four waves on each of the
   //          1024 SIMDs in BOTH precisions since round 5 (f64 round 4: three - 3072 slots - and migration was worth +16 %):
-  //          with all robots resident a hand-over only costs; beyond that, two chunks per launch (several launches: chunks
-  //          of 25 steps on ONE chain) let the waves that finish early take over the robots that started late.
+  //          with all robots resident a hand-over only costs; beyond that, in f64, two chunks per launch (several launches:
+  //          chunks of 25 steps on ONE chain) let the waves that finish early take over the robots that started late
+  //          (f32: never - measured slower).
   struct Plan { int S, launches, slices, migrate; };
   static constexpr int kWavesPerSimd = solo::kWavesPerSimd<T>;
   int resident_robots() const {
@@ -289,7 +290,9 @@ struct Engine final : EngineBase {
     else if (cfg.migrate_steps == -1 && !physics_only && (flags & SOLO_STEP_PHYSICS) && p.S >= 8) {
       // (8192 robots, f64, profiles/round5_baseline_configs_f64.log: one launch of 20 steps 1.485e8 in two chunks against
       // 1.474e8 without; 1000 steps 1.995e8 as one chain in chunks of 25 against 1.956e8 on two slices, 1.76e8 on one chain)
-      if (n > resident_cache) {
+      // f32 at 8192 robots: migration costs 2.6 % (K = 20) / 3.8 % (1000 steps) - its robot-steps are short against a
+      // hand-over (profiles/round5_launch_policy_f32_8192.log): f64 only
+      if (n > resident_cache && sizeof(T) == 8) {
         if (p.launches == 1) p.migrate = (p.S + 1) / 2;
         else if (p.S >= 50) { p.migrate = 25; if (cfg.rollout_streams == -1) streams = 1; }
       }

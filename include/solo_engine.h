@@ -164,8 +164,9 @@ typedef struct SoloConfig {
                                 the unluckiest SIMD's robots are.  Scheduling only: results are bit-identical.  0 = off
                                 (one wave steps one robot through the whole launch).  -1 = the engine chooses: off while
                                 every robot of a launch has a wave slot of its own (4096 robots: four waves on each of
-                                the chip's 1024 SIMDs, in both precisions since round 5), else two chunks per launch
-                                (chunks of 25 steps in a rollout of several launches) - solo_engine_plan reports it. */
+                                the chip's 1024 SIMDs, in both precisions since round 5), else - in f64 - two chunks per
+                                launch (chunks of 25 steps in a rollout of several launches); f32 never (measured slower) -
+                                solo_engine_plan reports it. */
   int32_t reserved0;         /* (padding; must be 0) */
   double solver_warm_start;  /* f in (0, 1]: the Gauss-Seidel iteration of a step STARTS from f x the impulses the previous
                                 step ended with (every row: motors, joint limits, contacts - clamped to the row's bounds
