@@ -55,6 +55,21 @@
 //    kernel: round 2's product was right because the allocator had picked v8.  Stand-alone loops of the same shape,
 //    down to the register numbers (tools/microbench/gpr_idx_hazard*.hip), never fail: the mechanism is not established.
 //    The rule here is the conservative one - no vector instruction in the shadow of either mode switch.
+//  * (round 5) WHERE the row update waits.  tools/microbench/pgs_row64.hip + gen_row64_scan.py (one wave per SIMD, the f64
+//    row in a straight line, one filler instruction inserted at every position in turn; profiles/round5_microbench_*):
+//    v_fma / v_max / v_add_f64 issue every 4.0 cycles, dependent or not, yet the 19-instruction row took 129 cycles, not
+//    76 - and removing any one of its cross-pipe dependencies changed nothing.  The wait sits at two places: a SCALAR
+//    instruction issued behind a vector instruction that WRITES AN SGPR (v_readlane, v_cmp) stalls until that write has
+//    landed, ~16 cycles - the s_lshl / s_set_gpr_idx_on behind the readlanes, and the s_and behind the compare; four
+//    v_nop behind the readlanes and three behind the compare are free.  Vector instructions do not wait there.  So the
+//    row's vector work that does not feed the chain - lam[row] = cand[row], thr = tol |lam| - now sits BEHIND THE
+//    READLANES, and the lane mask of the updated row comes from a scalar shift in front of them (a vector compare would
+//    be one more SGPR write): 129 -> 117 cycles per row for a wave alone, bit for bit the same arithmetic.  Same call
+//    (profiles/round5_row_order_ab_*.log, round5_scalar_lanemask_ab_f64.log): f64 20-step launch +2.7 %, one launch
+//    per step +4.2 %, launches of 250 +0.3 % (+1.5 % more with the scalar mask: one VALU instruction less per row for
+//    the waves that share a SIMD); f32 +2.9 / +4.6 / +1.9 %.  What is left - ~16 cycles behind the compare, 4 behind the
+//    readlanes - has no independent vector work to take: every arrangement of the three fillers there are measures the
+//    same (the deferred / ping-pong orders of the scan).
 //  * the manual wait states of gfx940-class hardware are respected by construction (>= 2 instructions
 //    between a VALU write of an SGPR / VCC and a VALU read of it, >= 2 between a VALU write and a DPP
 //    read, >= 1 before a v_readlane of a freshly written VGPR) - the assembler does not check them
@@ -81,6 +96,15 @@ namespace solo {
 // register to initialise per phase.  Between a VALU write of an SGPR / VCC and the VALU read of it sit two
 // other instructions (the manual wait states of gfx940-class hardware; the assembler does not check
 // inline asm).
+// vcc = the updated row's lane, by a SCALAR shift (round 5; a vector compare before: -DSOLO_PGS_VECTOR_LANEMASK, the A/B
+// build): one VALU instruction less per row for the waves that share the SIMD, the same issue slot for a wave alone
+#ifdef SOLO_PGS_VECTOR_LANEMASK
+#define SOLO_PGS_LANE_MASK "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"
+#define SOLO_PGS_LANE_OPERAND(lane) [lane] "v"(lane),
+#else
+#define SOLO_PGS_LANE_MASK "s_lshl_b64 vcc, 1, %[rs]\n\t"
+#define SOLO_PGS_LANE_OPERAND(lane)
+#endif
 #if defined(SOLO_PGS_HAZARD_PROBE) && SOLO_PGS_HAZARD_PROBE > 0
 // DIAGNOSTIC builds only (tools/gpu_hazard_probe.py; never the product): round 2's order of the row update - the indexed
 // v_fma directly behind s_set_gpr_idx_on, the v_cndmask directly behind s_set_gpr_idx_off - with an s_nop in the first
@@ -122,7 +146,7 @@ namespace solo {
 #endif
 #define SOLO_PGS_ROW(PH)                                                                           \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"                                                               \
-  "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
+  SOLO_PGS_LANE_MASK                                                                               \
   "v_readlane_b32 %[sd], %[dl], %[rs]\n\t"                                                         \
   SOLO_PGS_PROBE_CORE                                                                              \
   "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n\t"                                             \
@@ -136,16 +160,16 @@ namespace solo {
 #else
 #define SOLO_PGS_ROW(PH)                                                                           \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
-  "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
+  SOLO_PGS_LANE_MASK                                                                               \
   "v_readlane_b32 %[sd], %[dl], %[rs]\n\t"    /* the change of its impulse */                      \
+  "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n\t"   /* lam[row] = cand[row]: VECTOR work behind the readlane - a scalar */ \
+  "v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n\t"           /* instruction issued there waits for the readlane's SGPR write (see above) */ \
   "s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n\t"                                                      \
   "s_lshl_b64 %[t], -2, %[rs]\n\t"            /* (a scalar instruction BETWEEN the mode switch and the indexed VALU instruction: see above) */ \
   "v_fma_f32 %[v], v64, %[sd], %[v]\n\t"      /* v += column * change; the column is v[64 + row]: source 0, register-indexed */ \
   "s_set_gpr_idx_off\n\t"                                                                          \
   "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor (and the wait state after the mode switch) */ \
-  "v_cndmask_b32_e32 %[lam], %[lam], %[cand], vcc\n\t"                                             \
   "v_med3_f32 %[cand], %[v], %[lo], %[hi]\n\t"                                                     \
-  "v_mul_f32_e64 %[thr], %[tol], |%[lam]|\n\t"                                                     \
   "v_sub_f32_e32 %[dl], %[cand], %[lam]\n\t"                                                       \
   "v_cmp_gt_f32_e64 %[pend], |%[dl]|, %[thr]\n\t"                                                  \
   SOLO_PGS_COUNT_ROW                                                                               \
@@ -260,7 +284,7 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 #ifdef SOLO_STAMPS
         , [nch] "+s"(n_changed)
 #endif
-      : [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
+      : SOLO_PGS_LANE_OPERAND(lane) [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
         [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes), "{v[64:95]}"(A.a0), "{v[96:127]}"(A.a1)
       : "vcc", "scc");
   // (s_set_gpr_idx_on overwrites M0.  M0 is a RESERVED register for the AMDGPU backend - naming it in the clobber
@@ -342,20 +366,20 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<float>& A, floa
 #endif
 #define SOLO_PGS_ROW64(PH)                                                                         \
   "s_ff1_i32_b64 %[rs], %[todo]\n\t"          /* the row to update (wave-uniform) */               \
-  "v_cmp_eq_u32_e32 vcc, %[rs], %[lane]\n\t"                                                       \
+  SOLO_PGS_LANE_MASK                                                                               \
   "v_readlane_b32 s94, " SOLO_PGS64_DL_LO ", %[rs]\n\t"       /* the change of its impulse */                      \
   "v_readlane_b32 s95, " SOLO_PGS64_DL_HI ", %[rs]\n\t"                                                            \
+  "v_cndmask_b32_e32 " SOLO_PGS64_LAM_LO ", " SOLO_PGS64_LAM_LO ", " SOLO_PGS64_CAND_LO ", vcc\n\t"   /* lam[row] = cand[row] and its threshold: VECTOR work behind */ \
+  "v_cndmask_b32_e32 " SOLO_PGS64_LAM_HI ", " SOLO_PGS64_LAM_HI ", " SOLO_PGS64_CAND_HI ", vcc\n\t"   /* the readlanes - a scalar instruction issued there waits ~16 */ \
+  "v_mul_f64 %[thr], %[tol], |" SOLO_PGS64_LAM "|\n\t"                                                       /* cycles for their SGPR writes (see above) */ \
   "s_lshl_b32 %[ri], %[rs], 1\n\t"            /* register index of the column: 2 x row */          \
   "s_set_gpr_idx_on %[ri], gpr_idx(SRC0)\n\t"                                                      \
   "s_lshl_b64 %[t], -2, %[rs]\n\t"            /* (a scalar instruction between the mode switch and the indexed VALU instruction) */ \
   "v_fma_f64 %[v], " SOLO_PGS64_COL0 ", s[94:95], %[v]\n\t"  /* v += column * change (source 0 register-indexed) */ \
   "s_set_gpr_idx_off\n\t"                                                                          \
   "s_and_b64 %[w], " PH ", %[t]\n\t"          /* the phase's rows beyond the cursor (and the wait state after the mode switch) */ \
-  "v_cndmask_b32_e32 " SOLO_PGS64_LAM_LO ", " SOLO_PGS64_LAM_LO ", " SOLO_PGS64_CAND_LO ", vcc\n\t"   /* lam[row] = cand[row] */                       \
-  "v_cndmask_b32_e32 " SOLO_PGS64_LAM_HI ", " SOLO_PGS64_LAM_HI ", " SOLO_PGS64_CAND_HI ", vcc\n\t"                                                    \
   "v_max_f64 " SOLO_PGS64_CAND ", %[v], " SOLO_PGS64_LO "\n\t"                                                     \
   "v_min_f64 " SOLO_PGS64_CAND ", " SOLO_PGS64_CAND ", " SOLO_PGS64_HI "\n\t"                                               \
-  "v_mul_f64 %[thr], %[tol], |" SOLO_PGS64_LAM "|\n\t"                                                     \
   "v_add_f64 " SOLO_PGS64_DL ", " SOLO_PGS64_CAND ", -" SOLO_PGS64_LAM "\n\t"                                              \
   "v_cmp_gt_f64_e64 %[pend], |" SOLO_PGS64_DL "|, %[thr]\n\t"                                             \
   SOLO_PGS_COUNT_ROW                                                                               \
@@ -451,7 +475,7 @@ __device__ __forceinline__ int pgs_solve_gfx950(const ColumnBank<double>& A, dou
         , [nch] "+s"(n_changed)
 #endif
       : "{" SOLO_PGS64_LAM "}"(lam), "{" SOLO_PGS64_CAND "}"(cand), "{" SOLO_PGS64_DL "}"(dl), "{" SOLO_PGS64_LO "}"(lo), "{" SOLO_PGS64_HI "}"(hi),
-        [lane] "v"(lane), [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
+        SOLO_PGS_LANE_OPERAND(lane) [tol] "v"(tol), [mu] "v"(mu), [iters] "s"(iters), [ph0] "s"(phase0), [ph1] "s"(phase1), [ph2] "s"(phase2),
         [tan1] "s"(tan1_lanes), [tang] "s"(tangent_lanes),
         "{" SOLO_PGS64_BANK0 "}"(A.a0), "{" SOLO_PGS64_BANK1 "}"(A.a1)
       : "vcc", "scc", "s94", "s95");

@@ -1,6 +1,6 @@
 """DIAGNOSTIC (make -C gym_solo_amd/csrc stamps): where does a SINGLE-STEP launch (the closed loop's granularity) spend its
 time - per phase, for the median wave and for the 40 longest-lived waves (the ones the launch waits for)?  In-kernel
-s_memtime stamps (100 MHz constant clock per XCD: 10 ns ticks); the stamps build holds 14 workgroups per CU, not 16:
+s_memtime stamps (shader clock cycles); the stamps build holds 14 workgroups per CU, not 16:
 shares, not run times.
   DTYPE=float64 python tools/gpu_step_phases.py [N]"""
 import sys, os, ctypes as C
@@ -34,7 +34,7 @@ for rep in range(10):
   acc_med.append(np.median(d, axis=0)); acc_slow.append(d[slow].mean(axis=0)); spans.append((life.max(), np.median(life), life[slow].mean()))
   its = (buf[:, 15] & 0xffff).astype(np.int64)
 med, slw = np.mean(acc_med, axis=0), np.mean(acc_slow, axis=0)
-print('%s, N = %d, single-step launches (10): wave life median %.0f ticks, the 40 longest-lived %.0f, the longest %.0f (10-ns ticks)' % (
+print('%s, N = %d, single-step launches (10): wave life median %.0f ticks, the 40 longest-lived %.0f, the longest %.0f (shader cycles)' % (
   DTYPE, n, np.mean([s[1] for s in spans]), np.mean([s[2] for s in spans]), np.mean([s[0] for s in spans])))
 for k, nm in enumerate(names):
   print('   %-18s median wave %7.0f (%4.1f %%)    40 longest-lived %7.0f (%4.1f %%)' % (nm, med[k], 100 * med[k] / med.sum(), slw[k], 100 * slw[k] / slw.sum()))
