@@ -30,6 +30,12 @@ I = dict(
   thr='v_mul_f64 %[thr], %[tol], |v[50:51]|',
   add='v_add_f64 v[54:55], v[52:53], -v[50:51]',
   cmp='v_cmp_gt_f64_e64 %[pend], |v[54:55]|, %[thr]',
+  sm='s_lshl_b64 vcc, 1, %[rs]',
+  cmpv='v_cmp_gt_f64_e64 vcc, |v[54:55]|, %[thr]',
+  todov='s_and_b64 %[todo], vcc, %[w]',
+  cmpx='v_cmpx_gt_f64_e64 |v[54:55]|, %[thr]',
+  todox='s_and_b64 %[todo], exec, %[w]',
+  exon='s_mov_b64 exec, -1',
   br='s_nop 0',   # (the branch's issue slot)
   todo='s_and_b64 %[todo], %[pend], %[w]',
   keep='s_or_b64 %[todo], %[todo], %[ph]',   # keeps the walk going (not an instruction of the product's row)
@@ -42,6 +48,10 @@ ORDERS = {
   'product': 'ff1 eq rl0 rl1 ri on t fma off w c0 c1 max min thr add cmp br todo keep',
   # lam[row] = cand[row] and thr behind the compare (new candidates in a second pair; a real loop alternates the pairs)
   'deferred': 'ff1 rl0 rl1 ri on t fma off w maxn minn addn cmp eq c0 c1 thr br todo keep',
+  'round5': 'ff1 sm rl0 rl1 c0 c1 thr ri on t fma off w max min add cmp todo br keep',
+  'round5_vcc': 'ff1 sm rl0 rl1 c0 c1 thr ri on t fma off w max min add cmpv todov br keep',
+  'round5_nobr': 'ff1 sm rl0 rl1 c0 c1 thr ri on t fma off w max min add cmp todo keep',
+  'round5_w_late': 'ff1 sm rl0 rl1 c0 c1 thr ri on t fma off br max min add cmp w todo keep',
   'fillA': 'ff1 rl0 rl1 eq c0 c1 thr ri on t fma off w max min add cmp br todo keep',
   'fillA3': 'ff1 rl0 rl1 eq c0 c1 ri on t fma off w thr max min add cmp br todo keep',
   'eq_first': 'ff1 eq rl0 rl1 c0 c1 thr ri on t fma off w max min add cmp br todo keep',
