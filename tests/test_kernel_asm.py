@@ -83,3 +83,38 @@ def test_hand_over_waits_for_its_stores_before_it_publishes():
     assert any(l.startswith('s_waitcnt') and 'vmcnt(0)' in l for l in between), (m.group(1), between[-12:])
     checked += 1
   assert checked == 4   # {f, d} x {default solver, residual threshold}
+
+
+def test_no_scalar_instruction_in_the_shadow_of_the_row_updates_readlanes():
+  """Round 5 (solo_pgs_gfx950.h, tools/microbench/gen_row64_scan.py): a scalar instruction issued behind a vector
+  instruction that writes an SGPR waits ~16 cycles for that write - so in every Gauss-Seidel row update of every product
+  kernel the broadcast of the row's impulse change (v_readlane ... %[rs]) is followed by the row's independent VECTOR work
+  (lam[row] = cand[row], its threshold) before the first scalar instruction: >= 3 vector instructions behind the f64
+  row's two readlanes, >= 2 behind the f32 row's one - and the updated row's lane mask is a scalar shift, not a vector compare."""
+  import re
+  subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'gym_solo_amd', 'csrc'), 'asm'], stderr=subprocess.DEVNULL)
+  text = open(os.path.join(ROOT, 'gym_solo_amd', 'csrc', 'solo_engine.gfx950.s')).read()
+  rows = {'f': 0, 'd': 0}
+  for m in re.finditer(r'^_ZN4solo16solo_step_kernelI(\w)Lb\dELb\dELb\dEE\w*:.*?\n(.*?)^\.Lfunc_end', text, re.S | re.M):
+    ins = [l.strip() for l in m.group(2).split('\n') if re.match(r'^\s+[a-z]\w+', l) and not l.strip().startswith('.')]
+    for i, l in enumerate(ins):
+      if not l.startswith('s_set_gpr_idx_on'):
+        continue
+      # walk back from the mode switch to the row's s_ff1: the instructions of the row in front of the indexed FMA
+      j = i
+      while not ins[j].startswith('s_ff1_i32_b64'):
+        j -= 1
+        assert i - j < 12, ins[i - 12:i + 1]
+      head = ins[j:i]
+      lanes = [k for k, x in enumerate(head) if x.startswith('v_readlane_b32')]
+      assert lanes and len(lanes) == (2 if m.group(1) == 'd' else 1), head
+      behind = head[lanes[-1] + 1:]
+      vector_run = 0
+      for x in behind:
+        if not x.startswith('v_'):
+          break
+        vector_run += 1
+      assert vector_run >= (3 if m.group(1) == 'd' else 2), head
+      assert not any(x.startswith('v_cmp_eq_u32') for x in head) and any(x.startswith('s_lshl_b64 vcc, 1,') for x in head), head
+      rows[m.group(1)] += 1
+  assert rows['f'] >= 48 and rows['d'] >= 48, rows   # (six instantiations per precision x the row updates of their walks)
