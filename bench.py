@@ -48,6 +48,7 @@ VALU_CYCLES_ALONE = 4                                   # the SIMD; 4 for one wa
 # 1845 of 3162 in round 5's 128-VGPR kernel), the rest - moves, DPP, selects, integer, compares on 32-bit halves - 32-bit operations
 F64_ARITH_SHARE = 0.58
 SHADER_CLOCK_HZ = 2.4e9                                 # max clock, MI355X_MICROARCH.md chip table
+KERNEL_MS_SAMPLES = int(os.environ.get('SOLO_BENCH_KERNEL_SAMPLES', '101'))   # HIP-event samples of the dominant launch (roofline.kernel_ms: their median)
 METRIC = 'env-steps/s (whole node), 4096 Solo8 envs/GPU, 1/2/4/8 MI355X'
 # REHEARSAL knobs (never set by the driver; tests/test_bench_launcher.py): SOLO_BENCH_ENGINE=emu runs the whole script -
 # launcher, process group (gloo), timed regions, statistics all-reduce, JSON line - on the CPU wave emulator of the
@@ -250,6 +251,13 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd, 
   valu = pmc.get('valu_insts_per_env_step')
   if not valu:
     return 'dependent-issue-latency bound by construction (SURVEY.md §8d); no PMC profile committed for this dtype', None
+  # MEASURED (quote the counter, not a model): SQ_ACTIVE_INST_VALU - quad-cycles a SIMD's VALU was executing, summed
+  # over the waves - x 4 / (SIMDs x the launch's cycles, GRBM_GUI_ACTIVE / 8 XCDs), from the same --pmc pass of the same kernel
+  # sources and launch geometry (tools/make_pmc_traffic.py)
+  measured = pmc.get('valu_busy_share_measured')
+  if measured is None and pmc.get('step_kernel_wave_cycle_shares') and pmc.get('grbm_gui_active_per_launch'):
+    measured = (pmc['step_kernel_wave_cycle_shares']['active_inst_valu'] * pmc['step_kernel_wave_cycles'] * 4.0 /
+                (NUM_SIMDS * pmc['grbm_gui_active_per_launch'] / 8.0))
   cyc = VALU_CYCLES_SHARED if waves_per_simd >= 2 else VALU_CYCLES_ALONE
   if dtype == 'float64':  # (the mean over the kernel's mix of f64 arithmetic and 32-bit operations)
     cyc = cyc * (1.0 + F64_ARITH_SHARE)
@@ -264,7 +272,9 @@ def secondary_bound(pmc, env_steps_per_launch, chains, kern_ms, waves_per_simd, 
           'env-step - and the launch waiting for its slowest robot (DESIGN.md section 4)'
           % (valu, cyc, waves_per_simd, env_steps_per_launch, chains, util, NUM_SIMDS, clock / 1e9,
              ('%.0f' % pmc['insts_per_env_step']) if pmc.get('insts_per_env_step') else '~2300'),
-          {'bound': 'valu-issue', 'frac': util, 'valu_insts_per_env_step': valu, 'insts_per_env_step': pmc.get('insts_per_env_step'),
+          {'bound': 'valu-issue', 'frac': measured if measured is not None else util, 'frac_source': 'measured: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the committed --pmc pass' if measured is not None else 'modelled (no counter in the profile)',
+           'frac_modelled': util, 'wave_cycle_shares': pmc.get('step_kernel_wave_cycle_shares'),
+           'valu_insts_per_env_step': valu, 'insts_per_env_step': pmc.get('insts_per_env_step'),
            'cycles_per_valu_inst': cyc, 'simds': NUM_SIMDS, 'clock_hz': clock, 'concurrent_launch_chains': chains,
            'unit': 'share of the SIMDs\' VALU issue slots over the launch (SURVEY.md §8d: the secondary, practical bound)'})
 
@@ -484,7 +494,12 @@ def main():
     spl, slices = plan['steps_per_launch'], plan['slices']
     kk = min(k, 1000) // spl * spl or k   # (whole launches)
     bufs = eng.rollout_buffers(kk)   # (every step's outputs recorded: the timed region's own call)
-    kern_ms = statistics.median(eng.time_rollout(action_pool(kk), abi.STEP_ALL, out=bufs) for _ in range(15 if k <= 100 else 3))   # (a 20-step launch lasts as long as its slowest robot: 0.59 ... 0.98 ms from sample to sample - fifteen of them)
+    # (a 20-step launch lasts as long as its slowest robot - 0.59 ... 0.98 ms from action sample to action sample: fifteen samples
+    # (round 5) put the median ABOVE the wall clock's median of ~700 repeats; now as many samples as 0.15 s of launches hold,
+    # 101 for the driver's 20-step launch, fresh actions each)
+    samples = KERNEL_MS_SAMPLES if k <= 100 else 5
+    ks = sorted(eng.time_rollout(action_pool(kk), abi.STEP_ALL, out=bufs) for _ in range(samples))
+    kern_ms = statistics.median(ks)
     env_steps_per_launch = (n // slices) * spl
     bytes_per_launch = BYTES_PER_ENV_STEP[dtype] * env_steps_per_launch
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -498,7 +513,8 @@ def main():
             'traffic_profile': None if not pmc else {'entry': pmc.get('profile_key'), 'measured_on_this_launch_geometry': pmc.get('geometry_match'),
                                                      'stale': bool(pmc.get('stale')), 'kernel_source_hash': pmc.get('source_hash'),
                                                      'profile_kernel_source_hash': pmc.get('profile_hash') or pmc.get('kernel_source_hash')},
-            'kernel': eng.kernel_name, 'kernel_ms': kern_ms,
+            'kernel': eng.kernel_name, 'kernel_ms': kern_ms, 'kernel_ms_samples': len(ks), 'kernel_ms_min': ks[0], 'kernel_ms_max': ks[-1],
+            'kernel_ms_p10_p90': [ks[len(ks) // 10], ks[(9 * len(ks)) // 10]],
             'kernel_ms_note': 'HIP events around the launch chain of every slice, on the stream it is launched on; mean per '
                               'launch over slices and launches (the step kernel is the only kernel of a launch: its epilogue writes the outputs)',
             'bytes_per_env_step': BYTES_PER_ENV_STEP[dtype],
@@ -506,11 +522,41 @@ def main():
             'concurrent_launch_chains': slices, 'achieved_all_chains': achieved * slices,
             'launch_plan': plan, 'note': note, 'secondary': secondary}
 
+  def critical_path_floor(dtype, k, plan):
+    """The bound that binds at the metric's size is the launch's CRITICAL PATH: with every robot resident a fused launch lasts as
+    long as its slowest robot's K sequential steps.  Its floor, measured live: the same workload with ONE
+    wave per SIMD (resident_robots / waves_per_simd robots: nobody shares a SIMD, so the launch is its slowest robot's K steps
+    at a lone wave's issue rate) - HIP events, median of 51 launches.  kernel_ms / floor_ms says what sharing the SIMDs with
+    three other robots costs that path."""
+    lone = max(64, (plan.get('resident_robots') or 4096) // max(1, plan.get('waves_per_simd') or 4))
+    if lone >= n:
+      return None
+    tdtype = torch.float32 if dtype == 'float32' else torch.float64
+    env1 = build_env(lone, local_rank, dtype, steps_per_launch=args.steps_per_launch, rollout_streams=1, migrate_steps=0)
+    e1 = env1.engine
+    g1 = torch.Generator(device=dev).manual_seed(rank_seed(4321, rank))
+    spl = plan['steps_per_launch']
+    desynchronise_episodes(e1, g1, chunk=spl)
+    bufs = e1.rollout_buffers(spl)
+    pool = lambda: (torch.rand(spl, lone, abi.NUM_JOINTS, device=dev, dtype=tdtype, generator=g1) * 2 - 1) * two_pi
+    e1.time_rollout(pool(), abi.STEP_ALL, out=bufs)
+    fs = sorted(e1.time_rollout(pool(), abi.STEP_ALL, out=bufs) for _ in range(51 if spl <= 100 else 5))
+    env1._close()
+    return {'floor_ms': statistics.median(fs), 'floor_ms_min': fs[0], 'floor_ms_max': fs[-1], 'floor_robots': lone, 'floor_samples': len(fs),
+            'floor_note': 'the same launch (%d steps, same workload, steady state) with ONE wave per SIMD - %d robots: the slowest robot\'s '
+                          'sequential steps with its SIMD to itself; the launch at the metric\'s size cannot be shorter than its own slowest '
+                          'robot alone (the slowest of %d robots is slower than the slowest of %d: a lower bound of the bound)' % (spl, lone, n, lone)}
+
   times, stats, eng, env, action_pool, plan = timed(args.dtype, k, False, args.min_seconds, args.max_repeats)
   log('timed region done: %d repeats, stats all-reduce ok (episodes %.0f)' % (len(times), float(stats[2])))
   elapsed = statistics.median(times)
   roof = roofline(args.dtype, eng, action_pool, k, plan)
   env._close()
+  if rank == 0 and not EMU and not args.no_extra:
+    floor = critical_path_floor(args.dtype, k, plan)
+    if floor:
+      roof.update(floor)
+      roof['achieved_over_floor'] = floor['floor_ms'] / roof['kernel_ms']   # 1.0 = the launch is as short as its slowest robot alone would make it
 
   extra = {}
   if not args.no_extra:

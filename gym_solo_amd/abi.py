@@ -7,7 +7,7 @@ as DATA (``SoloModel``/``SoloConfig``).
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NUM_LEGS = 4
 NUM_DOF = 8
 NUM_JOINTS = 12
@@ -101,6 +101,7 @@ class SoloConfig(C.Structure):
     ('migrate_steps', C.c_int32),
     ('reserved0', C.c_int32),
     ('solver_warm_start', C.c_double),
+    ('base_lateral_friction', C.c_double),
   ]
 
 
@@ -221,6 +222,7 @@ ENTRY_POINTS = {
   'solo_engine_plan': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SoloLaunchPlan)]),
   'solo_engine_time_rollout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(C.c_double)]),
+  'solo_engine_reserve': (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
   'solo_engine_last_error': (C.c_char_p, [C.c_void_p]),
   'solo_last_create_error': (C.c_char_p, []),
   'solo_abi_version': (C.c_int, []),

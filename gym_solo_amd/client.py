@@ -88,13 +88,20 @@ class BatchedBulletClient:
   def changeDynamics(self, body, link, linearDamping=None, angularDamping=None,
                      restitution=None, lateralFriction=None, **kwargs):
     """solo8v2vanilla.py:158-163.  Damping / restitution are engine-wide constants; a lateral
-    friction that differs from the configured one is written to every env's parameter row."""
+    friction that differs from the configured one is written to every env's parameter row (the LEGS' coefficient:
+    links 0 .. 11; the base link, -1, keeps base_lateral_friction)."""
     cfg = self.engine.cfg
     for given, have, name in ((linearDamping, cfg.linear_damping, 'linearDamping'),
                               (angularDamping, cfg.angular_damping, 'angularDamping'),
                               (restitution, cfg.restitution, 'restitution')):
       if given is not None and not np.isclose(given, have):
         raise ValueError('{} is fixed at engine creation: {}'.format(name, have))
+    if link == -1:
+      # the base link: gym_solo never calls this for it (solo8v2vanilla.py:157-163 loops over range(getNumJoints)), so it keeps
+      # SoloConfig.base_lateral_friction - an engine-wide constant, not the per-robot parameter row
+      if lateralFriction is not None and not np.isclose(lateralFriction, cfg.base_lateral_friction):
+        raise ValueError('the base link\'s lateralFriction is fixed at engine creation (base_lateral_friction): {}'.format(cfg.base_lateral_friction))
+      return
     if lateralFriction is not None and not np.isclose(lateralFriction, cfg.lateral_friction):
       import torch
       self.engine.set_params(abi.PARAM_FRICTION, torch.full(

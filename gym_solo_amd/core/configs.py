@@ -65,6 +65,10 @@ class Solo8BaseConfig:
   solver_warm_start: float = 0.0
   motor_kp: float = 0.1           # pybullet POSITION_CONTROL default positionGain [recalled]
   motor_kd: float = 1.0           # pybullet POSITION_CONTROL default velocityGain [recalled]
+  # friction of the BASE link's collision spheres.  gym_solo's load_bodies() calls changeDynamics(lateralFriction=...)
+  # for `range(getNumJoints)` = links 0..11 (solo8v2vanilla.py:157-163) and never for the base (-1), which therefore keeps
+  # pybullet's default 0.5 [recalled] whatever `lateral_friction` says; per-robot friction (Engine.set_params) leaves it alone too
+  base_lateral_friction: float = 0.5
   contact_erp: float = 0.2
   contact_margin: float = 0.005
   joint_limit_margin: float = 0.5  # [rad] distance to a URDF joint limit below which its row is built
@@ -132,6 +136,9 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
   c.linear_damping = float(config.linear_damping)
   c.angular_damping = float(config.angular_damping)
   c.lateral_friction = float(config.lateral_friction)
+  c.base_lateral_friction = float(getattr(config, 'base_lateral_friction', 0.5))
+  if not c.base_lateral_friction >= 0:
+    raise ValueError('base_lateral_friction must be >= 0')
   c.restitution = float(config.restitution)
   c.contact_erp = float(config.contact_erp)
   c.contact_margin = float(config.contact_margin)

@@ -38,6 +38,8 @@ struct EngineBase {
   virtual int time_step(const void* a, uint32_t flags, int reps, hipStream_t s, double* ms) = 0;
   virtual int time_rollout(const void* a, int k, uint32_t flags, void* obs_out, void* reward_out, void* done_out, hipStream_t s, double* ms) = 0;
   virtual int plan(int k, SoloLaunchPlan* out) = 0;
+  virtual int reserve(int k, uint32_t flags) = 0;
+  virtual int check_fault() = 0;
   virtual const char* kernel_name() = 0;
   std::string err;
 };
@@ -165,7 +167,7 @@ struct Engine final : EngineBase {
   }
 
   // (SOLO_ERR_INCOMPLETE, sticky: a wave of an earlier migrating launch gave up waiting - a plain read of a pinned host word)
-  int check_fault() {
+  int check_fault() override {
     if (fault_host != nullptr && *(volatile int32_t*)fault_host != 0) {
       err = "a wave of an earlier launch with robot migration gave up waiting for its robot: some robots were not stepped through that launch (internal error)";
       return SOLO_ERR_INCOMPLETE;
@@ -252,7 +254,7 @@ struct Engine final : EngineBase {
   // ---- THE LAUNCH POLICY (round 5: it was bench.py's).  A rollout of k steps runs as `launches` fused launches of S steps
   //      per slice, `slices` independent launch chains, robots migrating every `migrate` steps of a launch (0: never).
   //      Configured values are taken as they are; -1 = the engine chooses, from what was measured on the benchmark workload
-  //      (profiles/round5_launch_policy_ab.log):
+  //      (profiles/round5_launch_policy_f32_8192.log, profiles/round5_baseline_configs_f64.log):
   //        * S = min(k, 250): the state record never leaves LDS inside a launch, and 250 steps average out the robots'
   //          unequal solver costs (1.8e8 env-steps/s against 1.2e8 at 20 steps per launch, f64);
   //        * two slices when the rollout takes several launches (one slice's launch boundary and tail overlap the other's
@@ -301,7 +303,20 @@ struct Engine final : EngineBase {
     p.slices = (streams > 1 && n >= 2 * streams) ? streams : 1;
     return p;
   }
-  // the record scratch of fused launches and the migration queues are sized for the rollout at hand (a larger one grows them)
+  // ints of the migration queue per robot (its sweep counter + its ring slots), for EVERY launch of a chain whose launches
+  // fuse up to S steps: the chunk count is not monotone in the step count - migration_chunk_steps stretches the chunks of a
+  // launch that would need more than 127 (a ring slot has 7 bits for the chunk index), so a ragged last launch of fewer steps
+  // can need MORE chunks than the full ones (S = 128, migrate 1: 64 chunks of 2; a 65-step tail: 65 chunks of 1) - but no
+  // launch ever has more than min(127, ceil(S / migrate)) (the regions were sized and strided for the S-step
+  // launch's count, and such a tail wrote past its slice's region).  The same expression sizes the allocation and strides
+  // the slices' regions (launch_chain), which asserts that every launch's queue fits.
+  static int queue_slots_per_robot(const Plan& p) {
+    const int chunks = solo::migration_chunks(p.S, p.migrate);
+    return 1 + (chunks < 127 ? chunks : 127);
+  }
+  // the record scratch of fused launches and the migration queues are sized for the rollout at hand (a larger one grows them:
+  // the one hidden device synchronisation of the stream-ordered calls - include/solo_engine.h "LAZY SCRATCH"; solo_engine_reserve
+  // does it ahead of time)
   int ensure_scratch(const Plan& p, uint32_t flags) {
     const bool records = (flags & (SOLO_STEP_OBS | SOLO_STEP_REWARD)) != 0;
     if (records && p.S > traj_steps) {
@@ -311,7 +326,7 @@ struct Engine final : EngineBase {
       traj_steps = p.S;
     }
     if (p.migrate > 0) {
-      const size_t need = (size_t)kMaxStreams * solo::kQueueHeader + (size_t)n * (1 + solo::migration_chunks(p.S, solo::migration_chunk_steps(p.S, p.migrate)));
+      const size_t need = (size_t)kMaxStreams * solo::kQueueHeader + (size_t)n * (size_t)queue_slots_per_robot(p);
       if (need > queue_ints) {
         HIP_TRY(hipDeviceSynchronize());
         if (queue) { (void)hipFree(queue); queue = nullptr; queue_ints = 0; }
@@ -376,8 +391,13 @@ struct Engine final : EngineBase {
         const int chunk = solo::migration_chunk_steps(steps, plan.migrate);
         b.q_chunk = chunk;
         b.q_rings = solo::migration_rings(count);
-        b.queue = queue + (size_t)slice * solo::kQueueHeader + (size_t)lo * (1 + solo::migration_chunks(S, solo::migration_chunk_steps(S, plan.migrate)));
+        b.queue = queue + (size_t)slice * solo::kQueueHeader + (size_t)lo * (size_t)queue_slots_per_robot(plan);
         const size_t ints = solo::migration_queue_ints(count, steps, chunk);
+        if (ints > (size_t)solo::kQueueHeader + (size_t)count * (size_t)queue_slots_per_robot(plan) ||
+            (size_t)(b.queue - queue) + ints > queue_ints) {   // (never: queue_slots_per_robot bounds every launch of <= S steps)
+          err = "internal error: the migration queue of a launch does not fit its slice's region";
+          return SOLO_ERR_INVALID_ARG;
+        }
         hipLaunchKernelGGL(solo::solo_queue_init_kernel, dim3((unsigned)((ints + 255) / 256)), dim3(256), 0, s, b.queue, ints, lo, count,
                            b.q_rings, steps, chunk, (const int32_t*)(use_order ? order : nullptr));
         HIP_TRY(hipGetLastError());
@@ -505,7 +525,10 @@ struct Engine final : EngineBase {
     // times a rollout of a given length with the engine's own geometry)
     const int S = cfg.steps_per_launch > 1 ? cfg.steps_per_launch : 1;
     Plan plan = make_plan(reps * S, flags);
-    if (cfg.steps_per_launch == -1) { plan.S = 1; plan.launches = reps; plan.migrate = 0; }   // (reps launches of ONE step, whatever the engine would choose for a rollout of reps steps)
+    if (cfg.steps_per_launch == -1) {   // (reps launches of ONE step, whatever the engine would choose for a rollout of reps steps - on ONE chain, whatever reps is)
+      plan.S = 1; plan.launches = reps; plan.migrate = 0;
+      if (cfg.rollout_streams == -1) plan.slices = 1;
+    }
     const int rc_chain = rollout_impl(plan, (const T*)a, reps * S, flags, nullptr, nullptr, nullptr, s, e0, e1, &groups);
     if (rc_chain) return rc_chain;
     HIP_TRY(hipStreamSynchronize(s));
@@ -541,6 +564,23 @@ struct Engine final : EngineBase {
       total += t;
     }
     *ms = total / groups / plan.launches;
+    return SOLO_OK;
+  }
+
+  int reserve(int k, uint32_t flags) override {
+    if (k <= 0) { err = "num_steps must be positive"; return SOLO_ERR_INVALID_ARG; }
+    if (int rc = check_flags(flags)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    // every rollout of up to k steps under this configuration: steps per launch grow with the rollout up to the cap, and the
+    // migration policy depends on the number of launches - the geometries of 1 .. k steps reduce to a handful
+    int last_S = -1, last_m = -1;
+    for (int kk = 1; kk <= k; kk = (kk < 512 ? kk + 1 : (kk * 2 < k ? kk * 2 : (kk == k ? k + 1 : k)))) {
+      const Plan p = make_plan(kk, flags);
+      if (p.S == last_S && p.migrate == last_m) continue;
+      last_S = p.S; last_m = p.migrate;
+      if (int rc = ensure_scratch(p, flags)) return rc;
+      if (p.slices > 1) if (int rc = ensure_streams(p.slices)) return rc;
+    }
     return SOLO_OK;
   }
 
@@ -670,6 +710,7 @@ int check_config(const SoloConfig* c, std::string* err) {
   if (!(c->restitution >= 0 && c->restitution <= 1)) return fail("restitution must be in [0, 1] (gym_solo configs.py:23)");
   if (!(c->action_scale > 0)) return fail("action_scale must be positive");
   if (c->lateral_friction < 0 || c->contact_margin < 0 || c->contact_erp < 0) return fail("negative contact parameter");
+  if (!(c->base_lateral_friction >= 0)) return fail("base_lateral_friction must be >= 0");
   return SOLO_OK;
 }
 
@@ -731,7 +772,9 @@ int solo_engine_destroy(SoloEngine* eng) {
   return SOLO_OK;
 }
 
-#define ENG_CALL(expr) (eng && eng->impl ? (eng->impl->expr) : (int)SOLO_ERR_INVALID_ARG)
+// (SOLO_ERR_INCOMPLETE is sticky: EVERY entry point that takes the engine checks the fault word first - ADVICE r5)
+static int eng_fault(SoloEngine* eng) { return eng && eng->impl ? eng->impl->check_fault() : (int)SOLO_ERR_INVALID_ARG; }
+#define ENG_CALL(expr) (eng_fault(eng) != SOLO_OK ? eng_fault(eng) : (eng->impl->expr))
 
 int solo_engine_set_program(SoloEngine* eng, const SoloProgram* prog) {
   if (!prog) return SOLO_ERR_INVALID_ARG;
@@ -764,6 +807,7 @@ int solo_engine_time_rollout(SoloEngine* eng, const void* a, int32_t k, uint32_t
   return ENG_CALL(time_rollout(a, k, flags, obs_out, reward_out, done_out, (hipStream_t)stream, ms));
 }
 int solo_engine_plan(SoloEngine* eng, int32_t k, SoloLaunchPlan* out) { return ENG_CALL(plan(k, out)); }
+int solo_engine_reserve(SoloEngine* eng, int32_t k, uint32_t flags) { return ENG_CALL(reserve(k, flags)); }
 const char* solo_engine_last_error(SoloEngine* eng) { return eng && eng->impl ? eng->impl->err.c_str() : "invalid engine handle"; }
 
 }  // extern "C"

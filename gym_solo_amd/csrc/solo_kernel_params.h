@@ -112,6 +112,9 @@ struct KParams {
   RowConst<T> row[64];
   ObsElemK<T> obs[SOLO_MAX_OBS];
   RewardInstrK<T> reward[SOLO_MAX_REWARD_OPS];
+  T mu_base;   // SoloConfig::base_lateral_friction: the friction rows of the BASE link's spheres (the robot's own coefficient -
+               // params[e][0] - is the legs').  Not part of StepConst: the f64 kernel's LDS is exactly eight allocation granules
+               // (10240 B) - the prologue parks it in s_keep[29] next to the robot's own coefficient.
 };
 
 // Workgroup -> robot map of a launch with no explicit order (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement":
@@ -256,6 +259,7 @@ inline void pack_params(const SoloConfig& c, const SoloModel& m, KParams<T>* k) 
   k->c.margin = (T)c.contact_margin;
   k->c.limit_margin = (T)c.joint_limit_margin;
   k->c.action_scale = (T)c.action_scale;
+  k->mu_base = (T)c.base_lateral_friction;
   k->c.iterations = c.solver_iterations;
   k->c.auto_reset = c.auto_reset;
   k->c.ulp_tol = c.solver_ulp_tolerance;

@@ -25,22 +25,39 @@ namespace solo {
 constexpr int kEventDone = 1, kEventRestart = 2;
 
 // Euler angles of pybullet.getEulerFromQuaternion ([recalled] pybullet.c; call sites
-// gym_solo/core/obs.py:271, rewards.py:233,265; known answer test_obs_observations.py:67-88)
+// gym_solo/core/obs.py:271, rewards.py:233,265; known answer test_obs_observations.py:67-88):
+//   |sarg| < 0.99999:  roll = atan2(2 (yz + wx), ww - xx - yy + zz), pitch = asin(sarg), yaw = atan2(2 (xy + wz), ww + xx - yy - zz)
+//   sarg <= -0.99999:  roll = 0, pitch = -pi/2, yaw = 2 atan2(x, -y);   sarg >= 0.99999:  roll = 0, pitch = pi/2, yaw = 2 atan2(-x, y)
+// Every angle is ONE atan2 and a fix-up - asin(s) = atan2(s, sqrt(1 - s^2)) - so that component `which` (0 roll, 1 pitch,
+// 2 yaw) can be a LANE's job: the in-place outputs of a single-step launch evaluate the three angles on three lanes with
+// one atan2 (round 6; one after the other they were three library calls at the end of every closed-loop f64 step), the
+// output epilogue (lane = step) calls it three times - the same function with the same arguments, so the two paths agree
+// bit for bit.
 template <typename T>
-__device__ __forceinline__ void euler_from_quat(T x, T y, T z, T w, T* roll, T* pitch, T* yaw) {
+__device__ __forceinline__ T euler_component(int which, T x, T y, T z, T w) {
   using R = Real<T>;
   const T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
   const T sarg = T(-2) * (x * z - w * y);
-  const T half_pi = R::half_pi();
-  if (sarg <= T(-0.99999)) {
-    *roll = T(0); *pitch = -half_pi; *yaw = T(2) * R::atan2(x, -y);
-  } else if (sarg >= T(0.99999)) {
-    *roll = T(0); *pitch = half_pi; *yaw = T(2) * R::atan2(-x, y);
-  } else {
-    *roll = R::atan2(T(2) * (y * z + w * x), squ - sqx - sqy + sqz);
-    *pitch = R::asin(sarg);
-    *yaw = R::atan2(T(2) * (x * y + w * z), squ + sqx - sqy - sqz);
+  const bool lo = sarg <= T(-0.99999), hi = sarg >= T(0.99999);
+  T ya, xa;
+  if (which == 0) { ya = T(2) * (y * z + w * x); xa = squ - sqx - sqy + sqz; }
+  else if (which == 1) { ya = sarg; xa = R::cos_of_asin(sarg); }
+  else {
+    ya = T(2) * (x * y + w * z); xa = squ + sqx - sqy - sqz;
+    if (lo) { ya = x; xa = -y; }
+    if (hi) { ya = -x; xa = y; }
   }
+  const T a = R::atan2(ya, xa);
+  const T half_pi = R::half_pi();
+  if (which == 0) return (lo || hi) ? T(0) : a;
+  if (which == 1) return lo ? -half_pi : (hi ? half_pi : a);
+  return (lo || hi) ? T(2) * a : a;
+}
+template <typename T>
+__device__ __forceinline__ void euler_from_quat(T x, T y, T z, T w, T* roll, T* pitch, T* yaw) {
+  *roll = euler_component<T>(0, x, y, z, w);
+  *pitch = euler_component<T>(1, x, y, z, w);
+  *yaw = euler_component<T>(2, x, y, z, w);
 }
 
 // gaussian tolerance, gym_solo/core/rewards.py:384-431 with margin_value = 0.1;
@@ -89,30 +106,51 @@ __device__ __forceinline__ void eval_observations(const KParams<T>* P, const T* 
 // val[i * stride]; LEAVES read the state, SCALE / ADD / MUL combine earlier values
 // (rewards.py:104-118: the weighted sum is compiled into the program).
 __device__ __forceinline__ bool reward_is_leaf(int op) { return op < SOLO_R_SCALE; }
+// One leaf of the reward program.  The four tolerance leaves differ only in WHAT they measure: every case prepares
+// (x or x^2, bounds, margin) and ONE sqrt and ONE tolerance() - the exp - follow for all of them.  In the in-place path of a
+// single-step launch lane i evaluates instruction i, so the leaf types of a program sit on different lanes of one wave: as
+// four cases with a tolerance() each they ran one after the other under EXEC masks (round 5: ~1.5 k cycles of a closed-loop
+// step's 8.8 k of outputs); in the output epilogue (lane = step: the instruction is the same on every lane) nothing changes.
+// Same arithmetic per leaf as before, bit for bit.
 template <typename T>
 __device__ __forceinline__ T reward_leaf(const RewardInstrK<T>& r, const T* rec, T roll, T pitch) {
   using R = Real<T>;
+  T x = T(0), lo = T(0), hi = T(0), margin = T(0), direct = T(0);
+  bool root = false, tol = true;
   switch (r.op) {
     case SOLO_R_UPRIGHT: {  // rewards.py:221-234: pitch relative to "fully upright" = -pi/2
       const T fu = T(-1.5707963267948966);
-      return fu * pitch / (fu * fu);
+      direct = fu * pitch / (fu * fu);
+      tol = false;
+      break;
     }
-    case SOLO_R_FLAT_TORSO:  // rewards.py:256-269
-      return tolerance<T>(R::sqrt(roll * roll + pitch * pitch), -r.a, r.a, r.b, r.d);
-    case SOLO_R_TORSO_HEIGHT:  // rewards.py:362-373
-      return tolerance<T>(rec[SOLO_S_POS + 2], r.a - r.b, r.a + r.b, r.c, r.d);
-    case SOLO_R_HORIZ_SPEED: {  // rewards.py:326-338
+    case SOLO_R_FLAT_TORSO:  // rewards.py:256-269: tolerance(sqrt(roll^2 + pitch^2), (-a, a), b)
+      x = roll * roll + pitch * pitch; root = true;
+      lo = -r.a; hi = r.a; margin = r.b;
+      break;
+    case SOLO_R_TORSO_HEIGHT:  // rewards.py:362-373: tolerance(z, (a - b, a + b), c)
+      x = rec[SOLO_S_POS + 2];
+      lo = r.a - r.b; hi = r.a + r.b; margin = r.c;
+      break;
+    case SOLO_R_HORIZ_SPEED: {  // rewards.py:326-338: tolerance(|v_xy|, (a - b, a + b), c)
       const T vx = rec[SOLO_S_LINVEL], vy = rec[SOLO_S_LINVEL + 1];
-      return tolerance<T>(R::sqrt(vx * vx + vy * vy), r.a - r.b, r.a + r.b, r.c, r.d);
+      x = vx * vx + vy * vy; root = true;
+      lo = r.a - r.b; hi = r.a + r.b; margin = r.c;
+      break;
     }
     case SOLO_R_SMALL_CONTROL: {  // rewards.py:290-301: mean |joint rate| over all 12 joints
       T sum = T(0);
       for (int j = 0; j < SOLO_NUM_DOF; ++j) sum += R::abs(rec[SOLO_S_QD + j]);
-      return tolerance<T>(sum / T(SOLO_NUM_JOINTS), T(0), T(0), r.a, r.d);
+      x = sum / T(SOLO_NUM_JOINTS);
+      margin = r.a;
+      break;
     }
-    case SOLO_R_CONST: return r.a;
-    default: return T(0);
+    case SOLO_R_CONST: direct = r.a; tol = false; break;
+    default: tol = false; break;
   }
+  if (!tol) return direct;
+  if (root) x = R::sqrt(x);
+  return tolerance<T>(x, lo, hi, margin, r.d);
 }
 template <typename T>
 __device__ __forceinline__ T reward_combine(const RewardInstrK<T>& r, const T* val, int stride) {

@@ -703,7 +703,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
       else if (type == ROW_NORMAL || is_limit) lam0 = R::max(lam0, T(0));
       const T wn1 = wave_lane_below<1>(lam0), wn2 = wave_lane_below<2>(lam0);  // (lane = row here: a contact's rows share a 16-lane row)
       if (type == ROW_TAN1 || type == ROW_TAN2) {
-        const T lim0 = mu * (type == ROW_TAN1 ? wn1 : wn2);
+        const T lim0 = (rc.body == BODY_BASE ? s_keep[29] : mu) * (type == ROW_TAN1 ? wn1 : wn2);   // (the base link keeps its own friction: see the solver)
         lam0 = R::clamp(lam0, -lim0, lim0);
       }
       if (!live) lam0 = T(0);
@@ -737,6 +737,10 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   T sv_lam0 = lam0;
   T sg[6], sh[2];
   int sv_leg = leg, n_live = 64;
+  // the row's friction coefficient is its SPHERE's: the base link's spheres keep SoloConfig::base_lateral_friction - the
+  // reference's changeDynamics loop sets lateralFriction for links 0 .. 11 only (solo8v2vanilla.py:157-163) -, the legs'
+  // the robot's own (params[e][0]).  Only the friction rows ever read it.
+  bool sv_on_base = rc.body == BODY_BASE;
   if constexpr (!kCompact) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) { s_rowvec[lane * kRS + i] = gh[i]; sg[i] = gh[i]; }
@@ -761,12 +765,13 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     s_rowvec[dst * kRS + 6] = hh[0];
     s_rowvec[dst * kRS + 7] = hh[1];
     s_rowleg[dst] = (unsigned char)leg;
-    const int tl = wave_push_int(sv_type | (leg << 4), dst);
+    const int tl = wave_push_int(sv_type | (leg << 4) | (sv_on_base ? 64 : 0), dst);
     sv_v0 = wave_push(sv_v0, dst);
     sv_nid = wave_push(sv_nid, dst);
     if constexpr (kResid) { sv_diag = wave_push(sv_diag, dst); if (warm_on) sv_lam0 = wave_push(sv_lam0, dst); }
     sv_type = tl & 15;
-    sv_leg = tl >> 4;
+    sv_leg = (tl >> 4) & 3;
+    sv_on_base = (tl & 64) != 0;
     wave_sync();
 #pragma unroll
     for (int i = 0; i < 6; ++i) sg[i] = s_rowvec[lane * kRS + i];
@@ -882,6 +887,7 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
   const bool is_tan1 = sv_type == ROW_TAN1, is_tangent = sv_type == ROW_TAN1 || sv_type == ROW_TAN2;
   const T imp = C.motor_impulse;
   if constexpr (sizeof(T) == 8) mu = s_keep[27];
+  mu = sv_on_base ? s_keep[29] : mu;   // (per lane from here on: the loops take it as a vector operand; s_keep[29]: SoloConfig::base_lateral_friction, parked by the prologue)
   T lo = T(0), hi = T(0);
   if (sv_motor) { lo = -imp; hi = imp; }
   else if (sv_normal || sv_limit) hi = R::big();
@@ -1292,6 +1298,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
   }
   const T mu = wave_cold_args(Bin)->params[(size_t)env * 4 + 0];
   const T mass_scale = wave_cold_args(Bin)->params[(size_t)env * 4 + 1];
+  const T mu_base = P0->mu_base;
   // issue priority (see physics_solve): a closed-loop step() is a launch of ONE step - it has no history
   // of its own, and its slowest robot, one that runs all the sweeps, decides how long the step takes.  A
   // robot's Gauss-Seidel cost is persistent, so such a launch starts from the sweep count of the robot's
@@ -1315,6 +1322,7 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
     // f64: the robot's friction coefficient and base-mass scale wait in LDS, not in two register pairs held across the
     // whole step loop (the f64 kernel lives on 168 VGPRs: see physics_solve, "PARK EARLY")
     if constexpr (sizeof(T) == 8) { if (lane0 == 0) { s_keep[27] = mu; s_keep[28] = mass_scale; } }
+    if (lane0 == 0) s_keep[29] = mu_base;   // (the base link's own friction coefficient: physics_solve)
   }
   int prio_sweeps = wave_uniform(hist_w);
   const int hist_sweeps = kMigrate ? 0 : prio_sweeps;
@@ -1454,8 +1462,10 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       // (lanes beyond a program load its entry 0 - one more address in an already issued load - and never use it)
       const ObsElemK<T> prog_obs = P0->obs[lane < n_obs ? lane : 0];
       const RewardInstrK<T> prog_reward = P0->reward[lane < n_rops ? lane : 0];
-      T roll, pitch, yaw;
-      euler_from_quat<T>(s_state[SOLO_S_QUAT], s_state[SOLO_S_QUAT + 1], s_state[SOLO_S_QUAT + 2], s_state[SOLO_S_QUAT + 3], &roll, &pitch, &yaw);
+      // the three Euler angles on three LANES, one atan2 for all of them (solo_outputs.h: euler_component - the function the
+      // output epilogue calls per angle, so the two paths agree bit for bit), broadcast to the wave
+      const T angle = euler_component<T>(lane < 3 ? lane : 0, s_state[SOLO_S_QUAT], s_state[SOLO_S_QUAT + 1], s_state[SOLO_S_QUAT + 2], s_state[SOLO_S_QUAT + 3]);
+      const T roll = wave_readlane(angle, 0), pitch = wave_readlane(angle, 1), yaw = wave_readlane(angle, 2);
       if (B.obs_inline != nullptr && lane < n_obs)
         B.obs_inline[(size_t)env * n_obs + lane] = observation_value<T>(prog_obs, s_state, roll, pitch, yaw);
       if (B.reward_inline != nullptr) {

@@ -480,7 +480,8 @@ template <> struct Real<float> {
     r = (x < 0.0f) ? 3.14159274f - r : r;
     return __builtin_copysignf(r, y);
   }
-  static __device__ __forceinline__ float asin(float x) { return atan2(x, __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(-x, x, 1.0f)))); }
+  static __device__ __forceinline__ float cos_of_asin(float x) { return __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(-x, x, 1.0f))); }   // sqrt(1 - x^2)
+  static __device__ __forceinline__ float asin(float x) { return atan2(x, cos_of_asin(x)); }
   // v_exp_f32 (2^x, 1 ulp) on a pre-scaled argument: the tolerance() rewards only need exp(-t^2/2), t^2/2 < 90
   static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
   static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
@@ -597,7 +598,9 @@ template <> struct Real<double> {
   // stores per lane at the top of a migrating kernel: 24 KB per wave, 1190 B of HBM writes per env-step of a 20-step
   // launch, measured).  Behind a call the constants live and die inside the callee.
   static __device__ __attribute__((noinline)) double atan2(double y, double x) { return ::atan2(y, x); }
-  static __device__ __attribute__((noinline)) double asin(double x) { return ::asin(x); }
+  // sqrt(1 - x^2) as sqrt((1 - x)(1 + x)): no cancellation near |x| = 1 (the Euler pitch: asin(x) = atan2(x, sqrt(1 - x^2)), solo_outputs.h)
+  static __device__ __forceinline__ double cos_of_asin(double x) { return sqrt((1.0 - x) * (1.0 + x)); }
+  static __device__ __forceinline__ double asin(double x) { return atan2(x, cos_of_asin(x)); }
   static __device__ __attribute__((noinline)) double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
   static __device__ __forceinline__ double min(double a, double b) { return ::fmin(a, b); }

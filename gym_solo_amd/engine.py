@@ -195,6 +195,12 @@ class Engine:
     self._check(self.lib.solo_engine_plan(self._handle(), int(num_steps), C.byref(p)), 'plan')
     return {name: int(getattr(p, name)) for name, _ in abi.SoloLaunchPlan._fields_}
 
+  def reserve(self, num_steps, flags=abi.STEP_ALL):
+    """Sizes the lazily grown scratch (the record scratch of fused launches, the migration queues) NOW for rollouts of up
+    to num_steps steps (solo_engine_reserve): the first rollout of a larger geometry otherwise synchronises the device and
+    re-allocates - not legal inside a HIP graph capture, and where an out-of-memory would surface mid-run."""
+    self._check(self.lib.solo_engine_reserve(self._handle(), int(num_steps), flags), 'reserve')
+
   def time_rollout(self, actions, flags=abi.STEP_ALL, out=None):
     """Mean ms per LAUNCH of one rollout of actions.shape[0] steps run exactly as rollout() runs it (plan()'s
     geometry; out = rollout_buffers(K): every step's outputs recorded, as a rollout collector's call does), measured with

@@ -36,12 +36,14 @@
 extern "C" {
 #endif
 
-#define SOLO_ABI_VERSION 5  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets
+#define SOLO_ABI_VERSION 6  /* 2: SOLO_STEP_AUTO_RESET; query-only launches never auto-reset; reset restores the motor targets
                                3: SoloConfig::solver_residual_threshold
                                4: SoloConfig::migrate_steps, SoloConfig::solver_warm_start, SoloStateView::warm
                                5: -1 = "the engine chooses" for steps_per_launch / rollout_streams / migrate_steps (the measured
                                   launch policy lives in the engine: solo_engine_plan reports it), solo_engine_time_rollout,
-                                  SOLO_ERR_INCOMPLETE */
+                                  SOLO_ERR_INCOMPLETE
+                               6: SoloConfig::base_lateral_friction (the base link keeps its own friction: the reference's
+                                  changeDynamics loop never reaches link -1), solo_engine_reserve */
 
 /* ---- fixed Solo8 dimensions -------------------------------------------- */
 #define SOLO_NUM_LEGS 4
@@ -81,8 +83,9 @@ typedef enum SoloStatus {
   SOLO_ERR_NO_DEVICE = -5,
   SOLO_ERR_INCOMPLETE = -6   /* a wave of an EARLIER launch with robot migration gave up waiting for its robot (a bounded
                                 wait that a correct queue never exhausts): some robots were not stepped through that
-                                launch.  Sticky: every later call on the handle returns it.  An internal error - never
-                                observed - surfaced instead of returned as SOLO_OK; the count is slot 6 of the statistics. */
+                                launch.  Sticky: every later call on the handle that takes the engine (everything but
+                                destroy, last_error and kernel_name) returns it.  An internal error - never observed -
+                                surfaced instead of returned as SOLO_OK; the count is slot 6 of the statistics. */
 } SoloStatus;
 
 typedef enum SoloDType { SOLO_F32 = 0, SOLO_F64 = 1 } SoloDType;
@@ -121,7 +124,9 @@ typedef struct SoloConfig {
   double motor_kd;           /* pybullet POSITION_CONTROL default velocityGain 1.0 [recalled] */
   double linear_damping;     /* configs.py:21 */
   double angular_damping;    /* configs.py:22 */
-  double lateral_friction;   /* configs.py:24 (x plane friction 1.0) */
+  double lateral_friction;   /* configs.py:24 (x plane friction 1.0): the collision spheres of links 0..11 - the legs.  The
+                                reference's changeDynamics loop runs over range(getNumJoints) (solo8v2vanilla.py:157-163) and so
+                                never reaches the base link (-1): see base_lateral_friction */
   double restitution;        /* configs.py:23, passed to changeDynamics for links 0..11 (solo8v2vanilla.py:158-163).  In [0, 1];
                                 WITHOUT EFFECT here, as in the reference: Bullet gives a contact the PRODUCT of its two bodies'
                                 restitutions ([recalled] btManifoldResult::calculateCombinedRestitution), and the ground the
@@ -179,6 +184,13 @@ typedef struct SoloConfig {
                                 0 = off (every step starts from zero impulses).  The cache - SoloStateView::warm, 64 reals
                                 per robot, the step kernel's lane layout - costs 2 x 64 reals of memory traffic per
                                 env-step, reported separately from the path's algorithmic bytes. */
+  double base_lateral_friction; /* friction of the BASE link's collision spheres (model spheres attached to body 0).  The
+                                reference sets lateralFriction with changeDynamics for links 0 .. 11 only
+                                (solo8v2vanilla.py:157-163: `for joint in range(joint_cnt)`), so the base keeps what loadURDF
+                                gave it: [recalled] pybullet's default 0.5 (x plane.urdf's 1.0).  Neither
+                                SoloConfig::lateral_friction nor solo_engine_set_params(0, ...) touches it: with the
+                                reference's 0.5 the two coincide, with any other leg friction (BASELINE configs[3]'s
+                                per-robot values) the belly keeps 0.5.  Host default 0.5; negative values are rejected. */
 } SoloConfig;
 
 /* ---- fused observation / reward / termination programs ------------------ */
@@ -371,6 +383,15 @@ typedef struct SoloLaunchPlan {
   int32_t resident_robots;   /* robots with a wave slot of their own on this device: waves_per_simd x SIMDs */
 } SoloLaunchPlan;
 int solo_engine_plan(SoloEngine* eng, int32_t num_steps, SoloLaunchPlan* out);
+/* LAZY SCRATCH.  The per-launch record scratch of fused launches ([N][steps_per_launch][32] reals: 0.5 GB for 8192 robots x
+ * 250 steps in f64) and the robot-migration queues are sized for the largest rollout geometry seen so far: the FIRST
+ * rollout / step / time_* call of a larger geometry synchronises the DEVICE, frees and re-allocates them (never shrinks) -
+ * the one hidden synchronisation of the otherwise stream-ordered calls, not legal inside a HIP stream capture, and the
+ * place where an out-of-memory surfaces (SOLO_ERR_HIP) after create.  solo_engine_reserve does that work NOW for rollouts
+ * of num_steps steps with these flags (and every shorter one under the same configuration): latency-sensitive or
+ * graph-capturing callers call it once after solo_engine_set_program; later calls within the reserved geometry allocate
+ * nothing and synchronise nothing.  Synchronises the device when it grows something. */
+int solo_engine_reserve(SoloEngine* eng, int32_t num_steps, uint32_t flags);
 /* Times ONE rollout of num_steps steps exactly as solo_engine_rollout_record runs it (solo_engine_plan's geometry; the
  * output buffers as there: NULL = that output is not recorded) with hipEvents recorded on the streams the kernels are
  * launched on; returns the mean milliseconds per LAUNCH over all slices and launches.  actions_dev: real [num_steps][N][12]. */

@@ -26,7 +26,8 @@
  *   stepSimulation()  solo8v2vanilla.py:91, fixedTimeStep=dt, numSubSteps=1
  *       solo8_base_env.py:39-41
  *   gravity configs.py:17, link damping configs.py:21-22 via changeDynamics
- *       solo8v2vanilla.py:158-163, friction configs.py:24, restitution configs.py:23 (never read: a contact's
+ *       solo8v2vanilla.py:158-163, friction configs.py:24 for links 0..11 - the loop at :157-163 never reaches the base
+ *       link (-1), whose spheres keep SoloConfig::base_lateral_friction -, restitution configs.py:23 (never read: a contact's
  *       restitution is the product of its bodies' - [recalled] btManifoldResult::calculateCombinedRestitution - and the
  *       ground, plane.urdf, has none)
  */
@@ -400,7 +401,9 @@ typedef struct {
   int leg[MAXROWS];        /* non-contact rows: the leg they belong to (solve order), else -1 */
   int key[MAXROWS];        /* the row's place in the 64-entry warm-start cache (SoloStateView::warm): the step kernel's
                               lane layout - motor / limit of dof j: 16 (j / 2) + (j & 1) (+ 14), sphere s row q: 16 (s / 4) + 2 + 3 (s % 4) + q */
-  double mu;
+  double mu[MAXROWS];      /* friction rows: the coefficient of their sphere - SoloConfig::base_lateral_friction for the
+                              base link's spheres, else the robot's lateral friction (params[0]): the reference's
+                              changeDynamics loop covers links 0..11 only, solo8v2vanilla.py:157-163 */
 } Rows;
 
 /* Jacobian row of direction d (world) at world point x attached to body b, in the
@@ -447,7 +450,7 @@ static void ground_at(const SoloTerrain* t, double x, double y, double* h, doubl
 static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const SoloTerrain* terrain, const Kin* k,
                        const double* st, const double ustar[NV], const double targets[ND],
                        double mu, Rows* R) {
-  R->n = 0; R->mu = mu;
+  R->n = 0;
   /* joint motors: velocity-level rows, [recalled] btMultiBodyJointMotor:
    *   v_target = kp*(q* - q)/dt + (1-kd)*qd,  |impulse| <= maxForce*dt */
   for (int j = 0; j < ND; ++j) {
@@ -502,6 +505,7 @@ static void build_rows(const SoloModel* mdl, const SoloConfig* cfg, const SoloTe
       int rt = R->n++;
       point_jacobian(mdl, k, b, x, td[q], R->J[rt]);
       R->rhs[rt] = 0; R->lo[rt] = 0; R->hi[rt] = 0; R->normal_row[rt] = rn; R->sphere[rt] = s; R->leg[rt] = -1;
+      R->mu[rt] = (b == 0) ? cfg->base_lateral_friction : mu;
       R->key[rt] = R->key[rn] + 1 + q;
     }
   }
@@ -578,7 +582,7 @@ int solo_oracle_step_env_warm(const SoloConfig* cfg, const SoloModel* mdl, const
       for (int r = 0; r < R.n; ++r) {
         if ((R.normal_row[r] >= 0) != (pass == 1)) continue;
         double lo = R.lo[r], hi = R.hi[r];
-        if (R.normal_row[r] >= 0) { hi = R.mu * lam[R.normal_row[r]]; lo = -hi; }
+        if (R.normal_row[r] >= 0) { hi = R.mu[r] * lam[R.normal_row[r]]; lo = -hi; }
         double l0 = cfg->solver_warm_start * warm[R.key[r]];
         if (l0 < lo) l0 = lo;
         if (l0 > hi) l0 = hi;
@@ -605,7 +609,7 @@ int solo_oracle_step_env_warm(const SoloConfig* cfg, const SoloModel* mdl, const
       double rel = 0;
       for (int i = 0; i < NV; ++i) rel += R.J[r][i] * up[i];
       double lo = R.lo[r], hi = R.hi[r];
-      if (R.normal_row[r] >= 0) { hi = R.mu * lam[R.normal_row[r]]; lo = -hi; }
+      if (R.normal_row[r] >= 0) { hi = R.mu[r] * lam[R.normal_row[r]]; lo = -hi; }
       double nl = lam[r] + (R.rhs[r] - rel) / diag[r];
       if (nl < lo) nl = lo;
       if (nl > hi) nl = hi;

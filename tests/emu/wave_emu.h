@@ -299,6 +299,7 @@ template <> struct Real<float> {
   static void sincos(float x, float* s, float* c, const float* = nullptr) { *s = std::sin(x); *c = std::cos(x); }
   static void sinc_cos(float x2, float* sinc, float* c, const float* = nullptr) { const float x = std::sqrt(x2); *c = std::cos(x); *sinc = x > 1e-12f ? std::sin(x) / x : 1.0f; }
   static float atan2(float y, float x) { return std::atan2(y, x); }
+  static float cos_of_asin(float x) { return std::sqrt(std::fmax(0.0f, std::fma(-x, x, 1.0f))); }
   static float asin(float x) { return std::asin(x); }
   static float exp(float x) { return std::exp(x); }
   static float abs(float x) { return std::fabs(x); }
@@ -320,6 +321,7 @@ template <> struct Real<double> {
   static void sincos(double x, double* s, double* c, const double* = nullptr) { *s = std::sin(x); *c = std::cos(x); }
   static void sinc_cos(double x2, double* sinc, double* c, const double* = nullptr) { const double x = std::sqrt(x2); *c = std::cos(x); *sinc = x > 1e-12 ? std::sin(x) / x : 1.0; }
   static double atan2(double y, double x) { return std::atan2(y, x); }
+  static double cos_of_asin(double x) { return std::sqrt((1.0 - x) * (1.0 + x)); }
   static double asin(double x) { return std::asin(x); }
   static double exp(double x) { return std::exp(x); }
   static double abs(double x) { return std::fabs(x); }

@@ -76,3 +76,29 @@ def test_two_rank_bench_end_to_end_on_the_emulator():
   assert d['episodes']['episodes'] > 0                      # both ranks' episodes went through the all-reduce
   assert d['timing']['stats_reduction_inside_timed_region'] is True
   assert "init_process_group('gloo') ok: world_size 2" in r.stderr and 'final barrier ok' in r.stderr
+
+
+def test_a_rank_that_dies_after_init_process_group_stops_the_others():
+  """the launcher's kill path was exercised only for EARLY failures.  Here both ranks rendezvous and initialise
+  the process group (gloo), do one collective - and then rank 1 exits non-zero while rank 0 is inside the next barrier, which
+  would otherwise wait for its timeout: the launcher sees the dead rank, stops rank 0 and reports the failing rank's status."""
+  import time
+  import pytest
+  sys.path.insert(0, ROOT)
+  import bench
+  child = [sys.executable, '-c',
+           'import os, sys, time, datetime\n'
+           'import torch, torch.distributed as dist\n'
+           'r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])\n'
+           'dist.init_process_group("gloo", rank=r, world_size=w, timeout=datetime.timedelta(seconds=600))\n'
+           't = torch.ones(1); dist.all_reduce(t); assert t.item() == w\n'
+           'print("rank %d initialised" % r, flush=True)\n'
+           'if r == 1:\n'
+           '  time.sleep(1); os._exit(7)\n'
+           'dist.barrier()\n'          # rank 0: waits for a peer that is gone
+           'time.sleep(300)\n']
+  t0 = time.time()
+  with pytest.raises(SystemExit) as e:
+    bench.launch_ranks(2, child_cmd=child)
+  assert time.time() - t0 < 90
+  assert e.value.code == 7 or e.value.code not in (0, None)

@@ -391,3 +391,87 @@ def test_workgroup_to_robot_map_is_a_bijection_with_contiguous_ranges_per_xcd():
     for x in range(min(8, count)):
       mine = got[x::8]
       assert mine == list(range(mine[0], mine[0] + len(mine))), (count, x)
+
+
+# ---- closed forms of the constraint rows on the PRODUCT KERNEL SOURCE (CPU emulator; tests/closed_form_cases.py - the GPU runs
+#      them at 4096 robots in tests/test_gpu_closed_forms.py, the oracle in tests/test_oracle_physics.py) -----------------------
+def _kin(ca, ma):
+  from oracle import solo_oracle as so
+  ph = so.OraclePhysics(ca, ma)
+  return ph, (lambda s: ph.momentum(np.ascontiguousarray(s))[0])
+
+
+def test_closed_form_coulomb_incline_on_the_kernel_source():
+  import closed_form_cases as cf
+  from helpers import incline_terrain
+  from gym_solo_amd.model import Solo8Model
+  ca, ma = make_abi('float64', linear_damping=0.0, angular_damping=0.0)
+  n = 6
+  e = EmuEngine(ca, ma, n, terrain=incline_terrain(10.0))
+  _, mom = _kin(ca, ma)
+  mus = cf.incline_frictions(n, seed=5)
+  e.params[:, 0] = mus
+  e.state[:] = cf.standing_on_incline(n)
+  zero = np.zeros((n, 12))
+  slides = mus < np.tan(cf.THETA)
+  e.rollout(np.zeros((250, n, 12)), abi.STEP_PHYSICS)
+  for k in range(3):
+    pre = e.state.copy()
+    e.step(zero, abi.STEP_PHYSICS)
+    for i in range(n):
+      got, want = cf.check_coulomb_step(mom, pre[i], e.state[i], mus[i], ca.dt)
+      if slides[i]:
+        assert mom(e.state[i]) @ cf.T1_SLOPE < -0.05
+        assert abs(got - want) < 1e-11 * abs(want), (i, got, want)
+      else:
+        assert abs(got) < 1e-7, (i, got)
+
+
+def test_closed_form_motor_clamp_and_push_out_on_the_kernel_source():
+  import closed_form_cases as cf
+  ca, ma = make_abi('float64', gravity=(0., 0., 0.), linear_damping=0.0, angular_damping=0.0)
+  n = 24
+  ph, _ = _kin(ca, ma)
+  st, acts, far, sign = cf.floating_at_rest(n)
+  e = EmuEngine(ca, ma, n)
+  e.state[:] = st
+  e.step(acts, abi.STEP_PHYSICS)
+  for i in range(n):
+    M = np.array(ph.step_debug(st[i].copy(), np.zeros(8)).M).reshape(abi.NV, abi.NV)
+    base, sat, hold, _, _ = cf.check_motor_clamp(M, st[i], e.state[i], far[i], sign[i], ca.motor_torque_limit * ca.dt)
+    assert max(base, sat, hold) < 1e-14, (i, base, sat, hold)
+  ca, ma = make_abi('float64')
+  st, acts, d, centres, radius = cf.belly_corner_penetrating(n)
+  e = EmuEngine(ca, ma, n)
+  e.state[:] = st
+  e.step(acts, abi.STEP_PHYSICS)
+  v = np.array([cf.contact_point_velocity(e.state[i], st[i], centres[i], radius) for i in range(n)])
+  np.testing.assert_allclose(v[:, 2], ca.contact_erp * d / ca.dt, rtol=0, atol=1e-11)
+  assert np.abs(v[:, :2]).max() < 1e-11
+
+
+@pytest.mark.parametrize('leg_mu,base_mu,slides', [(0.1, 0.5, False), (0.9, 0.1, True)])
+def test_base_link_friction_on_the_kernel_source(leg_mu, base_mu, slides):
+  """the base link's spheres keep SoloConfig::base_lateral_friction (solo8v2vanilla.py:157-163 never reaches link -1): per-lane
+  friction coefficient in the slot-space solver (f64) and in lane = row (f32) - both against the oracle, f64 against Coulomb"""
+  import closed_form_cases as cf
+  from helpers import incline_terrain
+  from oracle import solo_oracle as so
+  for dtype, tol in (('float64', 1e-9), ('float32', 2e-3)):
+    ca, ma = make_abi(dtype, lateral_friction=leg_mu, base_lateral_friction=base_mu, linear_damping=0.0, angular_damping=0.0)
+    terr = incline_terrain(10.0)
+    e = EmuEngine(ca, ma, 2, terrain=terr)
+    ph = so.OraclePhysics(ca, ma, terrain=terr)
+    mom = lambda s: ph.momentum(np.ascontiguousarray(s))[0]
+    st, acts = cf.belly_on_incline(2)
+    e.state[:] = st
+    ref = st.copy()
+    for k in range(120):
+      pre = e.state.copy()
+      e.step(acts, abi.STEP_PHYSICS)
+      ph.step(ref, acts)
+    np.testing.assert_allclose(e.state[:, :29], ref[:, :29], rtol=0, atol=tol)
+    if dtype == 'float64':
+      got, want = cf.check_coulomb_step(mom, pre[0], e.state[0], base_mu, ca.dt)
+      assert (abs(got - want) < 1e-11 * abs(want)) if slides else (abs(got) < 1e-10)
+      assert (mom(e.state[0]) @ cf.T1_SLOPE < -0.05) == slides

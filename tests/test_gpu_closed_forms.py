@@ -101,3 +101,137 @@ def test_motor_impulses_are_internal_at_benchmark_scale():
     worst = np.maximum(worst, [np.abs(mom[0][0] - mom[1][0]).max(), np.abs(mom[0][1] - mom[1][1]).max()])
   assert worst[0] < 1e-12 and worst[1] < 1e-12, worst
   on.close(); off.close()
+
+
+# ---- closed forms of the CONSTRAINT rows (round 6; tests/closed_form_cases.py: the same checkers hold the CPU oracle in
+#      tests/test_oracle_physics.py).  Friction, the motor clamp and the penetration push-out on the HIP engine at 4096 robots:
+#      Newton's and Coulomb's laws and the model's masses are the reference here, not the oracle's step. -------------------------
+def _put(eng, st):
+  import torch
+  eng.state.copy_(torch.as_tensor(st, device='cuda'))
+
+
+def _momentum_fn(ca, ma):
+  from oracle import solo_oracle as so
+  ph = so.OraclePhysics(ca, ma)
+  return ph, (lambda s: ph.momentum(np.ascontiguousarray(s))[0])
+
+
+def test_coulomb_friction_on_the_incline_at_benchmark_scale():
+  """4096 robots standing on BASELINE configs[4]'s 10-degree incline, per-robot friction as in configs[3] (set_params).
+  mu > tan(theta): the centre of mass comes to rest.  mu < tan(theta): on every checked step of the slide the external impulse
+  along t1 - mu n is - m g dt (sin theta - mu cos theta) to rounding, and the slide is a rigid translation with
+  a = g (sin theta - mu cos theta)."""
+  import torch
+  import closed_form_cases as cf
+  from helpers import incline_terrain
+  from gym_solo_amd.model import Solo8Model
+  eng, ca, ma = _engine(N, linear_damping=0.0, angular_damping=0.0, settle_steps=10)
+  eng.set_terrain(incline_terrain(10.0))
+  _, mom = _momentum_fn(ca, ma)
+  mus = cf.incline_frictions(N, seed=3)
+  eng.set_params(abi.PARAM_FRICTION, torch.as_tensor(mus, device='cuda'))
+  _put(eng, cf.standing_on_incline(N))
+  m = Solo8Model().total_mass
+  slides = mus < np.tan(cf.THETA)
+  zero = torch.zeros(N, 12, device='cuda', dtype=torch.float64)
+  done, vel = 0, {}
+  worst_slide = worst_stick = 0.0
+  for upto in (150, 200, 275, 399):
+    eng.rollout(zero.expand(upto - done, N, 12).contiguous(), abi.STEP_PHYSICS)   # one fused launch up to the checked step
+    pre = eng.state.cpu().numpy().copy()
+    eng.step(zero, abi.STEP_PHYSICS)                                            # the checked step: a launch of its own
+    post = eng.state.cpu().numpy().copy()
+    done = upto + 1
+    for i in range(N):
+      got, want = cf.check_coulomb_step(mom, pre[i], post[i], mus[i], ca.dt)
+      if slides[i]:
+        worst_slide = max(worst_slide, abs(got - want) / abs(want))
+      else:
+        worst_stick = max(worst_stick, abs(got))
+    vel[done] = np.array([mom(post[i]) / m for i in range(N)])
+  assert worst_slide < 1e-11, worst_slide
+  assert worst_stick < 1e-7, worst_stick
+  # "at rest": the landing's transient is still decaying (2e-6 m/s measured at worst among 2048 robots; the reference's own rest
+  # test - test_solo8v2vanilla.py:77-104, 6 decimals over 10 steps - allows 1.5e-4 m/s)
+  assert np.abs(vel[400][~slides]).max() < 1e-5
+  a = 9.81 * (np.sin(cf.THETA) - mus[slides] * np.cos(cf.THETA))
+  assert (vel[400][slides] @ cf.T1_SLOPE).max() < -0.05
+  np.testing.assert_allclose(-((vel[400] - vel[201])[slides] @ cf.T1_SLOPE), a * 199 * ca.dt, rtol=1e-6)
+  assert eng.stats.cpu().numpy()[5] == 0
+  eng.close()
+
+
+def test_saturated_motor_rows_at_benchmark_scale():
+  """4096 robots at rest afloat, no gravity: M(q) du of ONE step is 0 on the base rows, + limit dt on every motor row whose
+  target is out of reach (gym_solo/envs/solo8v2vanilla.py:87-90: forces = motor_torque_limit, configs.py:12), and a row that only
+  holds its joint either ends at rest or sits at its bound against the motion.  M(q): the oracle's CRBA (kinematics)."""
+  import torch
+  import closed_form_cases as cf
+  eng, ca, ma = _engine(N, gravity=(0., 0., 0.), linear_damping=0.0, angular_damping=0.0, settle_steps=1)
+  ph, _ = _momentum_fn(ca, ma)
+  st, acts, far, sign = cf.floating_at_rest(N)
+  _put(eng, st)
+  eng.step(torch.as_tensor(acts, device='cuda'), abi.STEP_PHYSICS)
+  post = eng.state.cpu().numpy()
+  limit_dt = ca.motor_torque_limit * ca.dt
+  worst = np.zeros(3)
+  held = stopped = 0
+  for i in range(N):
+    M = np.array(ph.step_debug(st[i].copy(), np.zeros(8)).M).reshape(abi.NV, abi.NV)
+    base, sat, hold, nh, ns = cf.check_motor_clamp(M, st[i], post[i], far[i], sign[i], limit_dt)
+    worst = np.maximum(worst, [base, sat, hold])
+    held += nh; stopped += ns
+  assert worst.max() < 1e-14, worst       # (impulse units: the bound itself is 2e-3)
+  assert held > 1000 and stopped > 1000
+  eng.close()
+
+
+def test_penetration_push_out_at_benchmark_scale():
+  """4096 robots at rest, one base sphere each 0.05 ... 2 mm inside the flat ground: after ONE step the contact point moves out
+  at contact_erp d / dt, without tangential velocity."""
+  import torch
+  import closed_form_cases as cf
+  eng, ca, ma = _engine(N, settle_steps=1)
+  st, acts, d, centres, radius = cf.belly_corner_penetrating(N)
+  _put(eng, st)
+  eng.step(torch.as_tensor(acts, device='cuda'), abi.STEP_PHYSICS)
+  post = eng.state.cpu().numpy()
+  v = np.array([cf.contact_point_velocity(post[i], st[i], centres[i], radius) for i in range(N)])
+  np.testing.assert_allclose(v[:, 2], ca.contact_erp * d / ca.dt, rtol=0, atol=1e-11)
+  assert np.abs(v[:, :2]).max() < 1e-11
+  eng.close()
+
+
+@pytest.mark.parametrize('leg_mu,base_mu,slides', [(0.1, 0.5, False), (0.1, 0.1, True), (0.9, 0.1, True)])
+def test_the_base_link_keeps_its_own_friction_gpu(leg_mu, base_mu, slides):
+  """The reference's changeDynamics loop covers links 0 .. 11 (solo8v2vanilla.py:157-163): the base link keeps its own
+  friction.  512 robots lying on their bellies on the incline, leg friction per robot through set_params as well: what decides
+  is base_lateral_friction - 0.5 holds where lateral_friction = 0.1 would slide, and a slippery belly slides by Coulomb's
+  closed form whatever the legs' coefficient."""
+  import torch
+  import closed_form_cases as cf
+  from helpers import incline_terrain
+  from gym_solo_amd.model import Solo8Model
+  n = 512
+  eng, ca, ma = _engine(n, lateral_friction=leg_mu, base_lateral_friction=base_mu, linear_damping=0.0, angular_damping=0.0, settle_steps=10)
+  eng.set_terrain(incline_terrain(10.0))
+  eng.set_params(abi.PARAM_FRICTION, torch.full((n,), leg_mu, device='cuda', dtype=torch.float64))   # (must not reach the belly)
+  _, mom = _momentum_fn(ca, ma)
+  st, acts = cf.belly_on_incline(n)
+  _put(eng, st)
+  a = torch.as_tensor(acts, device='cuda')
+  eng.rollout(a.expand(299, n, 12).contiguous(), abi.STEP_PHYSICS)
+  pre = eng.state.cpu().numpy().copy()
+  eng.step(a, abi.STEP_PHYSICS)
+  post = eng.state.cpu().numpy()
+  m = Solo8Model().total_mass
+  for i in range(0, n, 37):
+    v = mom(post[i]) / m
+    got, want = cf.check_coulomb_step(mom, pre[i], post[i], base_mu, ca.dt)
+    if slides:
+      assert v @ cf.T1_SLOPE < -0.1
+      assert abs(got - want) < 1e-11 * abs(want)
+    else:
+      assert np.abs(v).max() < 1e-9 and abs(got) < 1e-11
+  eng.close()

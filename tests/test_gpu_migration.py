@@ -177,3 +177,52 @@ def test_scratch_and_queues_grow_with_the_rollouts():
   assert forced.engine.stats.cpu().numpy()[6] == 0
   for e in (auto, forced, plain):
     e._close()
+
+
+@pytest.mark.parametrize('streams', [1, 2])
+def test_ragged_last_launch_needs_more_chunks_than_the_full_ones(streams):
+  """the chunk count of a migrating launch is NOT monotone in its step count - a launch of 128 steps with
+  migrate_steps = 1 is cut into 64 chunks of 2 (a ring slot has 7 bits for the chunk index), its 65-step ragged tail into 65
+  chunks of 1.  Queue regions sized and strided for the full launch's count were overrun by such a tail (beyond 1792 robots:
+  past the allocation; with two slices: into the next slice's header).  Now every launch of up to S steps fits its region
+  (queue_slots_per_robot): 193 steps at 2048 robots, against the plainest geometry, bit for bit."""
+  import torch
+  n, k = 2048, 193
+  mig = _env(n, 'float64', 128, streams, 1, 17)
+  plain = _env(n, 'float64', 1, 1, 0, 17)
+  assert mig.engine.plan(k)['migrate_steps'] == 2 and mig.engine.plan(k)['launches'] == 2
+  g = torch.Generator(device='cuda').manual_seed(77)
+  phase = torch.randint(0, 17, (n,), device='cuda', generator=g, dtype=torch.int32)
+  for e in (mig, plain):
+    e.engine.term_count[:, 0] = phase
+  acts = (torch.rand(k, n, 12, device='cuda', dtype=torch.float64, generator=g) * 2 - 1) * 6.2831853
+  want = plain.engine.rollout(acts, abi.STEP_ALL, record=True)
+  got = mig.engine.rollout(acts, abi.STEP_ALL, record=True)
+  torch.cuda.synchronize()
+  for x, y in zip(want, got):
+    assert torch.equal(x, y)
+  assert torch.equal(plain.engine.state, mig.engine.state) and torch.equal(plain.engine.term_count, mig.engine.term_count)
+  assert mig.engine.stats.cpu().numpy()[6] == 0
+  mig._close(); plain._close()
+
+
+def test_reserve_sizes_the_scratch_ahead_of_time():
+  """solo_engine_reserve (ABI 6): the lazily grown record scratch / migration queues are sized NOW for rollouts of up to K steps -
+  the first long rollout then allocates nothing (the buffers a 300-step rollout uses are the ones reserve() left: same pointers
+  are not visible through the ABI, so the observable is that results equal the plain engine's and a second reserve is a no-op)."""
+  import torch
+  n = 512
+  e = _env(n, 'float64', -1, -1, 3, 17)
+  plain = _env(n, 'float64', 1, 1, 0, 17)
+  e.engine.reserve(300)
+  e.engine.reserve(300)
+  with pytest.raises(ValueError):
+    e.engine.reserve(0)
+  g = torch.Generator(device='cuda').manual_seed(5)
+  acts = (torch.rand(300, n, 12, device='cuda', dtype=torch.float64, generator=g) * 2 - 1) * 6.2831853
+  want = plain.engine.rollout(acts, abi.STEP_ALL, record=True)
+  got = e.engine.rollout(acts, abi.STEP_ALL, record=True)
+  torch.cuda.synchronize()
+  for x, y in zip(want, got):
+    assert torch.equal(x, y)
+  e._close(); plain._close()

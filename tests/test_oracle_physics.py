@@ -211,3 +211,113 @@ def test_passive_rest_pose_reproduces_the_reference_vector():
   np.testing.assert_allclose(np.abs(q[0::2]), np.pi / 2, atol=1e-6)
   np.testing.assert_allclose(np.abs(q[1::2]), np.pi, atol=1e-6)
   assert np.all(np.sign(q) == np.sign([1, 1, 1, 1, -1, -1, -1, -1]))
+
+
+# ---- closed forms of the CONSTRAINT rows (round 6; tests/closed_form_cases.py): what a friction row, a saturated motor row and
+#      the penetration push-out must do whatever the solver's inner workings - the same checkers hold the HIP engine at 4096
+#      robots (tests/test_gpu_closed_forms.py) ----------------------------------------------------------------------------------
+def test_coulomb_friction_on_the_incline():
+  """Robots standing on the 10-degree incline with per-robot friction (gym_solo/core/configs.py:24 is the reference's one
+  global value).  mu > tan(theta): the centre of mass comes to rest and stays.  mu < tan(theta), every foot sliding down: the
+  step's external impulse along t1 - mu n is gravity's alone, - m g dt (sin theta - mu cos theta), however the normal load is
+  shared between the feet - to rounding, on every step of the slide."""
+  import closed_form_cases as cf
+  from helpers import make_abi, incline_terrain
+  ca, ma = make_abi('float64', linear_damping=0.0, angular_damping=0.0)
+  ph = so.OraclePhysics(ca, ma, terrain=incline_terrain(10.0))
+  n = 16
+  mus = cf.incline_frictions(n)
+  params = ph.default_params(n)
+  params[:, 0] = mus
+  st = cf.standing_on_incline(n)
+  mom = lambda s: ph.momentum(np.ascontiguousarray(s))[0]
+  m = Solo8Model().total_mass
+  zero = np.zeros((n, 12))
+  slides = mus < np.tan(cf.THETA)
+  assert slides.sum() == n // 2
+  for k in range(400):
+    pre = st.copy()
+    ph.step(st, zero, params, threads=4)
+    if k == 199:
+      v200 = np.array([mom(st[i]) / m for i in range(n)])
+    if k >= 100 and k % 25 == 0:
+      for i in range(n):
+        got, want = cf.check_coulomb_step(mom, pre[i], st[i], mus[i], ca.dt)
+        if slides[i]:
+          assert mom(st[i]) @ cf.T1_SLOPE / m < -0.01          # it does slide, down the slope
+          assert abs(got - want) < 1e-12 * abs(want) + 1e-15, (k, i, got, want)
+        else:
+          assert abs(got) < (1e-7 if k < 350 else 1e-9), (k, i, got)   # no net impulse: friction holds m g sin(theta) dt = 3e-3 (the landing's transient decays)
+  v = np.array([mom(st[i]) / m for i in range(n)])
+  assert np.abs(v[~slides]).max() < 1e-6, np.abs(v[~slides]).max()
+  # the slide as a whole (once the feet have landed): rigid translation with a = g (sin theta - mu cos theta)
+  a = 9.81 * (np.sin(cf.THETA) - mus[slides] * np.cos(cf.THETA))
+  np.testing.assert_allclose(-((v - v200)[slides] @ cf.T1_SLOPE), a * 200 * ca.dt, rtol=1e-6)
+
+
+def test_saturated_motor_rows_give_exactly_their_impulse_bound():
+  """POSITION_CONTROL with forces = motor_torque_limit (gym_solo/envs/solo8v2vanilla.py:87-90, configs.py:12): no gravity, no
+  contact, robots at rest in random poses.  M(q) du is the generalised impulse of the step: zero on the six base rows (motor
+  impulses are internal), + limit dt on every row whose target is out of reach, and on a row that only has to hold its joint
+  either the joint ends at rest or the row sits at its bound against the motion."""
+  import closed_form_cases as cf
+  from helpers import make_abi
+  ca, ma = make_abi('float64', gravity=(0., 0., 0.), linear_damping=0.0, angular_damping=0.0)
+  ph = so.OraclePhysics(ca, ma)
+  n = 64
+  st, acts, far, sign = cf.floating_at_rest(n)
+  pre = st.copy()
+  ph.step(st, acts)
+  limit_dt = ca.motor_torque_limit * ca.dt
+  held = stopped = 0
+  for i in range(n):
+    M = np.array(ph.step_debug(pre[i].copy(), np.zeros(8)).M).reshape(abi.NV, abi.NV)
+    base, sat, hold, nh, ns = cf.check_motor_clamp(M, pre[i], st[i], far[i], sign[i], limit_dt)
+    assert base < 1e-15 and sat < 1e-15 and hold < 1e-15, (i, base, sat, hold)
+    held += nh; stopped += ns
+  assert held > 20 and stopped > 20   # both branches of the holding rows occur
+
+
+def test_penetration_is_pushed_out_at_erp_times_depth_over_dt():
+  """One base sphere penetrating the ground by d, the robot at rest: the contact point leaves with normal velocity
+  contact_erp d / dt after one step (the push-out Bullet calls erp; SoloConfig::contact_erp) and without tangential velocity
+  (the friction rows hold it: the belly's friction is the base link's own 0.5)."""
+  import closed_form_cases as cf
+  from helpers import make_abi
+  ca, ma = make_abi('float64')
+  ph = so.OraclePhysics(ca, ma)
+  n = 32
+  st, acts, d, centres, radius = cf.belly_corner_penetrating(n)
+  for i in range(n):   # exactly one sphere within the contact margin
+    z = ph.sphere_centers(st[i].copy())[:, 2] - np.array(list(ma.sphere_radius))
+    assert (z < ca.contact_margin).sum() == 1 and abs(z.min() + d[i]) < 1e-15
+  pre = st.copy()
+  ph.step(st, acts)
+  for i in range(n):
+    v = cf.contact_point_velocity(st[i], pre[i], centres[i], radius)
+    assert abs(v[2] - ca.contact_erp * d[i] / ca.dt) < 1e-11, (i, v[2], ca.contact_erp * d[i] / ca.dt)
+    assert np.abs(v[:2]).max() < 1e-11
+
+
+@pytest.mark.parametrize('leg_mu,base_mu,slides', [(0.1, 0.5, False), (0.1, 0.1, True), (0.9, 0.1, True)])
+def test_the_base_link_keeps_its_own_friction(leg_mu, base_mu, slides):
+  """gym_solo sets lateralFriction for links 0 .. 11 only - `for joint in range(joint_cnt)`, solo8v2vanilla.py:157-163 - so the
+  base link keeps its own coefficient ([recalled] pybullet's default 0.5).  A robot lying on its belly (only BASE spheres touch)
+  on the 10-degree incline: with lateral_friction = 0.1 < tan(theta) it still stays, because the belly has 0.5; it is
+  base_lateral_friction that decides, and when that is below tan(theta) the slide obeys Coulomb's closed form with it."""
+  import closed_form_cases as cf
+  from helpers import make_abi, incline_terrain
+  ca, ma = make_abi('float64', lateral_friction=leg_mu, base_lateral_friction=base_mu, linear_damping=0.0, angular_damping=0.0)
+  ph = so.OraclePhysics(ca, ma, terrain=incline_terrain(10.0))
+  st, acts = cf.belly_on_incline(2)
+  mom = lambda s: ph.momentum(np.ascontiguousarray(s))[0]
+  for k in range(300):
+    pre = st.copy()
+    ph.step(st, acts)
+  v = mom(st[0]) / Solo8Model().total_mass
+  got, want = cf.check_coulomb_step(mom, pre[0], st[0], base_mu, ca.dt)
+  if slides:
+    assert v @ cf.T1_SLOPE < -0.1
+    assert abs(got - want) < 1e-12 * abs(want) + 1e-15
+  else:
+    assert np.abs(v).max() < 1e-9 and abs(got) < 1e-12

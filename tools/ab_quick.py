@@ -4,7 +4,8 @@ libraries alternate, REPS rounds:
 
   gpurun -- python tools/ab_quick.py [--reps 3] [--dtype float64] [--legs k20,closed,s250] [--n 4096] libA.so libB.so ...
 
-(library names are files under gym_solo_amd/csrc; a name may carry settings: libX.so:migrate=0:streams=2:spl=250:n=8192;
+(library names are files under gym_solo_amd/csrc - `@TREE/libX.so`: under TREE/gym_solo_amd/csrc, with TREE's python package:
+another commit's sources unpacked under the repo root -; a name may carry settings: libX.so:migrate=0:streams=2:spl=250:n=8192;
 what is not given is the engine's choice).  Legs: k20 = the driver's geometry (a rollout of 20 steps), closed = one
 solo_engine_step launch per env step (20 steps), s250 = a rollout of 1000 steps (fused launches of 250).
 Prints env-steps/s by wall clock (median of the repeats, barrier + device sync on both sides as bench.py does) and the
@@ -81,9 +82,15 @@ def main():
       for p in parts[1:]:
         key, val = p.split('=')
         spec[key] = val if key == 'dtype' else int(val)
-      env = dict(os.environ, SOLO_HIP_LIB=os.path.join(ROOT, 'gym_solo_amd', 'csrc', parts[0]), SOLO_AB_CHILD=json.dumps(spec))
+      # (`@TREE/libX.so`: the library AND the python package of another source tree under the repo root - e.g. a `git archive`
+      # of an earlier commit with another ABI version; the child is that tree's own copy of this script)
+      tree = ROOT
+      if parts[0].startswith('@'):
+        sub, parts[0] = parts[0][1:].split('/', 1)
+        tree = os.path.join(ROOT, sub)
+      env = dict(os.environ, SOLO_HIP_LIB=os.path.join(tree, 'gym_solo_amd', 'csrc', parts[0]), SOLO_AB_CHILD=json.dumps(spec))
       try:
-        res = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+        res = subprocess.run([sys.executable, os.path.join(tree, 'tools', 'ab_quick.py')], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
       except subprocess.TimeoutExpired:
         print('%s: TIMEOUT' % name, flush=True)
         raise SystemExit(1)  # (a hung GPU step: no further GPU step in this call)

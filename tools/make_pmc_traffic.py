@@ -55,6 +55,9 @@ out = {key: {
                                        ('active_inst_any', 'SQ_ACTIVE_INST_ANY'), ('active_inst_valu', 'SQ_ACTIVE_INST_VALU'),
                                        ('active_inst_sca', 'SQ_ACTIVE_INST_SCA'), ('active_inst_lds', 'SQ_ACTIVE_INST_LDS'),
                                        ('wait_inst_lds', 'SQ_WAIT_INST_LDS')) if c in s},
+  # the SIMDs' VALU busy share over the launch, MEASURED: SQ_ACTIVE_INST_VALU (quad-cycles, summed over the waves) x 4 /
+  # (1024 SIMDs x the launch's cycles = GRBM_GUI_ACTIVE / 8 XCDs) - bench.py's roofline.secondary.frac
+  'valu_busy_share_measured': (s['SQ_ACTIVE_INST_VALU'] * 4.0 / (1024 * s['GRBM_GUI_ACTIVE'] / 8.0)) if ('SQ_ACTIVE_INST_VALU' in s and s.get('GRBM_GUI_ACTIVE')) else None,
   'step_kernel_busy_cycles': s.get('SQ_BUSY_CYCLES'), 'step_kernel_wave_cycles': wave_cycles, 'step_kernel_waves': s.get('SQ_WAVES'),
   'grbm_gui_active_per_launch': s.get('GRBM_GUI_ACTIVE'),
   # MI355X_MICROARCH.md (DVFS): effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time (same pass)
