@@ -36,14 +36,17 @@ constexpr int kEventDone = 1, kEventRestart = 2;
 template <typename T>
 __device__ __forceinline__ T euler_component(int which, T x, T y, T z, T w) {
   using R = Real<T>;
-  const T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
-  const T sarg = T(-2) * (x * z - w * y);
+  // (EXPLICIT fused multiply-adds: this function is inlined with `which` a constant (the epilogue) and with `which` a lane's
+  // number (the in-place outputs) - left to -ffp-contract the two copies were contracted differently and a fused rollout's
+  // observations differed from single steps' in the last bit)
+  const T sarg = T(-2) * R::fma(x, z, -(w * y));
   const bool lo = sarg <= T(-0.99999), hi = sarg >= T(0.99999);
+  const T ww_zz = R::fma(w, w, z * z), xx_yy = R::fma(x, x, y * y), ww_xx = R::fma(w, w, x * x), yy_zz = R::fma(y, y, z * z);
   T ya, xa;
-  if (which == 0) { ya = T(2) * (y * z + w * x); xa = squ - sqx - sqy + sqz; }
+  if (which == 0) { ya = T(2) * R::fma(y, z, w * x); xa = ww_zz - xx_yy; }      // (ww - xx - yy + zz)
   else if (which == 1) { ya = sarg; xa = R::cos_of_asin(sarg); }
   else {
-    ya = T(2) * (x * y + w * z); xa = squ + sqx - sqy - sqz;
+    ya = T(2) * R::fma(x, y, w * z); xa = ww_xx - yy_zz;                          // (ww + xx - yy - zz)
     if (lo) { ya = x; xa = -y; }
     if (hi) { ya = -x; xa = y; }
   }
@@ -125,7 +128,7 @@ __device__ __forceinline__ T reward_leaf(const RewardInstrK<T>& r, const T* rec,
       break;
     }
     case SOLO_R_FLAT_TORSO:  // rewards.py:256-269: tolerance(sqrt(roll^2 + pitch^2), (-a, a), b)
-      x = roll * roll + pitch * pitch; root = true;
+      x = R::fma(roll, roll, pitch * pitch); root = true;   // (explicit: the same bits in every inlined copy)
       lo = -r.a; hi = r.a; margin = r.b;
       break;
     case SOLO_R_TORSO_HEIGHT:  // rewards.py:362-373: tolerance(z, (a - b, a + b), c)
@@ -134,7 +137,7 @@ __device__ __forceinline__ T reward_leaf(const RewardInstrK<T>& r, const T* rec,
       break;
     case SOLO_R_HORIZ_SPEED: {  // rewards.py:326-338: tolerance(|v_xy|, (a - b, a + b), c)
       const T vx = rec[SOLO_S_LINVEL], vy = rec[SOLO_S_LINVEL + 1];
-      x = vx * vx + vy * vy; root = true;
+      x = R::fma(vx, vx, vy * vy); root = true;
       lo = r.a - r.b; hi = r.a + r.b; margin = r.c;
       break;
     }

@@ -136,11 +136,23 @@ def test_thousand_steps_at_benchmark_scale_f64(name, n, regime):
   # (the stairs: a foot that crosses the edge between a tread cell and a riser cell of the bilinear heightfield crosses a
   # discontinuity of the ground normal - no regime in which the robots MOVE over them keeps nine in ten regular)
   assert regular.mean() > (0.5 if (name, regime) == ('stairs', 'glide') else MIN_REGULAR[regime]), regular.mean()
-  # the bar: the regular robots within 1e-8 on q, q-dot, base pose and base velocity after 1000 steps - 999 in 1000 of
-  # them, and every one within 3e-8: "regular" still allows a 1000-fold amplification, and engine and oracle - two
-  # formulations of the step - differ by 1e-13 per step (measured, profiles/round5_parity_scale_f64.log: one robot of
-  # 7988 at 1.7e-8 on the randomised ground, one of 2527 at 1.2e-8 on the incline, everything else below 1e-8) ...
-  assert np.quantile(worst[regular], 0.999) < 1e-8 and worst[regular].max() < 3e-8, {k: float(v[regular].max()) for k, v in errs.items()}
+  # THE BAR, derived per robot from the oracle's own sensitivity (round 6; round 5 had fitted "every regular robot < 3e-8" to two
+  # measured outliers).  The twin started 1e-10 away and ended `sens` away: the robot amplifies a perturbation made at step 0 by
+  # sens / 1e-10, and one made later by no more.  Engine and oracle - two formulations of the step - disagree by eps per step
+  # (measured above on THIS batch: median 1e-13, 99th percentile up to 4e-12), so after 1000 steps a robot's error is at most
+  #     K x sens,   K = 1000 steps x eps / 1e-10
+  # with eps the 99th percentile of the measured one-step disagreement.  Where that product is small the bar is the hard one:
+  #  * every QUIET robot (twin divergence < 1e-9: no amplification to speak of) within 1e-8 on q, q-dot, base pose, base velocity;
+  #  * every regular robot (twin divergence < 1e-7) within max(1e-8, K x its own twin divergence);
+  #  * and 999 in 1000 of the regular robots within 1e-8 whatever their sensitivity (a statement about the batch, not a bound).
+  quiet = sens < 1e-9
+  K = max(1.0, 1000.0 * float(np.quantile(eps, 0.99)) / 1e-10)
+  bound = np.maximum(1e-8, K * sens)
+  print('   bar: K = %.1f; quiet robots %d, worst %.1e (< 1e-8); regular robots: worst error / own bound %.2g' % (
+    K, int(quiet.sum()), worst[quiet].max() if quiet.any() else 0.0, (worst[regular] / bound[regular]).max()))
+  assert not quiet.any() or worst[quiet].max() < 1e-8, float(worst[quiet].max())
+  assert (worst[regular] <= bound[regular]).all(), float((worst[regular] / bound[regular]).max())
+  assert np.quantile(worst[regular], 0.999) < 1e-8, {k: float(v[regular].max()) for k, v in errs.items()}
   # ... and for the robots at large, chaotic or not: the engine is closer to the oracle than the oracle is to its own twin
   # that started 1e-10 rad away (rounding differences are ~1e-16 per step: the engine behaves like a perturbation far
   # below 1e-10).  99 % of them, not all: a contact that switches between sticking and sliding (or between two cells of
