@@ -54,7 +54,18 @@
 //    accumulator of `v_fma_f32 vD, v[64 + idx], s, vD` pinned, vD = v6 / v8 pass and v7 / v9 / v11 FAIL, in every
 //    kernel: round 2's product was right because the allocator had picked v8.  Stand-alone loops of the same shape,
 //    down to the register numbers (tools/microbench/gpr_idx_hazard*.hip), never fail: the mechanism is not established.
-//    The rule here is the conservative one - no vector instruction in the shadow of either mode switch.
+//    Round 6 (one time-boxed session: profiles/round6_hazard_probe.log; probes 11-14 below, accumulator pinned to v7, the register
+//    that fails): it is an ISSUE-SLOT hazard of the switch, not a property of scalar instructions - ONE instruction of any kind
+//    between s_set_gpr_idx_on and the instruction that uses the index cures it, a v_nop exactly like an s_nop (probe 11: clean);
+//    time in FRONT of the switch is irrelevant (s_nop 7 there: fails); the indexed operand as source 1 (gpr_idx(SRC1)) fails
+//    alike, the VOP2 encoding v_fmac_f32 too (into memory faults); and it needs two waves on the SIMD: at 1024 robots - one wave
+//    per SIMD but for the few SIMDs the dispatcher gives two - 0.3 ... 2.5 % of the robots go wrong, at 2048 (two per SIMD)
+//    nearly all.  That is what a missing interlock between the switch's write of M0 / MODE and the operand fetch of the wave's
+//    NEXT vector instruction would look like when the SIMD issues that instruction back to back (a wave alone issues every >= 4
+//    cycles and never does) - narrowed, not proven: no documentation here names it.
+//    The rule here is the conservative one - no vector instruction in the shadow of either mode switch (and, checked on the
+//    generated code by tools/check_gpr_idx.py: the region between a switch on and its switch off is straight-line - no label, no
+//    branch, no s_waitcnt - and holds exactly one vector instruction).
 //  * (round 5) WHERE the row update waits.  tools/microbench/pgs_row64.hip + gen_row64_scan.py (one wave per SIMD, the f64
 //    row in a straight line, one filler instruction inserted at every position in turn; profiles/round5_microbench_*):
 //    v_fma / v_max / v_add_f64 issue every 4.0 cycles, dependent or not, yet the 19-instruction row took 129 cycles, not
@@ -113,7 +124,15 @@ namespace solo {
 // of s_set_gpr_idx_on; 5 = the cursor shift behind s_set_gpr_idx_on (the product's first shadow), the second shadow
 // empty; 6 = the compiler's own shape - s_set_gpr_idx_on / indexed v_mov_b32 / s_set_gpr_idx_off - and the v_fma on the
 // moved value; 7 = as 6 with s_nop behind s_set_gpr_idx_on
-#if SOLO_PGS_HAZARD_PROBE == 8      /* round 2's order with the accumulator / the broadcast pinned to the registers of the kernels that PASS */
+// round 6 (the time-boxed session VERDICT r5 asked for; tools/gpu_hazard_probe.py, profiles/round6_hazard_probe.log) - all with the
+// accumulator pinned to v7, the register that FAILS in round 2's order: 11 = a VALU no-op (v_nop) in the shadow instead of a scalar
+// one; 12 = the indexed column as SOURCE 1 (gpr_idx(SRC1), the broadcast in source 0); 13 = the two-operand encoding (VOP2
+// v_fmac_f32: no third source operand to collect - the broadcast first moved into a VGPR); 14 = s_nop 7 in FRONT of the switch
+// (time since the v_readlane, none behind the switch)
+#if SOLO_PGS_HAZARD_PROBE >= 11 && SOLO_PGS_HAZARD_PROBE <= 14
+#define SOLO_PGS_V_CONSTRAINT "+{v7}"
+#define SOLO_PGS_SD_CONSTRAINT "=&{s64}"
+#elif SOLO_PGS_HAZARD_PROBE == 8      /* round 2's order with the accumulator / the broadcast pinned to the registers of the kernels that PASS */
 #define SOLO_PGS_V_CONSTRAINT "+{v8}"
 #define SOLO_PGS_SD_CONSTRAINT "=&{s66}"
 #elif SOLO_PGS_HAZARD_PROBE == 9    /* ... and to the registers of the kernels that FAIL */
@@ -129,7 +148,15 @@ namespace solo {
 #define SOLO_PGS_PROBE_IDX_ON "s_set_gpr_idx_on %[rs], gpr_idx(SRC0)\n\t"
 #define SOLO_PGS_PROBE_FMA "v_fma_f32 %[v], v64, %[sd], %[v]\n\ts_set_gpr_idx_off\n\t"
 #define SOLO_PGS_PROBE_MOV_FMA "v_mov_b32_e32 %[thr], v64\n\ts_set_gpr_idx_off\n\tv_fma_f32 %[v], %[thr], %[sd], %[v]\n\t"
-#if SOLO_PGS_HAZARD_PROBE == 2
+#if SOLO_PGS_HAZARD_PROBE == 11
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_IDX_ON "v_nop\n\t" SOLO_PGS_PROBE_FMA
+#elif SOLO_PGS_HAZARD_PROBE == 12
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT "s_set_gpr_idx_on %[rs], gpr_idx(SRC1)\n\t" "v_fma_f32 %[v], %[sd], v64, %[v]\n\ts_set_gpr_idx_off\n\t"
+#elif SOLO_PGS_HAZARD_PROBE == 13
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT "v_mov_b32_e32 %[thr], %[sd]\n\t" SOLO_PGS_PROBE_IDX_ON "v_fmac_f32_e32 %[v], v64, %[thr]\n\ts_set_gpr_idx_off\n\t"
+#elif SOLO_PGS_HAZARD_PROBE == 14
+#define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT "s_nop 7\n\t" SOLO_PGS_PROBE_IDX_ON SOLO_PGS_PROBE_FMA
+#elif SOLO_PGS_HAZARD_PROBE == 2
 #define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_IDX_ON "s_nop 0\n\t" SOLO_PGS_PROBE_FMA
 #elif SOLO_PGS_HAZARD_PROBE == 3
 #define SOLO_PGS_PROBE_CORE SOLO_PGS_PROBE_SHIFT SOLO_PGS_PROBE_IDX_ON SOLO_PGS_PROBE_FMA "s_nop 0\n\t"

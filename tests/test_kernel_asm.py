@@ -27,6 +27,21 @@ def test_the_check_sees_violations(tmp_path):
   n, errors = check_gpr_idx.check(str(bad))
   assert n == 4
   assert len(errors) == 3   # a vector instruction behind the switch; two compiler-generated switches outside a loop
+  # round 6: the region between a switch on and its switch off is straight-line, with the one indexed instruction
+  for body, what in ((['s_lshl_b64 s[0:1], -2, s4', 's_waitcnt lgkmcnt(0)', 'v_fma_f32 v1, v64, s5, v1'], 's_waitcnt'),
+                     (['s_lshl_b64 s[0:1], -2, s4', 's_cbranch_scc0 .L1', 'v_fma_f32 v1, v64, s5, v1'], 's_cbranch'),
+                     (['s_lshl_b64 s[0:1], -2, s4', '.L2:', 'v_fma_f32 v1, v64, s5, v1'], '.L2:'),
+                     (['s_lshl_b64 s[0:1], -2, s4', 'v_fma_f32 v1, v64, s5, v1', 'v_mov_b32_e32 v2, v3', 's_nop 0'], '2 vector'),
+                     (['s_lshl_b64 s[0:1], -2, s4'], '0 vector')):
+    f = tmp_path / 'region.s'
+    f.write_text('\n'.join(['_Z4kern:', '\t;;#ASMSTART', '\ts_set_gpr_idx_on s4, gpr_idx(SRC0)'] + ['\t' + b for b in body] +
+                            ['\ts_set_gpr_idx_off', '\ts_and_b64 s[0:1], s[2:3], s[4:5]', '\t;;#ASMEND', '']))
+    n, errors = check_gpr_idx.check(str(f))
+    assert len(errors) == 1 and what in errors[0], (what, errors)
+  ok = tmp_path / 'ok.s'
+  ok.write_text('\n'.join(['_Z4kern:', '\t;;#ASMSTART', '\ts_set_gpr_idx_on s4, gpr_idx(SRC0)', '\ts_lshl_b64 s[0:1], -2, s4', '\tv_fma_f32 v1, v64, s5, v1',
+                           '\ts_set_gpr_idx_off', '\ts_and_b64 s[0:1], s[2:3], s[4:5]', '\t;;#ASMEND', '']))
+  assert check_gpr_idx.check(str(ok)) == (2, [])
 
 
 def test_resource_budget_of_the_product_kernels():

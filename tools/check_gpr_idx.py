@@ -4,7 +4,8 @@ Round 3 found the step kernel computing wave-dependent garbage when a VECTOR ins
 s_set_gpr_idx_on (solo_pgs_gfx950.h: observed on this kernel, mechanism not established).  The rule the code follows -
 (1) every s_set_gpr_idx_on / s_set_gpr_idx_off is followed by a SCALAR instruction, and (2) the product contains no
 compiler-generated indexed sequence at all (every switch sits inside the hand-written Gauss-Seidel loops, i.e. between
-the ;;#ASMSTART / ;;#ASMEND markers of an inline-asm statement) - is checked here on the generated assembly of EVERY
+the ;;#ASMSTART / ;;#ASMEND markers of an inline-asm statement), and (3) the region between a switch on and its switch off is
+straight-line - no label, branch, s_waitcnt or barrier - with exactly one vector instruction - is checked here on the generated assembly of EVERY
 kernel instantiation, so that a compiler bump or a new dynamically indexed local array cannot bring the failure back
 unnoticed.   usage: python tools/check_gpr_idx.py [file.s]   (default: make -C gym_solo_amd/csrc asm)"""
 import os, re, subprocess, sys
@@ -30,6 +31,27 @@ def check(path):
       in_asm = True
     elif t.startswith(';;#ASMEND'):
       in_asm = False
+    if re.match(r'^s_set_gpr_idx_on\b', t):
+      # (3) the indexed-mode REGION - from the switch on to the switch off - is straight-line and short: no label, no branch,
+      # no s_waitcnt / barrier / sleep inside it (a wave must not be parked, pre-empted at a wait or re-entered with the
+      # mode on), and exactly ONE vector instruction (the indexed one) - round 6, VERDICT r5
+      region, closed = [], False
+      for j in range(i + 1, min(i + 12, len(lines))):
+        u = lines[j].strip()
+        if not u or u.startswith(';') or u.startswith('//'):
+          continue
+        if re.match(r'^s_set_gpr_idx_off\b', u):
+          closed = True
+          break
+        region.append(u)
+      if not closed:
+        errors.append('%s:%d: s_set_gpr_idx_on without an s_set_gpr_idx_off within 10 instructions in %s' % (path, i + 1, func))
+      for u in region:
+        if u.endswith(':') or re.match(r'^(s_cbranch|s_branch|s_waitcnt|s_barrier|s_sleep|s_setpc|s_swappc|s_call|s_endpgm|s_trap|s_sendmsg|\.)', u):
+          errors.append('%s:%d: the indexed-mode region spans `%s` in %s' % (path, i + 1, u, func))
+      if sum(1 for u in region if u.startswith('v_')) != 1:
+        errors.append('%s:%d: the indexed-mode region holds %d vector instructions (expected the indexed one only) in %s' % (
+          path, i + 1, sum(1 for u in region if u.startswith('v_')), func))
     if re.match(r'^s_set_gpr_idx_(on|off)\b', t):
       switches += 1
       if not in_asm:

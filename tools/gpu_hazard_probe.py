@@ -6,6 +6,8 @@ diagnostic builds of `make -C gym_solo_amd/csrc hazard-probes` (-DSOLO_PGS_HAZAR
   5 the cursor shift behind s_set_gpr_idx_on only  6 s_set_gpr_idx_on / indexed v_mov_b32 / off, v_fma on the moved value
   7 as 6 + s_nop                   8 / 9 round 2's order, accumulator + broadcast pinned to v8 / s66 and v7 / s64
   libsolo_hip_probe_<v>_<s>.so     round 2's order with any pinned pair
+  round 6, accumulator pinned to v7 (the failing register): 11 v_nop in the shadow   12 the column as source 1 (gpr_idx(SRC1))
+  13 the VOP2 encoding (v_fmac_f32)   14 s_nop 7 in FRONT of the switch
 in the residual-threshold kernels (which failed in round 3) and in the default ones.  Every build also counts waves
 that leave the loop with the index mode still ON (statistics slot 7) and switches it off there.  2048 robots: no
 variant listed here has ever faulted (one that is NOT built any more - three VGPR sources on the indexed v_fma - did).
@@ -20,6 +22,10 @@ from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
 from gym_solo_amd.workloads import register_benchmark_workload
 
 N = int(os.environ.get('N', '2048'))
+if N > 2048:
+  # round 6: probe 9 (and the VOP2 variant, 13) ended in GPU memory-access FAULTS at 4096 and 8192 robots - garbage columns drive
+  # the states to values whose terrain / table addresses are wild; a fault can reset the whole host's GPUs: never again above 2048
+  raise SystemExit('tools/gpu_hazard_probe.py: N > 2048 is refused (failing probes fault the GPU at 4096 robots: profiles/round6_hazard_probe.log)')
 g = torch.Generator(device='cuda').manual_seed(8)
 one = (torch.rand(8, 1, 12, device='cuda', generator=g) * 2 - 1) * (2 * np.pi)
 for resid in (1e-7, 0.0):
