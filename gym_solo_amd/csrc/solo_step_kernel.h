@@ -157,6 +157,9 @@ template <typename T> constexpr int kRowBlockReals = sizeof(T) == 4 ? 64 * 8 + 6
 #ifndef SOLO_W4_PIPELINED_BUILD
 #define SOLO_W4_PIPELINED_BUILD 0
 #endif
+#ifndef SOLO_W4_HYBRID_BUILD
+#define SOLO_W4_HYBRID_BUILD 1   // (0: the A/B build - no column is pipelined at four waves per SIMD, as in round 5)
+#endif
 constexpr int kLegSlots = 26;  // per-leg parking lot in LDS (see physics_solve): 0-11 K, 12-14 Lp factors, 15-16 unconstrained joint rates, 17-18 q, 19-22 cos / sin of the two link angles, 23-24 P^-1 h
 
 // one lane's constraint-row constants, as the step reads them from LDS (staged from KParams::row once per launch)
@@ -250,7 +253,7 @@ __device__ __forceinline__ int pgs_solve_cpp(const ColumnBank<T>& A, T& v, T& la
 // physics: A3 + A4 of SURVEY.md §8a.  physics_solve reads s_state (old) and returns this lane's
 // constraint impulse; physics_finish writes s_state (new).
 // ------------------------------------------------------------------------------------------
-template <typename T, bool kResid, typename FetchTarget>
+template <typename T, bool kResid, bool kPipelinedBuild, typename FetchTarget>
 __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers<T>& B, const StepTables<T>& tabs,
                                            const T* s_state, T my_target, FetchTarget&& fetch_target, T* s_rowvec, T (*s_hext)[8], unsigned char* s_rowleg,
                                            T* s_keep, T (*s_leg)[kLegSlots], const T* s_math, T mu, T mass_scale, int lane, int& row_at, bool& target_bad,
@@ -839,7 +842,38 @@ __device__ __forceinline__ T physics_solve(const StepConst<T>& C, const KBuffers
     // (software-pipelined by one slot: the row of slot r + 1 is fetched - eight LDS broadcasts - in front of the arithmetic
     // of slot r, across the tests too: a wave alone on its SIMD, the slow robot at the end of a launch, otherwise sits
     // out an LDS round trip at the head of every triple)
-    if constexpr (SOLO_F64_WAVES >= 4 && !SOLO_W4_PIPELINED_BUILD) {
+    if constexpr (SOLO_F64_WAVES >= 4 && SOLO_W4_HYBRID_BUILD && kPipelinedBuild) {
+      // round 6: pipelined by ONE row while the second half of the bank is still dead.  A second row in flight (17 VGPRs) does
+      // not fit next to the FULL bank (round 5: 64 spills) - but the bank fills progressively, and until slot 16 is written its
+      // upper tuple (32 VGPRs) is free: the columns of slots 0 .. 16 (as far as the registers reach: three more and four values are reloaded from scratch inside the step) - all the columns of the common robot-step (8 motor rows +
+      // up to three touching spheres) - are built with the next slot's row fetched behind the arithmetic of this one (a wave
+      // alone on its SIMD otherwise sits out an LDS round trip per column), the slots beyond as before.
+      typename ColumnBank<T>::Row cur = A.fetch(0);
+      {
+        typename ColumnBank<T>::Row nxt = A.fetch(1);
+        A.build_from(0, cur);
+        cur = A.fetch(2);
+        A.build_from(1, nxt);
+      }
+#pragma unroll
+      for (int j = 2; j < ColumnBank<T>::kSlots; j += 3) {
+        if (n_live > j) {
+          if (j + 2 < 17) {
+            typename ColumnBank<T>::Row nxt = A.fetch(j + 1);
+            A.build_from(j, cur);
+            cur = A.fetch(j + 2);
+            A.build_from(j + 1, nxt);
+            nxt = A.fetch(j + 3);                 // (the next triple's first row; a slot beyond L holds zeros)
+            A.build_from(j + 2, cur);
+            cur = nxt;
+          } else {
+            if (j == 17) A.build_from(j, cur); else A.build(j);
+            if (j + 1 < ColumnBank<T>::kSlots) A.build(j + 1);
+            if (j + 2 < ColumnBank<T>::kSlots) A.build(j + 2);
+          }
+        }
+      }
+    } else if constexpr (SOLO_F64_WAVES >= 4 && !SOLO_W4_PIPELINED_BUILD) {
       // (four waves per SIMD - the A/B build: 128 VGPRs have no room for a second row in flight)
       A.build(0); A.build(1);
 #pragma unroll
@@ -1400,7 +1434,9 @@ __global__ __launch_bounds__(64, kWavesPerSimd<T>) void solo_step_kernel(const K
       const T my_target = kLean ? T(0) : fetch_target(lane);
       bool target_bad = false;  // (set on a motor lane whose target is not finite)
       int row_at;  // where this lane's constraint row sits in s_rowvec / s_hext (its lane, or its slot: see physics_solve)
-      const T lam = physics_solve<T, kResid>(C, B, tabs, s_state, my_target, fetch_target, s_rowvec, s_hext, s_rowleg, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, target_bad, prio_sweeps, prio_steps, prio_rot,
+      // (the pipelined column build: the default-solver kernels whose robots do not migrate - the others, with a value or two more
+      // live across the step, would reload them from scratch inside it)
+      const T lam = physics_solve<T, kResid, !kResid && !kMigrate>(C, B, tabs, s_state, my_target, fetch_target, s_rowvec, s_hext, s_rowleg, s_keep, s_leg, s_math, mu, mass_scale, lane, row_at, target_bad, prio_sweeps, prio_steps, prio_rot,
                                              warm_in, kResid && warm_row != nullptr);
       if constexpr (kResid) if (warm_row != nullptr) {
         if constexpr (kMigrate) wave_store_shared(warm_row + (size_t)env * 64 + lane, lam);

@@ -215,6 +215,49 @@ def test_view_holds_the_last_done_flags_of_a_physics_and_done_only_rollout(dtype
   env._close()
 
 
+
+def test_a_fused_rollout_is_capturable_after_reserve():
+  """the per-launch scratch of fused launches grows lazily - a device synchronisation and an allocation the FIRST time a
+  larger rollout geometry is seen, neither of which a stream capture allows.  solo_engine_reserve (ABI 6) does that work ahead of
+  time: after reserve(K) a recording rollout of K steps - several fused launches on two stream slices (fork / join through
+  events), migration queues - is captured in a torch.cuda.CUDAGraph WITHOUT ever having run eagerly, and its replays equal an eager
+  engine's rollouts bit for bit."""
+  import torch
+  from gym_solo_amd import abi
+  from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig
+  from gym_solo_amd.workloads import register_benchmark_workload
+  envs = []
+  for _ in range(2):
+    cfg = Solo8VanillaConfig()
+    cfg.dtype, cfg._dtype_pinned, cfg.auto_reset = 'float64', True, True
+    cfg.num_envs, cfg._num_envs_pinned, cfg.steps_per_launch, cfg.rollout_streams, cfg.migrate_steps = 256, True, 16, 2, 5
+    env = make_env(config=cfg, copy_outputs=False)
+    register_benchmark_workload(env, max_steps=9)
+    env._ensure_program()
+    envs.append(env)
+  eager, captured = envs
+  n, k = eager.num_envs, 40
+  g = torch.Generator(device='cuda').manual_seed(13)
+  static = torch.zeros(k, n, 12, device='cuda', dtype=torch.float64)
+  out = captured.engine.rollout_buffers(k)
+  captured.engine.reserve(k)                 # (the captured engine has never launched a rollout)
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    captured.engine.rollout(static, abi.STEP_ALL, out=out)
+  for rep in range(3):
+    acts = (torch.rand(k, n, 12, device='cuda', dtype=torch.float64, generator=g) * 2 - 1) * 6.28
+    want = eager.engine.rollout(acts, abi.STEP_ALL, record=True)
+    static.copy_(acts)
+    graph.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(want, out):
+      assert torch.equal(x, y), rep
+    assert torch.equal(eager.engine.state, captured.engine.state), rep
+  assert captured.engine.stats.cpu().numpy()[6] == 0
+  for env in envs:
+    env._close()
+
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
 def test_step_is_capturable_in_a_hip_graph(dtype):
   """The engine enqueues everything on the caller's stream and never synchronises inside step(): an RL library can
