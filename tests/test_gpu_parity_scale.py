@@ -46,7 +46,7 @@ def _actions(regime, k0, k1, n, rng_params):
 # perturbation beyond 1e-7 in ANY arithmetic.  `glide` (round 5): the same sway about the straight-legged stand on
 # SLIPPERY ground (friction 0.1; randomised: ~U(0.05, 0.15)) - feet that slide all the time, no stick-slip transitions:
 # the moving regime in which (almost) every robot is regular and is held to the hard bar.  (Measured on the oracle,
-# profiles/round5_parity_scale_f64.log: smaller sway amplitudes or MORE friction make the motion less regular, not
+# profiles/round6_parity_scale_f64.log: smaller sway amplitudes or MORE friction make the motion less regular, not
 # more - friction 1.0 leaves 5 % of the robots regular.)
 GLIDE_FRICTION = 0.1
 # share of the robots that must be regular (the oracle's own 1e-10 twin within 1e-7), per ground and regime
