@@ -161,3 +161,61 @@ def belly_on_incline(n, lift=5e-4):
   for leg in range(4):
     acts[:, 3 * leg] = np.pi
   return st, acts
+
+
+# ---- (e) the joint-limit row ([recalled] btMultiBodyJointLimitConstraint; limits: the reference's getJointInfo fixture) -------
+def joints_running_into_limits(n, limit=10.0, margin=0.5, seed=4):
+  """n robots afloat, no gravity, motors WITHOUT torque (motor_torque_limit = 0: their rows are pinned to zero impulse), at rest
+  but for ONE joint per robot, which sits C inside a limit (0.01 ... 0.3 rad, within joint_limit_margin) and moves towards it at s
+  rad/s - some slow enough to stay inside within the step (s dt < C: the row must do NOTHING), some fast enough to cross it (the
+  row must stop them at the speed that just reaches the limit, C / dt).  Returns (states, dof, side (+1 upper / -1 lower), C, s)."""
+  rng = np.random.default_rng(seed)
+  st = np.zeros((n, abi.STATE_STRIDE))
+  st[:, abi.S_POS + 2] = 2.0
+  q = rng.normal(size=(n, 4))
+  st[:, abi.S_QUAT:abi.S_QUAT + 4] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  st[:, abi.S_Q:abi.S_Q + 8] = rng.uniform(-1.5, 1.5, (n, 8))
+  dof = rng.integers(0, 8, n)
+  side = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+  c = rng.uniform(0.01, 0.3, n)
+  fast = rng.random(n) < 0.6
+  s = np.where(fast, rng.uniform(1.2, 4.0, n), rng.uniform(0.05, 0.9, n)) * c / 1e-3   # relative to C / dt (dt = 1e-3)
+  st[np.arange(n), abi.S_Q + dof] = side * (limit - c)
+  st[np.arange(n), abi.S_QD + dof] = side * s
+  return st, dof, side, c, s
+
+
+def check_joint_limit_against_free(M, pre, post, free, dof, side, c, dt):
+  """The joint's rate TOWARDS its limit after the step is min(what it would be without the row, C / dt) - a unilateral row in
+  speculative form: it acts only if the joint would cross the limit within the step, and then leaves it exactly ON the limit - and
+  what the row adds to the step's generalised impulse, M(q) (u_post - u_free), is zero everywhere but on that joint's row, where it
+  pushes AWAY from the limit.  `free` = the state after the same step from the same state with the limits far away (a single moving
+  joint has velocity-product forces: they are in both).  M: the oracle's CRBA mass matrix at `pre`.
+  Returns (rate error, largest off-row impulse, sign violation, whether the row acted)."""
+  R = rot(pre[abi.S_QUAT:abi.S_QUAT + 4])
+  def gen(s):
+    return np.concatenate([R.T @ s[VEL[0]], R.T @ s[VEL[1]], s[VEL[2]]])
+  imp = M @ (gen(post) - gen(free))             # what the limit row added to the step
+  towards_free = side * free[abi.S_QD + dof]    # the rate towards the limit without the row
+  towards = side * post[abi.S_QD + dof]
+  want = min(towards_free, c / dt)
+  lam = -side * imp[6 + dof]                    # the row's impulse, counted AWAY from the limit
+  off = np.abs(np.delete(imp, 6 + dof)).max()
+  return abs(towards - want), off, max(0.0, -lam), (lam > 1e-12)
+
+
+# ---- (f) link damping ([recalled] btMultiBody: - m v k (1 + |v|) per link; configs.py:21-22 set k for every link) ------------------
+def translating_afloat(n, seed=6):
+  """n robots afloat in random poses, no gravity, no joint motion, no rotation: every link moves with the same velocity v0, so the
+  total damping force is - m_total k (1 + |v0|) v0 and one explicit-Euler step leaves v0 (1 - dt k (1 + |v0|)), nothing else."""
+  rng = np.random.default_rng(seed)
+  st = np.zeros((n, abi.STATE_STRIDE))
+  st[:, abi.S_POS + 2] = 2.0
+  q = rng.normal(size=(n, 4))
+  st[:, abi.S_QUAT:abi.S_QUAT + 4] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  st[:, abi.S_Q:abi.S_Q + 8] = rng.uniform(-1.5, 1.5, (n, 8))
+  st[:, abi.S_LINVEL:abi.S_LINVEL + 3] = rng.uniform(-3.0, 3.0, (n, 3))
+  acts = np.zeros((n, abi.NUM_JOINTS))
+  for d in range(abi.NUM_DOF):
+    acts[:, 3 * (d // 2) + d % 2] = st[:, abi.S_Q + d]     # the motors hold the pose (nothing for them to do)
+  return st, acts

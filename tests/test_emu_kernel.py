@@ -475,3 +475,32 @@ def test_base_link_friction_on_the_kernel_source(leg_mu, base_mu, slides):
       got, want = cf.check_coulomb_step(mom, pre[0], e.state[0], base_mu, ca.dt)
       assert (abs(got - want) < 1e-11 * abs(want)) if slides else (abs(got) < 1e-10)
       assert (mom(e.state[0]) @ cf.T1_SLOPE < -0.05) == slides
+
+
+def test_closed_form_joint_limit_and_damping_on_the_kernel_source():
+  import closed_form_cases as cf
+  from gym_solo_amd.model import Solo8Model
+  ca, ma = make_abi('float64', gravity=(0., 0., 0.), linear_damping=0.0, angular_damping=0.0, motor_torque_limit=0.0)
+  far = Solo8Model().to_abi()
+  for j in range(abi.NUM_DOF):
+    far.joint_lower[j], far.joint_upper[j] = -1e3, 1e3
+  n = 16
+  ph, _ = _kin(ca, ma)
+  st, dof, side, c, s = cf.joints_running_into_limits(n, margin=ca.joint_limit_margin)
+  e, f = EmuEngine(ca, ma, n), EmuEngine(ca, far, n)
+  e.state[:] = st; f.state[:] = st
+  zero = np.zeros((n, 12))
+  e.step(zero, abi.STEP_PHYSICS); f.step(zero, abi.STEP_PHYSICS)
+  for i in range(n):
+    M = np.array(ph.step_debug(st[i].copy(), np.zeros(8)).M).reshape(abi.NV, abi.NV)
+    rate, off, sign, on = cf.check_joint_limit_against_free(M, st[i], e.state[i], f.state[i], dof[i], side[i], c[i], ca.dt)
+    assert rate < 1e-10 and off < 1e-13 and sign == 0.0, (i, rate, off, sign)
+  ca, ma = make_abi('float64', gravity=(0., 0., 0.))
+  st, acts = cf.translating_afloat(n)
+  e = EmuEngine(ca, ma, n)
+  e.state[:] = st
+  e.step(acts, abi.STEP_PHYSICS)
+  v0 = st[:, abi.S_LINVEL:abi.S_LINVEL + 3]
+  want = v0 * (1 - ca.dt * ca.linear_damping * (1 + np.linalg.norm(v0, axis=1, keepdims=True)))
+  np.testing.assert_allclose(e.state[:, abi.S_LINVEL:abi.S_LINVEL + 3], want, rtol=0, atol=1e-13)
+  assert np.abs(e.state[:, abi.S_ANGVEL:abi.S_ANGVEL + 3]).max() < 1e-13 and np.abs(e.state[:, abi.S_QD:abi.S_QD + 8]).max() < 1e-13

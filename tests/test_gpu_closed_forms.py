@@ -235,3 +235,51 @@ def test_the_base_link_keeps_its_own_friction_gpu(leg_mu, base_mu, slides):
     else:
       assert np.abs(v).max() < 1e-9 and abs(got) < 1e-11
   eng.close()
+
+
+def test_joint_limit_rows_at_benchmark_scale():
+  """4096 robots, one joint each running into its URDF limit (the reference's fixture: -10 / +10 rad): against the same step of an
+  engine whose limits are far away, the row stops a joint that would cross exactly on the limit (rate C / dt), leaves one that
+  would not alone, and adds an impulse to that joint's row only, pushing away from the limit.  M(q): the oracle's CRBA."""
+  import torch
+  import closed_form_cases as cf
+  from gym_solo_amd.engine import Engine
+  from gym_solo_amd.model import Solo8Model
+  eng, ca, ma = _engine(N, gravity=(0., 0., 0.), linear_damping=0.0, angular_damping=0.0, motor_torque_limit=0.0, settle_steps=1)
+  far = Solo8Model().to_abi()
+  for j in range(abi.NUM_DOF):
+    far.joint_lower[j], far.joint_upper[j] = -1e3, 1e3
+  free = Engine(ca, far, N)
+  ph, _ = _momentum_fn(ca, ma)
+  st, dof, side, c, s = cf.joints_running_into_limits(N, margin=ca.joint_limit_margin)
+  zero = torch.zeros(N, 12, device='cuda', dtype=torch.float64)
+  for e in (eng, free):
+    _put(e, st)
+    e.step(zero, abi.STEP_PHYSICS)
+  post, post_free = eng.state.cpu().numpy(), free.state.cpu().numpy()
+  worst, acted = np.zeros(3), 0
+  for i in range(N):
+    M = np.array(ph.step_debug(st[i].copy(), np.zeros(8)).M).reshape(abi.NV, abi.NV)
+    rate, off, sign, on = cf.check_joint_limit_against_free(M, st[i], post[i], post_free[i], dof[i], side[i], c[i], ca.dt)
+    worst = np.maximum(worst, [rate, off, sign])
+    acted += int(on)
+  assert worst[0] < 1e-10 and worst[1] < 1e-13 and worst[2] == 0.0, worst
+  assert 1500 < acted < 3500
+  eng.close(); free.close()
+
+
+def test_link_damping_of_a_pure_translation_at_benchmark_scale():
+  """4096 robots translating afloat (no rotation, no joint motion, no gravity): one step leaves v0 (1 - dt k (1 + |v0|)) with
+  k = linear_damping (gym_solo/core/configs.py:21 through changeDynamics, solo8v2vanilla.py:158-163) and nothing else moves."""
+  import torch
+  import closed_form_cases as cf
+  eng, ca, ma = _engine(N, gravity=(0., 0., 0.), settle_steps=1)
+  st, acts = cf.translating_afloat(N)
+  _put(eng, st)
+  eng.step(torch.as_tensor(acts, device='cuda'), abi.STEP_PHYSICS)
+  post = eng.state.cpu().numpy()
+  v0 = st[:, abi.S_LINVEL:abi.S_LINVEL + 3]
+  want = v0 * (1 - ca.dt * ca.linear_damping * (1 + np.linalg.norm(v0, axis=1, keepdims=True)))
+  np.testing.assert_allclose(post[:, abi.S_LINVEL:abi.S_LINVEL + 3], want, rtol=0, atol=1e-13)
+  assert np.abs(post[:, abi.S_ANGVEL:abi.S_ANGVEL + 3]).max() < 1e-13 and np.abs(post[:, abi.S_QD:abi.S_QD + 8]).max() < 1e-13
+  eng.close()

@@ -321,3 +321,51 @@ def test_the_base_link_keeps_its_own_friction(leg_mu, base_mu, slides):
     assert abs(got - want) < 1e-12 * abs(want) + 1e-15
   else:
     assert np.abs(v).max() < 1e-9 and abs(got) < 1e-12
+
+
+def _far_limits():
+  ma = Solo8Model().to_abi()
+  for j in range(abi.NUM_DOF):
+    ma.joint_lower[j], ma.joint_upper[j] = -1e3, 1e3
+  return ma
+
+
+def test_joint_limit_row_stops_the_joint_on_the_limit():
+  """URDF limits -10 / +10 rad (the reference's getJointInfo fixture, test_obs_observations.py:123-162 columns 8-9): a joint that
+  would cross its limit within the step ends the step moving at exactly the rate that reaches the limit (C / dt), one that would
+  not is left alone, and what the row adds to the step is an impulse on that joint's row only, pushing away from the limit."""
+  import closed_form_cases as cf
+  from helpers import make_abi
+  ca, ma = make_abi('float64', gravity=(0., 0., 0.), linear_damping=0.0, angular_damping=0.0, motor_torque_limit=0.0)
+  ph, ph_free = so.OraclePhysics(ca, ma), so.OraclePhysics(ca, _far_limits())
+  n = 48
+  st, dof, side, c, s = cf.joints_running_into_limits(n, margin=ca.joint_limit_margin)
+  pre, free = st.copy(), st.copy()
+  zero = np.zeros((n, 12))
+  ph.step(st, zero)
+  ph_free.step(free, zero)
+  acted = 0
+  for i in range(n):
+    M = np.array(ph.step_debug(pre[i].copy(), np.zeros(8)).M).reshape(abi.NV, abi.NV)
+    rate, off, sign, on = cf.check_joint_limit_against_free(M, pre[i], st[i], free[i], dof[i], side[i], c[i], ca.dt)
+    assert rate < 1e-10 and off < 1e-13 and sign == 0.0, (i, rate, off, sign)
+    assert on == (s[i] > c[i] / ca.dt * (1 + 1e-9)) or abs(s[i] - c[i] / ca.dt) < 1e-3 * s[i]   # (the row acts iff the joint would cross)
+    acted += int(on)
+  assert 10 < acted < n - 10
+
+
+def test_link_damping_of_a_pure_translation():
+  """linearDamping 0.04 on every link (gym_solo/core/configs.py:21, solo8v2vanilla.py:158-163), [recalled] Bullet's form
+  - m v k (1 + |v|): a robot translating without rotation or joint motion loses v0 dt k (1 + |v0|) in one explicit-Euler step -
+  every link alike, so nothing else starts to move."""
+  import closed_form_cases as cf
+  from helpers import make_abi
+  ca, ma = make_abi('float64', gravity=(0., 0., 0.))
+  ph = so.OraclePhysics(ca, ma)
+  st, acts = cf.translating_afloat(32)
+  pre = st.copy()
+  ph.step(st, acts)
+  v0 = pre[:, abi.S_LINVEL:abi.S_LINVEL + 3]
+  want = v0 * (1 - ca.dt * ca.linear_damping * (1 + np.linalg.norm(v0, axis=1, keepdims=True)))
+  np.testing.assert_allclose(st[:, abi.S_LINVEL:abi.S_LINVEL + 3], want, rtol=0, atol=1e-13)
+  assert np.abs(st[:, abi.S_ANGVEL:abi.S_ANGVEL + 3]).max() < 1e-13 and np.abs(st[:, abi.S_QD:abi.S_QD + 8]).max() < 1e-13
