@@ -6,7 +6,7 @@ contact-build phases show one trip).  Used to see which phases carry the VALU wo
 """
 import sys
 import os, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = '/tmp/solo_stamps.gfx950.s'
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=fast',
                        '-fno-slp-vectorize', *(['-DSOLO_TU_F64', '-mllvm', '-disable-machine-licm'] if (sys.argv[1:] or ['f'])[0] == 'd' else ['-DSOLO_TU_F32']), '-DSOLO_STAMPS', '-S', '--cuda-device-only', '-o', path,
