@@ -283,3 +283,35 @@ def test_link_damping_of_a_pure_translation_at_benchmark_scale():
   np.testing.assert_allclose(post[:, abi.S_LINVEL:abi.S_LINVEL + 3], want, rtol=0, atol=1e-13)
   assert np.abs(post[:, abi.S_ANGVEL:abi.S_ANGVEL + 3]).max() < 1e-13 and np.abs(post[:, abi.S_QD:abi.S_QD + 8]).max() < 1e-13
   eng.close()
+
+
+@pytest.mark.parametrize('leg_mu,base_mu', [(0.1, 0.5), (0.9, 0.1)])
+def test_base_link_friction_in_the_f32_kernels(leg_mu, base_mu):
+  """The opt-in f32 kernels (lane = row, their own assembly loop) carry the base link's coefficient per lane as well: the belly
+  on the incline, 120 steps, f32 HIP engine against the f64 oracle (5e-3: f32's tolerance over a slide) - and the robot slides
+  exactly when the BASE coefficient is below tan(theta)."""
+  import torch
+  import closed_form_cases as cf
+  from helpers import incline_terrain
+  from gym_solo_amd.engine import Engine
+  from oracle import solo_oracle as so
+  if not torch.cuda.is_available():
+    pytest.fail('GPU tests need a visible MI355X')
+  n = 256
+  ca, ma = make_abi('float32', lateral_friction=leg_mu, base_lateral_friction=base_mu, linear_damping=0.0, angular_damping=0.0, settle_steps=10)
+  terr = incline_terrain(10.0)
+  eng = Engine(ca, ma, n)
+  eng.set_terrain(terr)
+  ph = so.OraclePhysics(ca, ma, terrain=terr)
+  st, acts = cf.belly_on_incline(n)
+  eng.state.copy_(torch.as_tensor(st, device='cuda', dtype=torch.float32))
+  a = torch.as_tensor(acts, device='cuda', dtype=torch.float32)
+  eng.rollout(a.expand(120, n, 12).contiguous(), abi.STEP_PHYSICS)
+  ref = st[:2].copy()
+  for _ in range(120):
+    ph.step(ref, acts[:2])
+  got = eng.state.cpu().numpy().astype(np.float64)
+  np.testing.assert_allclose(got[:, :29], np.tile(ref[0, :29], (n, 1)), rtol=0, atol=5e-3)
+  v_down = -(got[:, abi.S_LINVEL:abi.S_LINVEL + 3] @ cf.T1_SLOPE)
+  assert (v_down.min() > 0.05) if base_mu < np.tan(cf.THETA) else (np.abs(v_down).max() < 1e-4)
+  eng.close()
