@@ -20,7 +20,7 @@ episodic-return statistics vector at the end of the interval (inside the timed r
 
 Timing: after W warm-up steps, EXACTLY K steps are timed between barrier + device synchronisation
 on both sides, max over ranks.  A K-step region can be as short as half a millisecond (the driver
-uses K = 20), so it is repeated (fresh actions, the simulation simply continues) until 0.5 s (or 1000
+uses K = 20), so it is repeated (fresh actions, the simulation simply continues) until 2 s (or 4000
 repeats) have accumulated; `value` / `ms_per_step` are the MEDIAN repeat, min / max / count are
 reported next to it.  Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline`; the same run
 also measures the reference-precision figure (`value_f64`) and the reference-granularity figure
@@ -351,8 +351,8 @@ def main():
   ap.add_argument('--migrate-steps', type=int, default=-1,
                   help='SoloConfig.migrate_steps of the rollouts: robots change waves every this many steps of a launch '
                        '(0 = off; -1, the default = the engine chooses: only when a launch has more robots than the chip has wave slots)')
-  ap.add_argument('--min-seconds', type=float, default=0.5, help='repeat the K-step timed region until this much time ...')
-  ap.add_argument('--max-repeats', type=int, default=1000, help='... or this many repeats have accumulated (round 4: 30 - twenty milliseconds of GPU work at K = 20)')
+  ap.add_argument('--min-seconds', type=float, default=2.0, help='repeat the K-step timed region until this much time ... (round 5: 0.5)')
+  ap.add_argument('--max-repeats', type=int, default=4000, help='... or this many repeats have accumulated (round 4: 30 - twenty milliseconds of GPU work at K = 20; round 5: 1000)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -486,6 +486,18 @@ def main():
     plan = {'steps_per_launch': 1, 'launches': k, 'slices': 1, 'migrate_steps': 0} if closed_loop else eng.plan(k)
     return times, total, eng, env, action_pool, plan
 
+  def action_generation_ms(action_pool, k):
+    """What the timed region leaves out: drawing the K x N x 12 random actions on the device - torch's generator, in
+    front of the barrier.  Measured on its own (device sync on both sides, median of 21) and reported next to `value`."""
+    ts = []
+    for _ in range(21):
+      device_sync()
+      t0 = time.perf_counter()
+      action_pool(k)
+      device_sync()
+      ts.append(time.perf_counter() - t0)
+    return statistics.median(ts) * 1e3
+
   def roofline(dtype, eng, action_pool, k, plan):
     """The dominant kernel of a rollout, measured live: HIP events on the streams its launches are issued on
     (mean over the slices' chains and launches: solo_engine_time_rollout runs the rollout exactly as solo_engine_rollout
@@ -551,6 +563,7 @@ def main():
   log('timed region done: %d repeats, stats all-reduce ok (episodes %.0f)' % (len(times), float(stats[2])))
   elapsed = statistics.median(times)
   roof = roofline(args.dtype, eng, action_pool, k, plan)
+  gen_ms = action_generation_ms(action_pool, k)
   env._close()
   if rank == 0 and not EMU and not args.no_extra:
     floor = critical_path_floor(args.dtype, k, plan)
@@ -623,6 +636,9 @@ def main():
       'timing': {'repeats': len(times), 'statistic': 'median', 'stats_reduction_inside_timed_region': bool(distributed), 'min_ms_per_step': min(times) / k * 1e3,
                  'max_ms_per_step': max(times) / k * 1e3, 'value_best_repeat': world * n * k / min(times),
                  'value_worst_repeat': world * n * k / max(times), 'first_repeats_ms_per_step': [t / k * 1e3 for t in times[:6]],
+                 'action_generation_ms_per_repeat': gen_ms, 'value_including_action_generation': world * n * k / (elapsed + gen_ms * 1e-3),
+                 'action_generation_note': 'the K x N x 12 actions of a repeat are drawn on the device (torch generator) in FRONT of the barrier: outside the timed '
+                                           'region, as the contract prescribes for inputs (resident in HBM when the region starts); measured on its own, device sync on both sides',
                  'note': 'W warm-up steps and one untimed repeat of the timed call first; then each repeat = exactly K steps '
                          'between barrier + device sync on both sides (max over ranks), fresh actions, the simulation '
                          'continues from repeat to repeat; with more than one rank the statistics all-reduce is inside every repeat and is the '
