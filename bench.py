@@ -58,7 +58,7 @@ MAX_STEPS = int(os.environ.get('SOLO_BENCH_MAX_STEPS', '1000'))
 
 
 def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=-1, rollout_streams=-1, residual_threshold=0.0, migrate_steps=-1,
-              warm_start=0.0):
+              warm_start=0.0, ulp_tolerance=None):
   """-1 for the three launch knobs = the engine chooses (SoloConfig's defaults: the measured launch policy lives in the
   engine since round 5, Engine.plan(k) reports it)."""
   from gym_solo_amd.envs.solo8v2vanilla import Solo8VanillaConfig, Solo8VanillaEnv
@@ -73,6 +73,7 @@ def build_env(num_envs, device, dtype, max_steps=MAX_STEPS, steps_per_launch=-1,
   cfg.solver_residual_threshold = residual_threshold
   cfg.solver_warm_start = warm_start
   cfg.migrate_steps = migrate_steps
+  cfg.solver_ulp_tolerance = ulp_tolerance   # (None: the precision's default - 512 half-ulps in f64, 2 in f32: core/configs.py)
   if EMU:
     cfg.settle_steps = 30
   env = Solo8VanillaEnv(config=cfg, copy_outputs=False)
@@ -419,7 +420,7 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
-  def timed(dtype, k, closed_loop, min_seconds, max_repeats, residual_threshold=0.0, steady=True, warm_start=0.0):
+  def timed(dtype, k, closed_loop, min_seconds, max_repeats, residual_threshold=0.0, steady=True, warm_start=0.0, ulp_tolerance=None):
     """Repeats of the K-step timed region on a fresh engine; returns per-repeat seconds (max over
     ranks), the summed episodic statistics of the timed repeats and the engine."""
     tdtype = torch.float32 if dtype == 'float32' else torch.float64
@@ -427,7 +428,7 @@ def main():
     # the closed loop is one solo_engine_step launch per env step by definition; command-line values override
     env = build_env(n, local_rank, dtype, steps_per_launch=1 if closed_loop else args.steps_per_launch,
                     rollout_streams=1 if closed_loop else args.rollout_streams, residual_threshold=residual_threshold,
-                    migrate_steps=0 if closed_loop else args.migrate_steps, warm_start=warm_start)
+                    migrate_steps=0 if closed_loop else args.migrate_steps, warm_start=warm_start, ulp_tolerance=ulp_tolerance)
     eng = env.engine
     gen = torch.Generator(device=dev).manual_seed(rank_seed(1234, rank))
 
@@ -564,6 +565,7 @@ def main():
   elapsed = statistics.median(times)
   roof = roofline(args.dtype, eng, action_pool, k, plan)
   gen_ms = action_generation_ms(action_pool, k)
+  eng_cfg_ulp = eng.cfg.solver_ulp_tolerance
   env._close()
   if rank == 0 and not EMU and not args.no_extra:
     floor = critical_path_floor(args.dtype, k, plan)
@@ -611,6 +613,14 @@ def main():
     extra['value_closed_loop_note'] = ('one solo_engine_step launch per env step (outputs evaluated in that launch), the '
                                        'granularity of Solo8VanillaEnv.step (solo8v2vanilla.py:72-102), actions pre-generated, '
                                        'no host synchronisation between steps; median over repeats of %d steps; headline precision and (suffix) the other one' % ke)
+    # round 5's convergence tolerance (2 half-ulps; the f64 default is 512 since round 6: core/configs.py says why), for continuity
+    if args.dtype == 'float64':
+      tu, _, _, eu, _, _ = timed(args.dtype, ke, False, 0.3, 10, ulp_tolerance=2)
+      extra['value_ulp_tolerance_2'] = world * n * ke / statistics.median(tu)
+      extra['value_ulp_tolerance_2_note'] = ('the same rollout with SoloConfig.solver_ulp_tolerance = 2 half-ulps (1.1e-16 relative), the default up to round 5; `value` runs '
+                                             'with the f64 default of round 6, 512 half-ulps = 5.7e-14 relative - below the rounding noise between two f64 formulations of one '
+                                             'step (1e-13), rest behaviour and parity against the oracle\'s 50 plain sweeps unchanged (profiles/round6_ulp_tolerance_sweep.log)')
+      eu._close()
     # rounds 1-2 timed the first steps of 4096 synchronised episodes (every robot freshly reset, nobody terminating):
     # the same kernels under that lighter regime, so that this round's line can be compared with theirs
     tsy, _, _, esy, _, _ = timed(args.dtype, ke, False, 0.3, 10, steady=False)
@@ -628,9 +638,10 @@ def main():
       'dtype': 'f32' if args.dtype == 'float32' else 'f64', 'data': 'synthetic',
       'config': {'workload': 'BASELINE configs[1]: %d Solo8 envs/GPU, flat ground, POSITION_CONTROL, '
                              'U(-2pi,2pi) actions, TorsoIMU+MotorEncoder obs, stand reward, '
-                             'TimeBasedTermination(%d)+auto-reset, steady state (episode phases spread uniformly by %d untimed steps), dt=1e-3, 50 PGS iterations' % (n, MAX_STEPS, MAX_STEPS),
+                             'TimeBasedTermination(%d)+auto-reset, steady state (episode phases spread uniformly by %d untimed steps), dt=1e-3, <= 50 PGS sweeps (to convergence)' % (n, MAX_STEPS, MAX_STEPS),
                  'envs_per_gpu': n, 'steps_per_launch': plan['steps_per_launch'], 'rollout_streams': plan['slices'], 'migrate_steps': plan['migrate_steps'],
                  'launches_per_slice': plan['launches'], 'waves_per_simd': plan.get('waves_per_simd'),
+                 'solver_iterations': 50, 'solver_ulp_tolerance': int(eng_cfg_ulp),
                  'launch_policy': 'chosen by the engine (SoloConfig -1 defaults; solo_engine_plan)' if (args.steps_per_launch, args.rollout_streams, args.migrate_steps) == (-1, -1, -1) else 'command line',
                  'parallelism': 'env-batch sharded x%d, RCCL all-reduce of return stats only' % world},
       'timing': {'repeats': len(times), 'statistic': 'median', 'stats_reduction_inside_timed_region': bool(distributed), 'min_ms_per_step': min(times) / k * 1e3,

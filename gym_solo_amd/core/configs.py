@@ -13,6 +13,9 @@ import numpy as np
 from gym_solo_amd import abi
 
 
+DEFAULT_ULP_TOLERANCE_F64, DEFAULT_ULP_TOLERANCE_F32 = 512, 2   # (Solo8BaseConfig.solver_ulp_tolerance = None)
+
+
 @dataclass
 class Solo8BaseConfig:
   dt: float = 1e-3
@@ -50,7 +53,15 @@ class Solo8BaseConfig:
   # throughput; one-step joint-rate error ~1e-4 rad/s against the f64 path: DESIGN.md section 6)
   dtype: str = 'float64'
   solver_iterations: int = 50     # Bullet default [recalled]
-  solver_ulp_tolerance: int = 2   # impulse changes of <= this many half-ulps (relative) count as converged (0 = exact)
+  # Convergence of the Gauss-Seidel iteration: a row whose clamped candidate differs from its impulse by at most this many
+  # half-ulps, relative (k x 2^-53 |impulse| in f64, k x 2^-24 in f32), is left alone, and a sweep that updates no row ends the
+  # iteration (0 = only an exact fixed point ends it).  None = the precision's default: **512 in float64** - 5.7e-14 relative, half
+  # of the rounding noise of the step itself (two f64 formulations of one step, the engine's and the oracle's, disagree by 1e-13 in
+  # the median: tests/test_gpu_parity_scale.py measures it) - and 2 in float32 (1.2e-7).  Measured (round 6,
+  # profiles/round6_ulp_tolerance_sweep.log): 0 / 2 / 512 / 4096 half-ulps leave a resting robot's joint rates and the 60-step
+  # parity against the oracle's 50 plain sweeps where they are (5.5e-9 rad/s; 9e-11 / 2e-11 / 6e-11 - and 9e-10 at 4096), and
+  # take the mean sweeps per robot-step from 9.7 to 9.5 / 8.4 / 8.0.  Round 5's default was 2.
+  solver_ulp_tolerance: int = None
   # pybullet's solverResidualThreshold: the Gauss-Seidel iteration ends after a sweep whose largest squared
   # velocity-level change is below it.  pybullet's documented default is 1e-7 [recalled] and gym_solo never changes it -
   # but this solver does not warm-start, and with 1e-7 it leaves a resting robot jittering at 5e-5 rad/s, where the
@@ -144,7 +155,8 @@ def config_to_abi(config, starting_joint_pos=None, joint_ordering=None,
   c.contact_margin = float(config.contact_margin)
   c.joint_limit_margin = float(getattr(config, 'joint_limit_margin', 0.5))
   c.solver_iterations = int(config.solver_iterations)
-  c.solver_ulp_tolerance = int(getattr(config, 'solver_ulp_tolerance', 2))
+  tol = getattr(config, 'solver_ulp_tolerance', None)
+  c.solver_ulp_tolerance = int(tol) if tol is not None else (DEFAULT_ULP_TOLERANCE_F64 if config.dtype == 'float64' else DEFAULT_ULP_TOLERANCE_F32)
   if c.solver_ulp_tolerance < 0:
     raise ValueError('solver_ulp_tolerance must be >= 0')
   c.solver_residual_threshold = float(getattr(config, 'solver_residual_threshold', 0.0))
