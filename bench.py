@@ -615,7 +615,7 @@ def main():
                                        'no host synchronisation between steps; median over repeats of %d steps; headline precision and (suffix) the other one' % ke)
     # round 5's convergence tolerance (2 half-ulps; the f64 default is 512 since round 6: core/configs.py says why), for continuity
     if args.dtype == 'float64':
-      tu, _, _, eu, _, _ = timed(args.dtype, ke, False, 0.3, 10, ulp_tolerance=2)
+      tu, _, _, eu, _, _ = timed(args.dtype, ke, False, 1.0, 2000, ulp_tolerance=2)   # (a sample like `value`'s: a launch lasts 0.55 ... 0.8 ms from repeat to repeat)
       extra['value_ulp_tolerance_2'] = world * n * ke / statistics.median(tu)
       extra['value_ulp_tolerance_2_note'] = ('the same rollout with SoloConfig.solver_ulp_tolerance = 2 half-ulps (1.1e-16 relative), the default up to round 5; `value` runs '
                                              'with the f64 default of round 6, 512 half-ulps = 5.7e-14 relative - below the rounding noise between two f64 formulations of one '
