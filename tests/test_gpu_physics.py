@@ -289,3 +289,37 @@ def test_identical_robots_stay_identical(torch, dtype, n, spl, streams, terrain,
       for a, b in zip(ref, [got[0][0], got[1][0]] + [x[:, 0] for x in got[2:]]):
         np.testing.assert_array_equal(a, b)
     env._close()
+
+
+def test_convergence_tolerance_changes_sweeps_not_physics():
+  """SoloConfig.solver_ulp_tolerance (f64 default 512 half-ulps since round 6; 2 before; 0 = exact fixed point): whatever the
+  tolerance, 60 contact-rich flailing steps stay within 1e-9 of the oracle - whose solver has no convergence test at all and runs
+  its 50 plain sweeps - while the sweeps a robot-step takes go down; and the f32 default stays at 2 (512 f32 half-ulps would be
+  3e-5 relative)."""
+  import torch
+  from gym_solo_amd.engine import Engine
+  from oracle import solo_oracle as so
+  from helpers import make_abi, random_actions
+  if not torch.cuda.is_available():
+    pytest.fail('GPU tests need a visible MI355X')
+  assert make_abi('float64')[0].solver_ulp_tolerance == 512 and make_abi('float32')[0].solver_ulp_tolerance == 2
+  n = 512
+  rng = np.random.default_rng(7)
+  a = np.stack([random_actions(rng, n) for _ in range(60)])
+  ca, ma = make_abi('float64')
+  ref = None
+  sweeps = {}
+  for tol in (0, 2, 512):
+    ca, ma = make_abi('float64', steps_per_launch=60, solver_ulp_tolerance=tol)
+    eng = Engine(ca, ma, n)
+    if ref is None:
+      ph = so.OraclePhysics(ca, ma)
+      ref = eng.state.cpu().numpy().copy()
+      for k in range(60):
+        ph.step(ref, a[k], threads=8)
+    eng.rollout(torch.as_tensor(a, device='cuda'), abi.STEP_PHYSICS)
+    err = np.abs(eng.state.cpu().numpy()[:, :29] - ref[:, :29]).max()
+    sweeps[tol] = float(eng.cost.double().mean())
+    assert err < 1e-9, (tol, err)
+    eng.close()
+  assert sweeps[0] >= sweeps[2] > sweeps[512]
