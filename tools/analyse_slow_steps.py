@@ -7,8 +7,9 @@ import numpy as np
 from gym_solo_amd import abi
 from helpers import make_abi
 import emu_kernel
-d = np.load(os.path.join(ROOT, 'gpurun_out', 'slow_steps.npz'))
-ca, ma = make_abi('float32')
+DTYPE = os.environ.get('DTYPE', 'float32')
+d = np.load(os.path.join(ROOT, 'gpurun_out', 'slow_steps_%s.npz' % DTYPE))
+ca, ma = make_abi(DTYPE)
 e = emu_kernel.EmuEngine(ca, ma, 1, variant='trace')
 lib = e.lib
 lib.solo_emu_trace.restype = C.c_int
